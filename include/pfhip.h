@@ -1,0 +1,124 @@
+/*
+ * pfhip.h — C ABI of libpfhip.so: the MI355X (gfx950) device path of the background
+ * forecasting hot path of nianticlabs/panoptic-forecasting.
+ *
+ * The reference has no FFI of its own for this path: its "native boundary" is
+ * torch.ops.torch_scatter.scatter_min + ATen/cuDNN, reached from
+ *   PCTransformModel.predict  panoptic_forecasting/models/pc_transform/pc_transform_model.py:26-150
+ *   BGModel.predict           panoptic_forecasting/models/bg/bg_model.py:91-102
+ *   hardnet.forward           panoptic_forecasting/models/bg/hardnet.py:353-387
+ * Each entry point below names the reference lines it replaces.  The Python
+ * shims that bind them (ctypes) are panoptic-forecasting_amd/{lib,pc_transform_model,bg_model}.py;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - every buffer is a caller-owned DEVICE pointer (tensor.data_ptr()); C-contiguous;
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *  - calls only enqueue work on `stream`: no allocation, no host sync, no hidden copies
+ *    (plan create/destroy excepted) — they may be captured into a hipGraph;
+ *  - every function returns 0 on success or a negative PF_E* code; pf_last_error() gives
+ *    the thread-local message;
+ *  - one in-flight call per (workspace, stream); plans are immutable after creation and
+ *    may be shared between threads/streams.
+ */
+#ifndef PFHIP_H
+#define PFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_OK 0
+#define PF_EINVAL (-1)    /* bad argument */
+#define PF_EWORKSPACE (-2) /* workspace too small */
+#define PF_EBLOB (-3)     /* malformed weight blob */
+#define PF_EHIP (-4)      /* HIP runtime error (launch, alloc in plan create) */
+#define PF_EUNSUPPORTED (-5)
+
+typedef struct pf_plan pf_plan;
+
+/* ABI version (major*1000 + minor). */
+int pf_version(void);
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char *pf_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Warp + z-buffered splat  — replaces pc_transform_model.py:41-150 (unproject :41-59, cam->vehicle
+ * :63, ego warp :68, vehicle->cam + project :71-78, validity :83-89, sentinel :105, 4-corner
+ * bins :106-117, torch_scatter.scatter_min :118-119, winner gather :120-139).
+ *
+ *   depth      [B,T_total,H,W] f32        depth_mask [B,T_total,H,W] u8 (0/1)
+ *   seg        [B,T_total,H,W,C] u8       C = seg_channels (1, or 3 for is_img)
+ *   Kinv,K     [B,3,3] f32   E,Einv [B,4,4] f32   T_tgt [B,T_total,4,4] f32
+ *     (Kinv/Einv are the caller's torch.inverse(K)/torch.inverse(E): LAPACK bits decide floor())
+ *   frames t_first .. t_first+T-1 are warped (only_this_ind => t_first=ind, T=1; else 0, T_total).
+ *   per_frame = 0: all T frames share ONE z-buffer (reference semantics of a single predict call)
+ *                  out_seg [B,H,W,C] u8, out_depth [B,H,W] f32
+ *   per_frame = 1: every frame gets its own z-buffer and its own sentinel, i.e. T independent
+ *                  only_this_ind=t calls in one launch: out_seg [B,T,H,W,C], out_depth [B,T,H,W]
+ *   out_result2d (nullable) [B,T,H,W,2] i64: clamped (x,y) of the floor/floor corner (:147)
+ *
+ * Winner rule: minimum depth; ties -> lowest source element index e = r*P + t*N + n (r = corner
+ * replica 0..3, P = T*N), which is pytorch_scatter's CPU rule.  Bins reached only by invalid
+ * points yield seg=0, depth=max+1 (:105,:133); untouched bins seg=0, depth=-1 (:136-138).
+ * Out of contract: non-finite projected coordinates, |z| >= 2^24.
+ */
+int pf_warp_splat_workspace(int B, int T, int H, int W, int per_frame, size_t *bytes);
+int pf_warp_splat(const float *depth, const uint8_t *depth_mask, const uint8_t *seg, int seg_channels,
+                  const float *Kinv, const float *E, const float *T_tgt, const float *Einv,
+                  const float *K, int B, int T_total, int t_first, int T, int H, int W, int per_frame,
+                  uint8_t *out_seg, float *out_depth, int64_t *out_result2d,
+                  void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FC-HarDNet-70 bg network — replaces bg_model.py:53-71,91-102 and hardnet.py:353-387.
+ *
+ * The plan is built from a weight blob (layout: panoptic-forecasting_amd/packing.py — op table +
+ * BN-folded fp32 OIHW weights).  Plan creation uploads/re-tiles the weights (allocates device
+ * memory once); forward calls allocate nothing.
+ */
+int pf_hardnet_plan_create(const void *blob_host, size_t bytes, int in_ch, int n_cls, pf_plan **out);
+void pf_hardnet_plan_destroy(pf_plan *plan);
+int pf_hardnet_workspace(const pf_plan *plan, int B, int H, int W, size_t *bytes);
+
+/* hop_flags: emulate the reference's on-disk hop between the two tasks on the fly */
+#define PF_HOP_NONE 0
+#define PF_HOP_TRAINID_LUT 1 /* seg ids -> trainIds (export_cityscapes_segmentation_results.py:34-38) */
+#define PF_HOP_DEPTH_U16 2   /* depth -> round(clamp(d+1,0,255)*256) u16 (:119-124) -> x/256-1, mask=d>0,
+                                d[~mask]=-1, clamp to [min_depth,max_depth] (bg_dataset.py:224-230,166-170);
+                                depth_mask argument is ignored (may be NULL) */
+
+/*
+ * Fused forward: one-hot of T label maps (labels >= n_cls -> zero vector, bg_model.py:53-59) +
+ * normalised masked depth (:50-51,:66-68) feed the stem conv directly (the [B,36,H,W] tensor is never
+ * materialised), then hardnet (hardnet.py:353-371), bilinear align_corners upsample to (out_h,out_w)
+ * (:372-384) and argmax (bg_model.py:98).
+ *   seg   [B,T,H,W] u8 or i64 (seg_is_i64)      depth [B,T,H,W] f32     depth_mask [B,T,H,W] u8
+ *   out_seg [B,out_h,out_w] u8 or i64 (out_seg_is_i64)
+ *   out_logits (nullable) [B,n_cls,out_h,out_w] f32; out_orig_logits (nullable) [B,n_cls,H/4,W/4] f32
+ */
+int pf_bg_forward(const pf_plan *plan, const void *seg, int seg_is_i64, const float *depth,
+                  const uint8_t *depth_mask, float depth_mean, float depth_std, int hop_flags,
+                  float min_depth, float max_depth, int B, int T, int H, int W, int out_h, int out_w,
+                  void *out_seg, int out_seg_is_i64, float *out_logits, float *out_orig_logits,
+                  void *ws, size_t ws_bytes, void *stream);
+
+/* Dense-input forward (convert2onehot=False configurations, bg_model.py:61-71): x [B,in_ch,H,W] f32. */
+int pf_hardnet_forward_dense(const pf_plan *plan, const float *x, int B, int H, int W, int out_h,
+                             int out_w, void *out_seg, int out_seg_is_i64, float *out_logits,
+                             float *out_orig_logits, void *ws, size_t ws_bytes, void *stream);
+
+/* Introspection for per-stage parity tests: where tensor `name` (packing.py tensor names, e.g.
+ * "base.4.out") lives inside the workspace for this (B,H,W): byte offset, channels, height, width. */
+int pf_hardnet_tensor_view(const pf_plan *plan, const char *name, int B, int H, int W,
+                           size_t *ws_offset, int *channels, int *h, int *w);
+/* Dense-equivalent FLOPs of one forward at (H,W) per sample (2*Cout*Hout*Wout*Cin*k*k summed). */
+int pf_hardnet_flops(const pf_plan *plan, int H, int W, double *flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFHIP_H */

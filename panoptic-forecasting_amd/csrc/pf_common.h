@@ -1,0 +1,31 @@
+// Internal helpers shared by the translation units of libpfhip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/pfhip.h"
+
+namespace pf {
+
+// thread-local last-error text (pf_last_error)
+char *error_buffer();
+int fail(int code, const char *fmt, ...);
+
+#define PF_HIP_CHECK(expr)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) return pf::fail(PF_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define PF_LAUNCH_CHECK(what)                                                                \
+    do {                                                                                     \
+        hipError_t _e = hipGetLastError();                                                   \
+        if (_e != hipSuccess) return pf::fail(PF_EHIP, "%s: %s", what, hipGetErrorString(_e)); \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace pf

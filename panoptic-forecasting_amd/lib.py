@@ -1,0 +1,69 @@
+"""ctypes binding of ``csrc/libpfhip.so`` (C ABI: include/pfhip.h).
+
+The HIP library is the only implementation of the device path: if it is missing or
+fails to load this module raises — there is no CPU or PyTorch fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libpfhip.so')
+
+_c = ctypes
+_vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
+
+SIGNATURES = {
+    'pf_version': (_i, []),
+    'pf_last_error': (_c.c_char_p, []),
+    'pf_warp_splat_workspace': (_i, [_i, _i, _i, _i, _i, _c.POINTER(_sz)]),
+    'pf_warp_splat': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
+                           _vp, _vp, _vp, _vp, _sz, _vp]),
+    'pf_hardnet_plan_create': (_i, [_vp, _sz, _i, _i, _c.POINTER(_vp)]),
+    'pf_hardnet_plan_destroy': (None, [_vp]),
+    'pf_hardnet_workspace': (_i, [_vp, _i, _i, _i, _c.POINTER(_sz)]),
+    'pf_bg_forward': (_i, [_vp, _vp, _i, _vp, _vp, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i,
+                           _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    'pf_hardnet_forward_dense': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    'pf_hardnet_tensor_view': (_i, [_vp, _c.c_char_p, _i, _i, _i, _c.POINTER(_sz), _c.POINTER(_i),
+                                    _c.POINTER(_i), _c.POINTER(_i)]),
+    'pf_hardnet_flops': (_i, [_vp, _i, _i, _c.POINTER(_c.c_double)]),
+}
+
+_lib = None
+
+
+class PfError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpfhip.so (once) and type its entry points; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PfError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                          '(make -C panoptic-forecasting_amd/csrc). There is no fallback path.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the ABI symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise PfError('%s failed (%d): %s' % (what, rc, load().pf_last_error().decode()))
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise PfError('%s must live on the GPU (got %s): the HIP path has no CPU fallback' % (name, t.device))
+    if not t.is_contiguous():
+        raise PfError('%s must be contiguous' % name)
+    return t
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -9,9 +9,9 @@ and serialises the op table of ``hardnet_arch.Spec`` plus the folded weights.
 
 Blob layout (little endian, all offsets from the start of the blob):
 
-  header   64 B : magic "PFHNET01", u32 version, n_tensors, n_ops, in_ch, n_cls, pad,
+  header   64 B : magic "PFHNET02", u32 version, n_tensors, n_ops, in_ch, n_cls, pad,
                   u64 tensor_table_off, op_table_off, weights_off, total_bytes
-  tensors  n_tensors x {u32 channels, u32 pad}
+  tensors  n_tensors x 48 B {u32 channels, u32 pad, char name[40]}
   ops      n_ops x 128 B {u32 kind,k,stride,relu,cin,cout,n_src,dst,dst_choff,pad[3],
                           {u32 tensor,choff,ch}[4], u64 w_off, u64 b_off, pad to 128}
   weights  fp32: per conv OIHW [cout][cin][k][k] then bias[cout]  (w_off/b_off in floats)
@@ -23,8 +23,9 @@ import torch
 
 from . import hardnet_arch as arch
 
-MAGIC = b'PFHNET01'
-VERSION = 1
+MAGIC = b'PFHNET02'
+VERSION = 2
+TENSOR_BYTES = 48
 OP_BYTES = 128
 MAX_SRC = 4
 BN_EPS = 1e-5  # nn.BatchNorm2d default, as constructed at hardnet.py:21
@@ -72,14 +73,14 @@ def pack_blob(sd, in_ch=36, n_cls=11, prefix='model.'):
     weights = np.concatenate(chunks).astype('<f4')
 
     t_off = 64
-    o_off = t_off + 8 * len(spec.tensors)
+    o_off = t_off + TENSOR_BYTES * len(spec.tensors)
     wts_off = (o_off + OP_BYTES * len(spec.ops) + 63) // 64 * 64
     total = wts_off + weights.nbytes
     out = bytearray(total)
     struct.pack_into('<8sIIIIII4Q', out, 0, MAGIC, VERSION, len(spec.tensors), len(spec.ops), in_ch,
                      n_cls, 0, t_off, o_off, wts_off, total)
     for i, t in enumerate(spec.tensors):
-        struct.pack_into('<II', out, t_off + 8 * i, t.channels, 0)
+        struct.pack_into('<II40s', out, t_off + TENSOR_BYTES * i, t.channels, 0, t.name.encode()[:39])
     for i, op in enumerate(spec.ops):
         if len(op.srcs) > MAX_SRC:
             raise ValueError('%s has %d sources (max %d)' % (op.name, len(op.srcs), MAX_SRC))
