@@ -1,0 +1,219 @@
+"""``task: bg`` — drop-in for reference ``models/bg/bg_model.py`` + ``models/bg/hardnet.py``.
+
+Same constructor params, same ``predict``/``forward`` returns and the SAME state_dict keys
+(``depth_mean``, ``depth_std``, ``model.base.N...``, ``model.conv1x1_up.N...``,
+``model.denseBlocksUp.N.layers.M...``, ``model.finalConv``) so the reference's ``bg_model.pt`` loads
+unchanged.  The nn.Modules here only *hold* parameters; the arithmetic is ``pf_bg_forward`` in
+libpfhip.so (BN folded and weights re-tiled when the plan is built).
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import hardnet_arch as arch
+from . import lib as _lib
+from . import packing
+from .base_model import BaseModel
+
+
+class _Node(nn.Module):
+    """Anonymous container: gives dotted state_dict paths without any behaviour."""
+
+
+def _get_or_make(root, path):
+    node = root
+    for part in path:
+        if not hasattr(node, part):
+            node.add_module(part, _Node())
+        node = getattr(node, part)
+    return node
+
+
+class HardNetParams(nn.Module):
+    """Parameter holder whose state_dict mirrors reference ``hardnet`` (hardnet.py:261-327)."""
+
+    def __init__(self, in_ch, n_cls):
+        super().__init__()
+        self.spec = arch.Spec(in_ch, n_cls)
+        for op in self.spec.conv_ops():
+            parts = op.name.split('.')
+            if op.bn:          # ConvLayer: conv (no bias) + norm   (hardnet.py:16-25)
+                holder = _get_or_make(self, parts)
+                cin = 3 if op.kind == arch.OP_STEM else op.cin
+                holder.add_module('conv', nn.Conv2d(cin, op.cout, op.k, op.stride, op.k // 2, bias=False))
+                holder.add_module('norm', nn.BatchNorm2d(op.cout))
+            else:              # finalConv: plain conv with bias (hardnet.py:325-327)
+                parent = _get_or_make(self, parts[:-1])
+                conv = nn.Conv2d(op.cin, op.cout, op.k, op.stride, 0, bias=True)
+                nn.init.kaiming_normal_(conv.weight)          # expand_last_layer, hardnet.py:334-339
+                parent.add_module(parts[-1], conv)
+        # expand_first_layer (hardnet.py:329-332): mean over the RGB input channels, tiled to in_ch
+        stem = getattr(self.base, '0').conv
+        w = stem.weight.data.mean(1, keepdim=True).expand(-1, in_ch, -1, -1).clone()
+        stem.weight = nn.Parameter(w)
+
+    def load_pretrained(self, path):
+        """hardnet.py:393-400: ImageNet/Cityscapes FC-HarDNet pickle, ``module.`` prefix stripped."""
+        sd = torch.load(path, map_location='cpu')['model_state']
+        sd = {k[len('module.'):]: v for k, v in sd.items()}
+        own = self.state_dict()
+        for k, v in sd.items():
+            if k in own and own[k].shape == v.shape:
+                own[k].copy_(v)
+            elif k == 'base.0.conv.weight':
+                own[k].copy_(v.mean(1, keepdim=True).expand_as(own[k]))
+
+
+class BGModel(BaseModel):
+
+    def __init__(self, params):
+        super().__init__()
+        self.num_classes = num_classes = params['data']['num_classes']
+        self.use_depth_inps = params['model'].get('use_depth_inps')
+        self.num_inputs = params['model'].get('num_inputs', 1)
+        self.min_depth = params['data'].get('min_depth')
+        self.max_depth = params['data'].get('max_depth')
+        self.convert2onehot = params['model'].get('convert2onehot')
+        self.return_logits = params['model'].get('return_logits', True)
+        final_w = params['model'].get('final_w')
+        final_h = params['model'].get('final_h')
+        self.final_size = (final_h, final_w) if final_w is not None and final_h is not None else None
+        in_ch = num_classes
+        if self.use_depth_inps:
+            depth_norm_params = params['data'].get('depth_norm_params')
+            if depth_norm_params is None:
+                mean, std = torch.zeros(1), torch.zeros(1)
+            else:
+                mean, std = depth_norm_params
+            self.depth_mean = nn.Parameter(torch.as_tensor(mean, dtype=torch.float32).reshape(1).clone(),
+                                           requires_grad=False)
+            self.depth_std = nn.Parameter(torch.as_tensor(std, dtype=torch.float32).reshape(1).clone(),
+                                          requires_grad=False)
+            in_ch += 1
+        in_ch *= self.num_inputs
+        self.in_ch = in_ch
+        self.model = HardNetParams(in_ch, num_classes)
+        pretrain = params['model'].get('hardnet', {}).get('pretrain_path')
+        if pretrain is not None:
+            self.model.load_pretrained(pretrain)
+        self._plan = None
+        self._ws = None
+        self._norm = None
+
+    # ---- plan lifecycle -------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        res = super().load_state_dict(state_dict, strict)
+        self.invalidate()
+        return res
+
+    def invalidate(self):
+        """Drop the device plan (call after mutating parameters by hand)."""
+        if self._plan is not None:
+            _lib.load().pf_hardnet_plan_destroy(self._plan)
+        self._plan = None
+        self._norm = None
+
+    def __del__(self):
+        try:
+            self.invalidate()
+        except Exception:
+            pass
+
+    def _get_plan(self):
+        if self._plan is None:
+            L = _lib.load()
+            blob = packing.pack_blob(self.state_dict(), self.in_ch, self.num_classes)
+            buf = ctypes.create_string_buffer(blob, len(blob))
+            plan = ctypes.c_void_p()
+            _lib.check(L.pf_hardnet_plan_create(buf, len(blob), self.in_ch, self.num_classes, ctypes.byref(plan)),
+                       'pf_hardnet_plan_create')
+            self._plan = plan
+            if self.use_depth_inps:
+                self._norm = (float(self.depth_mean.item()), float(self.depth_std.item()))
+        return self._plan
+
+    def _workspace(self, b, h, w, device):
+        L = _lib.load()
+        need = ctypes.c_size_t()
+        _lib.check(L.pf_hardnet_workspace(self._get_plan(), b, h, w, ctypes.byref(need)), 'pf_hardnet_workspace')
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != device:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ---- device forward ---------------------------------------------------------------------
+    def run(self, inps, depths, depth_masks, want_logits=True, want_orig=True, hop_flags=0, seg_dtype=torch.int64):
+        """One ``pf_bg_forward`` / ``pf_hardnet_forward_dense`` call -> (seg, logits|None, orig|None)."""
+        L = _lib.load()
+        plan = self._get_plan()
+        fused = bool(self.convert2onehot and self.use_depth_inps and inps.dim() == 4)
+        if fused:
+            b, t, h, w = inps.shape
+        else:
+            x = self._dense_input(inps, depths, depth_masks)
+            b, _, h, w = x.shape
+        dev = inps.device
+        oh, ow = self.final_size if self.final_size is not None else (h, w)
+        ws = self._workspace(b, h, w, dev)
+        seg = torch.empty((b, oh, ow), dtype=seg_dtype, device=dev)
+        logits = torch.empty((b, self.num_classes, oh, ow), dtype=torch.float32, device=dev) if want_logits else None
+        orig = None
+        if want_orig:
+            vo, vc, vh, vw = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            _lib.check(L.pf_hardnet_tensor_view(plan, b'finalConv', b, h, w, ctypes.byref(vo), ctypes.byref(vc),
+                                                ctypes.byref(vh), ctypes.byref(vw)), 'pf_hardnet_tensor_view')
+            orig = torch.empty((b, vc.value, vh.value, vw.value), dtype=torch.float32, device=dev)
+        ptr = lambda t_: t_.data_ptr() if t_ is not None else None
+        i64 = int(seg_dtype == torch.int64)
+        if fused:
+            if inps.dtype not in (torch.uint8, torch.int64):
+                inps = inps.long()
+            inps = _lib.require_cuda(inps.contiguous(), 'seg')
+            depths = _lib.require_cuda(depths.float().contiguous(), 'depth')
+            mask = None
+            if not (hop_flags & 2):
+                mask = _lib.require_cuda(depth_masks.to(torch.uint8).contiguous(), 'depth_mask')
+            mean, std = self._norm
+            rc = L.pf_bg_forward(plan, inps.data_ptr(), int(inps.dtype == torch.int64), depths.data_ptr(), ptr(mask),
+                                 mean, std, hop_flags, float(self.min_depth or 0.0), float(self.max_depth or 0.0),
+                                 b, t, h, w, oh, ow, seg.data_ptr(), i64, ptr(logits), ptr(orig),
+                                 ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, 'pf_bg_forward')
+        else:
+            x = _lib.require_cuda(x.contiguous(), 'input')
+            rc = L.pf_hardnet_forward_dense(plan, x.data_ptr(), b, h, w, oh, ow, seg.data_ptr(), i64, ptr(logits),
+                                            ptr(orig), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, 'pf_hardnet_forward_dense')
+        return seg, logits, orig
+
+    def _dense_input(self, inps, depths, depth_masks):
+        """bg_model.py:61-69 as device-side torch glue for the non-default configurations
+        (convert2onehot False, or no depth channels): builds [B, in_ch, H, W] f32."""
+        if self.convert2onehot:
+            m = inps < self.num_classes
+            oh = F.one_hot(torch.where(m, inps, torch.zeros_like(inps)).long(), self.num_classes) * m.unsqueeze(-1)
+            inps = oh.permute(0, 1, 4, 2, 3).float()
+        b, t, c, h, w = inps.shape
+        x = inps.reshape(b, t * c, h, w).float()
+        if self.use_depth_inps:
+            d = (depths - self.depth_mean) / self.depth_std
+            x = torch.cat([x, d * depth_masks], dim=1)
+        return x
+
+    # ---- reference surface ------------------------------------------------------------------
+    def forward(self, inps, depths, depth_masks, return_orig_size=False):
+        _, logits, orig = self.run(inps, depths, depth_masks, True, return_orig_size)
+        return (logits, orig) if return_orig_size else logits
+
+    def loss(self, inputs, labels):
+        raise NotImplementedError('bg training step (bg_model.py:73-89) is scope row f4 — not built yet')
+
+    @torch.no_grad()
+    def predict(self, inputs, labels=None):
+        seg, logits, orig = self.run(inputs['seg'], inputs.get('depth'), inputs.get('depth_mask'),
+                                     want_logits=self.return_logits, want_orig=True)
+        out = {'seg': seg, 'orig_size_logits': orig}
+        if logits is not None:
+            out['logits'] = logits
+        return out

@@ -1,9 +1,330 @@
-// placeholder until the HarDNet plan lands (next commit)
-#include "pf_common.h"
-extern "C" int pf_hardnet_plan_create(const void *, size_t, int, int, pf_plan **) { return pf::fail(PF_EUNSUPPORTED, "not built yet"); }
-extern "C" void pf_hardnet_plan_destroy(pf_plan *) {}
-extern "C" int pf_hardnet_workspace(const pf_plan *, int, int, int, size_t *) { return pf::fail(PF_EUNSUPPORTED, "not built yet"); }
-extern "C" int pf_bg_forward(const pf_plan *, const void *, int, const float *, const uint8_t *, float, float, int, float, float, int, int, int, int, int, int, void *, int, float *, float *, void *, size_t, void *) { return pf::fail(PF_EUNSUPPORTED, "not built yet"); }
-extern "C" int pf_hardnet_forward_dense(const pf_plan *, const float *, int, int, int, int, int, void *, int, float *, float *, void *, size_t, void *) { return pf::fail(PF_EUNSUPPORTED, "not built yet"); }
-extern "C" int pf_hardnet_tensor_view(const pf_plan *, const char *, int, int, int, size_t *, int *, int *, int *) { return pf::fail(PF_EUNSUPPORTED, "not built yet"); }
-extern "C" int pf_hardnet_flops(const pf_plan *, int, int, double *) { return pf::fail(PF_EUNSUPPORTED, "not built yet"); }
+// Plan = parsed op table + device-resident, MFMA-tiled weights; forward = walk the table and enqueue.
+//
+// Replaces the module walk of reference hardnet.py:353-387 (hardnet.forward) and the glue of
+// bg_model.py:61-71,91-102.  The op table comes from the blob (packing.py / hardnet_arch.py); nothing
+// about FC-HarDNet-70 is hard-coded here, so single-op test networks use the same code.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "conv_mfma.h"
+#include "net_kernels.h"
+#include "pf_blob.h"
+
+using namespace pf;
+
+struct ConvPlan {
+    ConvTiling tiling;
+    size_t wpk_off = 0;   // floats into dev_weights
+    size_t bias_off = 0;  // floats (padded to 16*n_tiles)
+    size_t raw_off = 0;   // folded OIHW copy (stem only)
+};
+
+struct pf_plan {
+    BlobHeader hdr;
+    std::vector<BlobTensor> tensors;
+    std::vector<BlobOp> ops;
+    std::vector<ConvPlan> conv;  // parallel to ops
+    float *dev_weights = nullptr;
+    uint8_t *dev_lut = nullptr;
+    size_t dev_floats = 0;
+};
+
+namespace {
+
+struct Dims {
+    int h = 0, w = 0;
+};
+
+// Cityscapes id -> trainId (public label table; ids outside 0..33 -> 0, like the zeros_like init of
+// export_cityscapes_segmentation_results.py:34-38)
+void fill_lut(uint8_t *lut) {
+    memset(lut, 0, 256);
+    for (int i = 0; i < 34; ++i) lut[i] = 255;
+    const int ids[19] = {7, 8, 11, 12, 13, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 31, 32, 33};
+    for (int t = 0; t < 19; ++t) lut[ids[t]] = (uint8_t)t;
+}
+
+// spatial size of every tensor for an H x W network input
+int propagate_dims(const pf_plan *p, int H, int W, std::vector<Dims> &d) {
+    d.assign(p->tensors.size(), Dims());
+    if (p->ops.empty()) return fail(PF_EBLOB, "empty op table");
+    d[p->ops[0].src[0].tensor] = {H, W};
+    for (const BlobOp &o : p->ops) {
+        const Dims in = d[o.src[0].tensor];
+        if (in.h <= 0 || in.w <= 0) return fail(PF_EBLOB, "op reads a tensor that was never produced");
+        Dims out = in;
+        switch (o.kind) {
+            case OP_STEM:
+            case OP_CONV: {
+                const int pad = o.k / 2;
+                out.h = (in.h + 2 * pad - (int)o.k) / (int)o.stride + 1;
+                out.w = (in.w + 2 * pad - (int)o.k) / (int)o.stride + 1;
+                break;
+            }
+            case OP_POOL: out = {in.h / 2, in.w / 2}; break;
+            case OP_UPSAMPLE: out = d[o.src[1].tensor]; break;
+            case OP_HEAD: break;
+            default: return fail(PF_EBLOB, "unknown op kind %u", o.kind);
+        }
+        if (out.h <= 0 || out.w <= 0) return fail(PF_EINVAL, "input %dx%d is too small for this network", H, W);
+        if (d[o.dst].h && (d[o.dst].h != out.h || d[o.dst].w != out.w) && o.kind != OP_HEAD)
+            return fail(PF_EBLOB, "tensor %u written with two different sizes", o.dst);
+        if (o.kind != OP_HEAD) d[o.dst] = out;
+    }
+    return PF_OK;
+}
+
+// workspace: every tensor except the network input gets its own 256-B aligned region
+int layout(const pf_plan *p, int B, const std::vector<Dims> &d, std::vector<size_t> &off, size_t &total) {
+    off.assign(p->tensors.size(), (size_t)-1);
+    size_t cur = 0;
+    const uint32_t input = p->ops[0].src[0].tensor;
+    for (size_t t = 0; t < p->tensors.size(); ++t) {
+        if (t == input || d[t].h == 0) continue;
+        off[t] = cur;
+        cur += align_up((size_t)B * p->tensors[t].channels * d[t].h * d[t].w * sizeof(float), 256);
+    }
+    total = cur ? cur : 256;
+    return PF_OK;
+}
+
+int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B, int H, int W, int out_h, int out_w,
+            void *out_seg, int out_seg_is_i64, float *out_logits, float *out_orig, void *ws, size_t ws_bytes,
+            hipStream_t s) {
+    std::vector<Dims> d;
+    int rc = propagate_dims(p, H, W, d);
+    if (rc) return rc;
+    std::vector<size_t> off;
+    size_t need = 0;
+    layout(p, B, d, off, need);
+    if (ws_bytes < need) return fail(PF_EWORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
+    const uint32_t input = p->ops[0].src[0].tensor;
+    auto tptr = [&](uint32_t t) -> float * {
+        return t == input ? const_cast<float *>(dense_x) : reinterpret_cast<float *>((char *)ws + off[t]);
+    };
+
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const BlobOp &o = p->ops[i];
+        const Dims in = d[o.src[0].tensor];
+        const Dims out = o.kind == OP_HEAD ? in : d[o.dst];
+        if (o.kind == OP_STEM && stem) {
+            StemArgs a = *stem;
+            a.w = p->dev_weights + p->conv[i].raw_off;
+            a.bias = p->dev_weights + p->conv[i].bias_off;
+            a.lut = p->dev_lut;
+            a.dst = tptr(o.dst);
+            a.Hout = out.h;
+            a.Wout = out.w;
+            if (o.cout != 16 || o.k != 3 || o.stride != 2 || o.dst_choff != 0 ||
+                p->tensors[o.dst].channels != 16 || (uint32_t)(a.T * (a.n_cls + 1)) != o.cin)
+                return fail(PF_EUNSUPPORTED, "fused stem expects a 3x3/s2 conv %d->16, got %u->%u k%u s%u",
+                            a.T * (a.n_cls + 1), o.cin, o.cout, o.k, o.stride);
+            if ((rc = launch_stem(a, s))) return rc;
+        } else if (o.kind == OP_STEM || o.kind == OP_CONV) {
+            if (o.src[0].tensor == input && !dense_x)
+                return fail(PF_EINVAL, "network input is consumed by a generic conv: use pf_hardnet_forward_dense");
+            ConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.n_src = (int)o.n_src;
+            int c0 = 0;
+            for (int j = 0; j < a.n_src; ++j) {
+                a.src[j] = tptr(o.src[j].tensor);
+                a.src_ctotal[j] = (int)p->tensors[o.src[j].tensor].channels;
+                a.src_choff[j] = (int)o.src[j].choff;
+                a.src_cstart[j] = c0;
+                c0 += (int)o.src[j].ch;
+            }
+            for (int j = a.n_src; j <= kConvMaxSrc; ++j) a.src_cstart[j] = c0;
+            a.wpk = p->dev_weights + p->conv[i].wpk_off;
+            a.bias = p->dev_weights + p->conv[i].bias_off;
+            a.dst = tptr(o.dst);
+            a.dst_ctotal = (int)p->tensors[o.dst].channels;
+            a.dst_choff = (int)o.dst_choff;
+            a.Cin = (int)o.cin; a.Cout = (int)o.cout;
+            a.Hin = in.h; a.Win = in.w; a.Hout = out.h; a.Wout = out.w;
+            a.nchunks = p->conv[i].tiling.nchunks;
+            a.relu = (int)o.relu;
+            if ((rc = launch_conv(a, p->conv[i].tiling, B, s))) return rc;
+        } else if (o.kind == OP_POOL) {
+            if ((rc = launch_avgpool2(tptr(o.src[0].tensor), tptr(o.dst), B * (int)o.cin, in.h, in.w, s))) return rc;
+        } else if (o.kind == OP_UPSAMPLE) {
+            if ((rc = launch_upsample(tptr(o.src[0].tensor), tptr(o.dst), B * (int)o.cin, in.h, in.w, out.h, out.w, s)))
+                return rc;
+        } else if (o.kind == OP_HEAD) {
+            HeadArgs a;
+            a.logits = tptr(o.src[0].tensor);
+            a.out_seg = out_seg; a.out_logits = out_logits; a.out_is_i64 = out_seg_is_i64;
+            a.B = B; a.C = (int)o.cin; a.Hin = in.h; a.Win = in.w; a.Hout = out_h; a.Wout = out_w;
+            if (out_orig)
+                PF_HIP_CHECK(hipMemcpyAsync(out_orig, a.logits, (size_t)B * a.C * in.h * in.w * sizeof(float),
+                                            hipMemcpyDeviceToDevice, s));
+            if ((rc = launch_head(a, s))) return rc;
+        }
+    }
+    return PF_OK;
+}
+
+}  // namespace
+
+extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch, int n_cls, pf_plan **out) {
+    if (!blob || !out) return fail(PF_EINVAL, "pf_hardnet_plan_create: null argument");
+    if (bytes < sizeof(BlobHeader)) return fail(PF_EBLOB, "blob shorter than its header");
+    BlobHeader h;
+    memcpy(&h, blob, sizeof(h));
+    if (memcmp(h.magic, kBlobMagic, 8) != 0 || h.version != kBlobVersion)
+        return fail(PF_EBLOB, "bad blob magic/version");
+    if (h.total_bytes != bytes || h.tensor_off + (uint64_t)h.n_tensors * sizeof(BlobTensor) > bytes ||
+        h.op_off + (uint64_t)h.n_ops * sizeof(BlobOp) > bytes || h.weights_off > bytes || (h.weights_off & 3))
+        return fail(PF_EBLOB, "blob table offsets out of range (total %llu, got %zu)",
+                    (unsigned long long)h.total_bytes, bytes);
+    if ((int)h.in_ch != in_ch || (int)h.n_cls != n_cls)
+        return fail(PF_EINVAL, "blob is for in_ch=%u n_cls=%u, caller asked for %d/%d", h.in_ch, h.n_cls, in_ch, n_cls);
+    pf_plan *p = new pf_plan();
+    p->hdr = h;
+    p->tensors.resize(h.n_tensors);
+    p->ops.resize(h.n_ops);
+    memcpy(p->tensors.data(), (const char *)blob + h.tensor_off, h.n_tensors * sizeof(BlobTensor));
+    memcpy(p->ops.data(), (const char *)blob + h.op_off, h.n_ops * sizeof(BlobOp));
+    const float *wts = reinterpret_cast<const float *>((const char *)blob + h.weights_off);
+    const size_t n_w = (bytes - h.weights_off) / sizeof(float);
+
+    // validate + tile the weights on the host
+    std::vector<float> host;
+    p->conv.resize(p->ops.size());
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const BlobOp &o = p->ops[i];
+        bool ok = o.n_src >= 1 && o.n_src <= (uint32_t)kMaxSrc && o.dst < h.n_tensors;
+        uint32_t cin = 0;
+        for (uint32_t j = 0; ok && j < o.n_src; ++j) {
+            ok = o.src[j].tensor < h.n_tensors &&
+                 o.src[j].choff + o.src[j].ch <= p->tensors[o.src[j].tensor].channels;
+            cin += o.src[j].ch;
+        }
+        if (ok && (o.kind == OP_STEM || o.kind == OP_CONV))
+            ok = cin == o.cin && o.dst_choff + o.cout <= p->tensors[o.dst].channels && (o.k == 1 || o.k == 3) &&
+                 (o.stride == 1 || o.stride == 2) && o.w_off + (uint64_t)o.cout * o.cin * o.k * o.k <= n_w &&
+                 o.b_off + o.cout <= n_w;
+        if (!ok) {
+            delete p;
+            return fail(PF_EBLOB, "op %zu is inconsistent with the tensor table", i);
+        }
+        if (o.kind != OP_STEM && o.kind != OP_CONV) continue;
+        if (o.k == 1 && o.stride != 1) {
+            delete p;
+            return fail(PF_EUNSUPPORTED, "1x1 conv with stride %u", o.stride);
+        }
+        ConvPlan &c = p->conv[i];
+        c.tiling = choose_tiling((int)o.k, (int)o.stride, (int)o.cin, (int)o.cout, 0);
+        c.wpk_off = host.size();
+        host.resize(host.size() + c.tiling.packed_floats());
+        pack_conv_weights(wts + o.w_off, (int)o.cin, (int)o.cout, c.tiling, host.data() + c.wpk_off);
+        c.bias_off = host.size();
+        const size_t nb = (size_t)c.tiling.cout_blocks * c.tiling.nt * 16;
+        host.resize(host.size() + nb, 0.f);
+        memcpy(host.data() + c.bias_off, wts + o.b_off, o.cout * sizeof(float));
+        if (o.kind == OP_STEM) {
+            c.raw_off = host.size();
+            host.insert(host.end(), wts + o.w_off, wts + o.w_off + (size_t)o.cout * o.cin * o.k * o.k);
+        }
+        host.resize(align_up(host.size(), 64), 0.f);
+    }
+    p->dev_floats = host.size();
+    uint8_t lut[256];
+    fill_lut(lut);
+    hipError_t e = hipMalloc((void **)&p->dev_weights, (host.size() + 64) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->dev_lut, 256);
+    if (e == hipSuccess) e = hipMemcpy(p->dev_weights, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->dev_lut, lut, 256, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        pf_hardnet_plan_destroy(p);
+        return fail(PF_EHIP, "plan upload: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return PF_OK;
+}
+
+extern "C" void pf_hardnet_plan_destroy(pf_plan *p) {
+    if (!p) return;
+    if (p->dev_weights) (void)hipFree(p->dev_weights);
+    if (p->dev_lut) (void)hipFree(p->dev_lut);
+    delete p;
+}
+
+extern "C" int pf_hardnet_workspace(const pf_plan *p, int B, int H, int W, size_t *bytes) {
+    if (!p || !bytes || B <= 0 || H <= 0 || W <= 0) return fail(PF_EINVAL, "pf_hardnet_workspace: bad argument");
+    std::vector<Dims> d;
+    int rc = propagate_dims(p, H, W, d);
+    if (rc) return rc;
+    std::vector<size_t> off;
+    return layout(p, B, d, off, *bytes);
+}
+
+extern "C" int pf_bg_forward(const pf_plan *p, const void *seg, int seg_is_i64, const float *depth,
+                             const uint8_t *depth_mask, float depth_mean, float depth_std, int hop_flags,
+                             float min_depth, float max_depth, int B, int T, int H, int W, int out_h, int out_w,
+                             void *out_seg, int out_seg_is_i64, float *out_logits, float *out_orig_logits, void *ws,
+                             size_t ws_bytes, void *stream) {
+    if (!p || !seg || !depth || !out_seg || !ws) return fail(PF_EINVAL, "pf_bg_forward: null pointer argument");
+    if (!depth_mask && !(hop_flags & PF_HOP_DEPTH_U16))
+        return fail(PF_EINVAL, "pf_bg_forward: depth_mask is required unless PF_HOP_DEPTH_U16 is set");
+    if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0)
+        return fail(PF_EINVAL, "pf_bg_forward: bad dims");
+    if (p->ops.empty() || p->ops[0].kind != OP_STEM)
+        return fail(PF_EUNSUPPORTED, "pf_bg_forward: plan does not start with a fused stem");
+    StemArgs st;
+    memset(&st, 0, sizeof(st));
+    st.seg = seg; st.depth = depth; st.mask = depth_mask;
+    st.depth_mean = depth_mean; st.depth_std = depth_std; st.min_depth = min_depth; st.max_depth = max_depth;
+    st.seg_is_i64 = seg_is_i64; st.hop = hop_flags; st.B = B; st.T = T; st.n_cls = (int)p->hdr.n_cls;
+    st.H = H; st.W = W;
+    return run_net(p, &st, nullptr, B, H, W, out_h, out_w, out_seg, out_seg_is_i64, out_logits, out_orig_logits, ws,
+                   ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int pf_hardnet_forward_dense(const pf_plan *p, const float *x, int B, int H, int W, int out_h, int out_w,
+                                        void *out_seg, int out_seg_is_i64, float *out_logits, float *out_orig_logits,
+                                        void *ws, size_t ws_bytes, void *stream) {
+    if (!p || !x || !ws) return fail(PF_EINVAL, "pf_hardnet_forward_dense: null pointer argument");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(PF_EINVAL, "pf_hardnet_forward_dense: bad dims");
+    const bool has_head = !p->ops.empty() && p->ops.back().kind == OP_HEAD;
+    if (has_head && (!out_seg || out_h <= 0 || out_w <= 0))
+        return fail(PF_EINVAL, "pf_hardnet_forward_dense: out_seg/out size required");
+    return run_net(p, nullptr, x, B, H, W, out_h, out_w, out_seg, out_seg_is_i64, out_logits, out_orig_logits, ws,
+                   ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int pf_hardnet_tensor_view(const pf_plan *p, const char *name, int B, int H, int W, size_t *ws_offset,
+                                      int *channels, int *h, int *w) {
+    if (!p || !name || !ws_offset || !channels || !h || !w) return fail(PF_EINVAL, "pf_hardnet_tensor_view: null");
+    std::vector<Dims> d;
+    int rc = propagate_dims(p, H, W, d);
+    if (rc) return rc;
+    std::vector<size_t> off;
+    size_t total;
+    layout(p, B, d, off, total);
+    for (size_t t = 0; t < p->tensors.size(); ++t) {
+        if (strncmp(p->tensors[t].name, name, sizeof(p->tensors[t].name)) == 0) {
+            if (off[t] == (size_t)-1) return fail(PF_EINVAL, "tensor '%s' is not materialised", name);
+            *ws_offset = off[t];
+            *channels = (int)p->tensors[t].channels;
+            *h = d[t].h;
+            *w = d[t].w;
+            return PF_OK;
+        }
+    }
+    return fail(PF_EINVAL, "no tensor named '%s'", name);
+}
+
+extern "C" int pf_hardnet_flops(const pf_plan *p, int H, int W, double *flops) {
+    if (!p || !flops) return fail(PF_EINVAL, "pf_hardnet_flops: null");
+    std::vector<Dims> d;
+    int rc = propagate_dims(p, H, W, d);
+    if (rc) return rc;
+    double f = 0;
+    for (const BlobOp &o : p->ops)
+        if (o.kind == OP_STEM || o.kind == OP_CONV)
+            f += 2.0 * o.cout * d[o.dst].h * d[o.dst].w * o.cin * o.k * o.k;
+    *flops = f;
+    return PF_OK;
+}

@@ -1,0 +1,33 @@
+// Non-GEMM stages of the bg network — interface (see net_kernels.hip).
+#pragma once
+#include "pf_common.h"
+
+namespace pf {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct StemArgs {
+    const void *seg;       // [B,T,H,W] u8 or i64
+    const float *depth;    // [B,T,H,W]
+    const uint8_t *mask;   // [B,T,H,W] (ignored with PF_HOP_DEPTH_U16)
+    const float *w;        // folded OIHW [16][T*(n_cls+1)][3][3]
+    const float *bias;     // [16]
+    const uint8_t *lut;    // [256] id -> trainId (device)
+    float *dst;            // [B,16,Hout,Wout]
+    float depth_mean, depth_std, min_depth, max_depth;
+    int seg_is_i64, hop, B, T, n_cls, H, W, Hout, Wout;
+};
+
+struct HeadArgs {
+    const float *logits;  // [B,C,Hin,Win]
+    void *out_seg;        // [B,Hout,Wout] u8 or i64
+    float *out_logits;    // nullable [B,C,Hout,Wout]
+    int out_is_i64, B, C, Hin, Win, Hout, Wout;
+};
+
+int launch_stem(const StemArgs &a, hipStream_t s);
+int launch_avgpool2(const float *src, float *dst, int planes, int Hin, int Win, hipStream_t s);
+int launch_upsample(const float *src, float *dst, int planes, int Hin, int Win, int Hout, int Wout, hipStream_t s);
+int launch_head(const HeadArgs &a, hipStream_t s);
+
+}  // namespace pf

@@ -1,0 +1,202 @@
+// The non-GEMM stages of the bg network (all HBM/L2-bound, VALU only):
+//   stem_onehot_kernel : bg_model.py:53-69 (one-hot, depth normalise, concat) fused with the stem conv
+//                        hardnet.py base.0 (3x3 s2, BN folded, ReLU).  The [B,36,H,W] tensor is never built:
+//                        a one-hot channel contributes exactly one weight column per tap, so the conv is
+//                        a gather-sum of 16-wide weight rows from LDS.  Optionally emulates the reference's
+//                        on-disk hop (export_cityscapes_segmentation_results.py:34-38,119-124 and
+//                        bg_dataset.py:224-230,166-170) on the fly.
+//   avgpool2_kernel    : nn.AvgPool2d(2,2)                     hardnet.py:296
+//   upsample_kernel    : F.interpolate(bilinear, align_corners) hardnet.py:248-253
+//   head_kernel        : final bilinear upsample + argmax      hardnet.py:372-384, bg_model.py:98
+#include "net_kernels.h"
+
+namespace pf {
+
+// align_corners=True source index (ATen area_pixel_compute_scale / compute_source_index)
+__device__ __forceinline__ void lin_coord(int o, float scale, int in_size, int &i0, int &i1, float &l0, float &l1) {
+    const float r = scale * (float)o;
+    i0 = min((int)r, in_size - 1);
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = fminf(fmaxf(r - (float)i0, 0.f), 1.f);
+    l0 = 1.f - l1;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_onehot_kernel(StemArgs a) {
+    // weights in LDS as [tap][ch][16]: row = one input channel's 16 output weights for that tap
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    __shared__ uint8_t lut[256];
+    const int in_ch = a.T * (a.n_cls + 1);
+    for (int e = threadIdx.x; e < 9 * in_ch * 16; e += 256) {
+        const int co = e & 15, ch = (e >> 4) % in_ch, tap = (e >> 4) / in_ch;
+        wl[e] = a.w[((size_t)co * in_ch + ch) * 9 + tap];
+    }
+    lut[threadIdx.x] = (a.hop & PF_HOP_TRAINID_LUT) ? a.lut[threadIdx.x] : (uint8_t)threadIdx.x;
+    __syncthreads();
+
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (ox >= a.Wout || oy >= a.Hout) return;
+    const size_t N = (size_t)a.H * a.W;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = a.bias[i];
+    const float mean_ = a.depth_mean, std_ = a.depth_std;
+
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        if (iy < 0 || iy >= a.H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            if (ix < 0 || ix >= a.W) continue;
+            const int tap = ky * 3 + kx;
+            const size_t pix = (size_t)iy * a.W + ix;
+            for (int t = 0; t < a.T; ++t) {
+                const size_t idx = ((size_t)b * a.T + t) * N + pix;
+                // label -> one-hot column (labels >= n_cls contribute nothing, bg_model.py:54-57)
+                int cls = a.seg_is_i64 ? (int)reinterpret_cast<const long long *>(a.seg)[idx]
+                                       : (int)reinterpret_cast<const uint8_t *>(a.seg)[idx];
+                if (a.hop & PF_HOP_TRAINID_LUT) cls = lut[cls & 255];
+                if (cls >= 0 && cls < a.n_cls) {
+                    const f32x4v *row = reinterpret_cast<const f32x4v *>(wl + (tap * in_ch + t * a.n_cls + cls) * 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4v r = row[q];
+                        acc[q * 4 + 0] += r[0]; acc[q * 4 + 1] += r[1]; acc[q * 4 + 2] += r[2]; acc[q * 4 + 3] += r[3];
+                    }
+                }
+                // depth channel: ((d - mean)/std) * mask   (bg_model.py:50-51,66-67)
+                float d = a.depth[idx];
+                float m;
+                if (a.hop & PF_HOP_DEPTH_U16) {
+                    const float q = rintf(fminf(fmaxf(d + 1.f, 0.f), 255.f) * 256.f);  // export :119-124
+                    d = q / 256.f - 1.f;                                                // load bg_dataset.py:225
+                    const bool mk = d > 0.f;
+                    d = mk ? fminf(fmaxf(d, a.min_depth), a.max_depth) : -1.f;           // :227-228,:166-170
+                    m = mk ? 1.f : 0.f;
+                } else {
+                    m = a.mask[idx] ? 1.f : 0.f;
+                }
+                const float dn = ((d - mean_) / std_) * m;
+                const f32x4v *row = reinterpret_cast<const f32x4v *>(wl + (tap * in_ch + a.T * a.n_cls + t) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4v r = row[q];
+                    acc[q * 4 + 0] += r[0] * dn; acc[q * 4 + 1] += r[1] * dn;
+                    acc[q * 4 + 2] += r[2] * dn; acc[q * 4 + 3] += r[3] * dn;
+                }
+            }
+        }
+    }
+    const size_t op = (size_t)a.Hout * a.Wout;
+    float *o = a.dst + (size_t)b * 16 * op + (size_t)oy * a.Wout + ox;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i * op] = fmaxf(acc[i], 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool2_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                       int planes, int Hin, int Win, int Hout, int Wout) {
+    const size_t total = (size_t)planes * Hout * Wout;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % Wout);
+        const size_t r = i / Wout;
+        const int y = (int)(r % Hout);
+        const size_t p = r / Hout;
+        const float *s = src + (p * Hin + 2 * y) * (size_t)Win + 2 * x;
+        dst[i] = (((s[0] + s[1]) + s[Win]) + s[Win + 1]) * 0.25f;
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                       int planes, int Hin, int Win, int Hout, int Wout) {
+    const float sh = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
+    const float sw = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+    const size_t total = (size_t)planes * Hout * Wout;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % Wout);
+        const size_t r = i / Wout;
+        const int y = (int)(r % Hout);
+        const size_t p = r / Hout;
+        int y0, y1, x0, x1;
+        float hy0, hy1, lx0, lx1;
+        lin_coord(y, sh, Hin, y0, y1, hy0, hy1);
+        lin_coord(x, sw, Win, x0, x1, lx0, lx1);
+        const float *s = src + p * (size_t)Hin * Win;
+        const float t0 = lx0 * s[(size_t)y0 * Win + x0] + lx1 * s[(size_t)y0 * Win + x1];
+        const float t1 = lx0 * s[(size_t)y1 * Win + x0] + lx1 * s[(size_t)y1 * Win + x1];
+        dst[i] = hy0 * t0 + hy1 * t1;
+    }
+}
+
+// final upsample + argmax; logits [B,C,Hin,Win] -> seg [B,Hout,Wout] (+ optional full logits)
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
+    const float sh = a.Hout > 1 ? (float)(a.Hin - 1) / (float)(a.Hout - 1) : 0.f;
+    const float sw = a.Wout > 1 ? (float)(a.Win - 1) / (float)(a.Wout - 1) : 0.f;
+    const size_t opl = (size_t)a.Hout * a.Wout, ipl = (size_t)a.Hin * a.Win;
+    const size_t total = (size_t)a.B * opl;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % a.Wout);
+        const size_t r = i / a.Wout;
+        const int y = (int)(r % a.Hout);
+        const int b = (int)(r / a.Hout);
+        int y0, y1, x0, x1;
+        float hy0, hy1, lx0, lx1;
+        lin_coord(y, sh, a.Hin, y0, y1, hy0, hy1);
+        lin_coord(x, sw, a.Win, x0, x1, lx0, lx1);
+        const float *s = a.logits + (size_t)b * a.C * ipl;
+        const size_t o00 = (size_t)y0 * a.Win + x0, o01 = (size_t)y0 * a.Win + x1;
+        const size_t o10 = (size_t)y1 * a.Win + x0, o11 = (size_t)y1 * a.Win + x1;
+        float best = -INFINITY;
+        int arg = 0;
+        for (int c = 0; c < a.C; ++c) {
+            const float *sc = s + (size_t)c * ipl;
+            const float t0 = lx0 * sc[o00] + lx1 * sc[o01];
+            const float t1 = lx0 * sc[o10] + lx1 * sc[o11];
+            const float v = hy0 * t0 + hy1 * t1;
+            if (a.out_logits) a.out_logits[((size_t)b * a.C + c) * opl + (size_t)y * a.Wout + x] = v;
+            if (v > best) { best = v; arg = c; }  // first maximum wins, like torch.argmax on CPU
+        }
+        if (a.out_is_i64) reinterpret_cast<long long *>(a.out_seg)[i] = arg;
+        else reinterpret_cast<uint8_t *>(a.out_seg)[i] = (uint8_t)arg;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static unsigned grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+int launch_stem(const StemArgs &a, hipStream_t s) {
+    if (a.T * (a.n_cls + 1) * 9 * 16 * sizeof(float) > 60000)
+        return fail(PF_EUNSUPPORTED, "stem: T=%d n_cls=%d weights exceed LDS budget", a.T, a.n_cls);
+    const size_t lds = (size_t)a.T * (a.n_cls + 1) * 9 * 16 * sizeof(float);
+    hipLaunchKernelGGL(stem_onehot_kernel, dim3((a.Wout + 63) / 64, (a.Hout + 3) / 4, a.B), dim3(256), lds, s, a);
+    PF_LAUNCH_CHECK("stem_onehot_kernel");
+    return PF_OK;
+}
+
+int launch_avgpool2(const float *src, float *dst, int planes, int Hin, int Win, hipStream_t s) {
+    const int Ho = Hin / 2, Wo = Win / 2;
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for((size_t)planes * Ho * Wo)), dim3(256), 0, s, src, dst, planes,
+                       Hin, Win, Ho, Wo);
+    PF_LAUNCH_CHECK("avgpool2_kernel");
+    return PF_OK;
+}
+
+int launch_upsample(const float *src, float *dst, int planes, int Hin, int Win, int Hout, int Wout, hipStream_t s) {
+    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((size_t)planes * Hout * Wout)), dim3(256), 0, s, src, dst,
+                       planes, Hin, Win, Hout, Wout);
+    PF_LAUNCH_CHECK("upsample_kernel");
+    return PF_OK;
+}
+
+int launch_head(const HeadArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(head_kernel, dim3(grid_for((size_t)a.B * a.Hout * a.Wout)), dim3(256), 0, s, a);
+    PF_LAUNCH_CHECK("head_kernel");
+    return PF_OK;
+}
+
+}  // namespace pf

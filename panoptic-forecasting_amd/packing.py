@@ -58,10 +58,15 @@ def folded_params(sd, spec, prefix='model.'):
     return out
 
 
-def pack_blob(sd, in_ch=36, n_cls=11, prefix='model.'):
-    """bytes: the blob handed to the C library."""
-    spec = arch.Spec(in_ch, n_cls)
-    params = folded_params(sd, spec, prefix)
+def pack_blob(sd, in_ch=36, n_cls=11, prefix='model.', spec=None, params=None):
+    """bytes: the blob handed to the C library.
+
+    ``spec``/``params`` let tests serialise an arbitrary op table with ready-made
+    {op name: (weight, bias)} instead of the bg network + checkpoint."""
+    if spec is None:
+        spec = arch.Spec(in_ch, n_cls)
+    if params is None:
+        params = folded_params(sd, spec, prefix)
     chunks = []
     w_off = {}
     n_floats = 0

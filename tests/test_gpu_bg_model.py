@@ -1,0 +1,127 @@
+"""HIP bg network (pf_bg_forward through BGModel) vs the reference fixtures (g3) and the torch oracle.
+
+Tolerances (stated by the parity contract): fp32 path, logits of O(1):
+  max |orig_size_logits - ref| <= 1e-3,  argmax agreement >= 99.9 %.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+LOGIT_TOL = 1e-3
+AGREE = 0.999
+
+
+def _sd():
+    from panoptic_forecasting_amd import synth
+    with open(os.path.join(G, 'calib_seed1234.json')) as f:
+        return synth.make_state_dict(seed=1234, calib=json.load(f))
+
+
+def _model(h=None, w=None, **kw):
+    from panoptic_forecasting_amd.registry import build_model
+    params = {'task': 'bg', 'no_gpu': False, 'load_model': None, 'load_best_model': False,
+              'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])],
+                       'min_depth': 0.1, 'max_depth': 200},
+              'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True}}
+    if h is not None:
+        params['model'].update(final_h=h, final_w=w)
+    params['model'].update(kw)
+    m = build_model(params)
+    m.load_state_dict(_sd())
+    m.eval()
+    return m
+
+
+@pytest.mark.parametrize('size', ['64x128', '96x160'])
+def test_matches_reference_fixture(size):
+    z = np.load(os.path.join(G, 'g3_%s.npz' % size))
+    h, w = z['seg_in'].shape[-2:]
+    m = _model(h, w)
+    inputs = {'seg': torch.from_numpy(z['seg_in']).long().cuda(), 'depth': torch.from_numpy(z['depth']).cuda(),
+              'depth_mask': torch.from_numpy(z['mask']).cuda()}
+    out = m.predict(inputs, None)
+    assert out['seg'].dtype == torch.int64 and out['logits'].shape == z['logits'].shape
+    e1 = np.abs(out['orig_size_logits'].cpu().numpy() - z['orig_size_logits']).max()
+    e2 = np.abs(out['logits'].cpu().numpy() - z['logits']).max()
+    agree = (out['seg'].cpu().numpy() == z['seg']).mean()
+    assert e1 <= LOGIT_TOL and e2 <= LOGIT_TOL, (e1, e2)
+    assert agree >= AGREE, agree
+
+
+def test_stage_by_stage_vs_oracle():
+    """Every block output inside the workspace against the oracle's taps (bisecting aid)."""
+    from helpers import view_tensor
+    from oracle import hardnet_ref
+    from panoptic_forecasting_amd import synth
+    h, w = 128, 192
+    m = _model(h, w)
+    inp = synth.make_bg_inputs(b=1, h=h, w=w, seed=9)
+    taps = {}
+    ref = hardnet_ref.bg_predict(_sd(), inp, final_size=(h, w), taps=taps)
+    out = m.predict({k: v.cuda() for k, v in inp.items()}, None)
+    names = {'base.0': 'base.0', 'base.1': 'base.1', 'base.2': 'base.2', 'base.3': 'base.3',
+             'base.4': 'base.4.out', 'base.7': 'base.7.out', 'base.10': 'base.10.out', 'base.13': 'base.13.out',
+             'base.16': 'base.16.out', 'denseBlocksUp.0': 'denseBlocksUp.0.out',
+             'denseBlocksUp.3': 'denseBlocksUp.3.out'}
+    for tap, tname in names.items():
+        got = view_tensor(m._get_plan(), m._ws, tname, 1, h, w).cpu()
+        err = (got - taps[tap]).abs().max().item()
+        assert err <= 1e-4 * (1 + taps[tap].abs().max().item()), (tap, err)
+    assert (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max() <= LOGIT_TOL
+
+
+@pytest.mark.parametrize('h,w,b', [(256, 512, 1), (160, 224, 2)])
+def test_matches_oracle(h, w, b):
+    from oracle import hardnet_ref
+    from panoptic_forecasting_amd import synth
+    m = _model(h, w)
+    inp = synth.make_bg_inputs(b=b, h=h, w=w, seed=2)
+    ref = hardnet_ref.bg_predict(_sd(), inp, final_size=(h, w))
+    out = m.predict({k: v.cuda() for k, v in inp.items()}, None)
+    err = (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max().item()
+    agree = (out['seg'].cpu() == ref['seg']).float().mean().item()
+    assert err <= LOGIT_TOL, err
+    assert agree >= AGREE, agree
+    hist = torch.bincount(out['seg'].flatten().cpu(), minlength=11)
+    assert (hist > 0).sum() >= 5          # the synthetic net must not collapse to one class
+
+
+def test_u8_in_u8_out_and_no_logits():
+    from panoptic_forecasting_amd import synth
+    m = _model(64, 128, return_logits=False)
+    inp = {k: v.cuda() for k, v in synth.make_bg_inputs(b=1, h=64, w=128, seed=4).items()}
+    a = m.predict(inp, None)
+    assert 'logits' not in a
+    seg8, _, _ = m.run(inp['seg'].to(torch.uint8), inp['depth'], inp['depth_mask'], want_logits=False,
+                       want_orig=False, seg_dtype=torch.uint8)
+    assert torch.equal(seg8.long(), a['seg'])
+
+
+def test_dense_path_equals_fused_path():
+    """convert2onehot=False configuration (bg_model.py:61-71) through pf_hardnet_forward_dense."""
+    from oracle import hardnet_ref
+    from panoptic_forecasting_amd import synth
+    h, w = 64, 96
+    sd = _sd()
+    inp = synth.make_bg_inputs(b=2, h=h, w=w, seed=6)
+    fused = _model(h, w).predict({k: v.cuda() for k, v in inp.items()}, None)
+    dense_m = _model(h, w, convert2onehot=False)
+    x = hardnet_ref.bg_inputs_to_tensor(sd, inp['seg'], inp['depth'], inp['depth_mask'])
+    onehot = x[:, :33].reshape(2, 3, 11, h, w).cuda()
+    d = dense_m.predict({'seg': onehot, 'depth': inp['depth'].cuda(), 'depth_mask': inp['depth_mask'].cuda()}, None)
+    assert (d['orig_size_logits'] - fused['orig_size_logits']).abs().max() <= 1e-4
+    assert (d['seg'] == fused['seg']).float().mean() >= AGREE
+
+
+def test_cpu_inputs_fail_loudly():
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.lib import PfError
+    m = _model(64, 128)
+    with pytest.raises(PfError):
+        m.predict(synth.make_bg_inputs(b=1, h=64, w=128), None)

@@ -1,0 +1,93 @@
+"""HIP MFMA convolution / pool / upsample kernels vs torch fp32 (F.conv2d etc. on the CPU), through the C ABI.
+
+Tolerance: both sides are exact-fp32 dot products that differ only in summation order; for K = Cin*k*k
+terms of O(1) magnitude the difference is bounded by ~K * 2^-24 * sum|a*b|.  We assert
+max|err| <= 2e-5 * (1 + max|ref|) which holds with margin for K <= 4000.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(ref):
+    return 2e-5 * (1.0 + ref.abs().max().item())
+
+
+CASES = [
+    # cin, cout, k, stride, h, w, b
+    (48, 10, 3, 1, 64, 128, 1), (58, 18, 3, 1, 32, 96, 2), (76, 28, 3, 1, 40, 72, 1), (32, 48, 3, 1, 64, 64, 1),
+    (24, 32, 3, 2, 64, 128, 1), (36, 16, 3, 2, 50, 70, 2), (3, 5, 3, 2, 33, 47, 1),
+    (48, 64, 1, 1, 64, 128, 1), (126, 63, 1, 1, 32, 64, 2), (534, 267, 1, 1, 8, 16, 1), (286, 320, 1, 1, 4, 8, 1),
+    (402, 158, 3, 1, 4, 8, 1), (196, 88, 3, 1, 16, 32, 1), (91, 28, 3, 1, 30, 50, 1), (17, 70, 3, 1, 9, 13, 3),
+    (5, 3, 1, 1, 7, 5, 1), (160, 24, 3, 1, 16, 24, 1),
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,h,w,b', CASES)
+@pytest.mark.parametrize('relu', [True, False])
+def test_single_conv(cin, cout, k, stride, h, w, b, relu):
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    g = torch.Generator().manual_seed(cin * 131 + cout)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    spec = MiniSpec(cin)
+    spec.conv('c', [arch.Src(0, 0, cin)], cout, k, stride, relu=relu)
+    net = MiniNet(spec, {'c': (wt, bias)}).run(x.cuda())
+    out = net.tensor('c').cpu()
+    ref = F.conv2d(x, wt, bias, stride=stride, padding=k // 2)
+    if relu:
+        ref = F.relu(ref)
+    assert out.shape == ref.shape
+    err = (out - ref).abs().max().item()
+    assert err <= _tol(ref), (err, _tol(ref))
+    net.close()
+
+
+def test_multi_source_and_channel_slots():
+    """HarDBlock-style wiring: a conv reading three channel ranges (one a slice of a wider tensor) and
+    writing into a channel slot of a wider tensor; the untouched channels must stay untouched."""
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    g = torch.Generator().manual_seed(5)
+    b, h, w = 2, 24, 40
+    x = torch.randn(b, 20, h, w, generator=g)
+    spec = MiniSpec(20)
+    wide = spec.tensor('wide', 50)                               # slots: [0:18] L1, [18:50] L2
+    spec.conv('L1', [arch.Src(0, 0, 20)], 18, 3, dst=wide, dst_choff=0)
+    spec.conv('L2', [arch.Src(wide, 0, 18), arch.Src(0, 0, 20)], 32, 3, dst=wide, dst_choff=18)
+    spec.conv('L3', [arch.Src(wide, 18, 32), arch.Src(wide, 0, 18), arch.Src(0, 4, 9)], 21, 1)
+    P = {}
+    for name, cin, cout, k in [('L1', 20, 18, 3), ('L2', 38, 32, 3), ('L3', 59, 21, 1)]:
+        P[name] = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.randn(cout, generator=g))
+    net = MiniNet(spec, P).run(x.cuda())
+    l1 = F.relu(F.conv2d(x, *P['L1'], padding=1))
+    l2 = F.relu(F.conv2d(torch.cat([l1, x], 1), *P['L2'], padding=1))
+    l3 = F.relu(F.conv2d(torch.cat([l2, l1, x[:, 4:13]], 1), *P['L3']))
+    wide_out = net.tensor('wide').cpu()
+    assert (wide_out[:, :18] - l1).abs().max() <= _tol(l1)
+    assert (wide_out[:, 18:] - l2).abs().max() <= _tol(l2)
+    assert (net.tensor('L3').cpu() - l3).abs().max() <= _tol(l3)
+    net.close()
+
+
+@pytest.mark.parametrize('h,w', [(16, 32), (17, 23), (6, 10)])
+def test_pool_and_upsample(h, w):
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    g = torch.Generator().manual_seed(h)
+    x = torch.randn(2, 7, h, w, generator=g)
+    spec = MiniSpec(7)
+    eye = torch.eye(7).view(7, 7, 1, 1).contiguous()
+    t = spec.conv('id', [arch.Src(0, 0, 7)], 7, 1, relu=False)
+    p = spec.pool('pool', t)
+    spec.upsample('up', p, t)
+    net = MiniNet(spec, {'id': (eye, torch.zeros(7))}).run(x.cuda())
+    pooled = F.avg_pool2d(x, 2, 2)
+    up = F.interpolate(pooled, size=(h, w), mode='bilinear', align_corners=True)
+    assert (net.tensor('pool').cpu() - pooled).abs().max() <= 1e-6
+    assert (net.tensor('up').cpu() - up).abs().max() <= 1e-5
+    net.close()
