@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""Headline benchmark: bg forecast frames/sec @1024x2048, 3 inputs -> Δt=3 (BASELINE.json configs[1]).
+
+One "step" = one pass of the hot path over one batch of synthetic, HBM-resident inputs on every rank:
+    3 x (unproject + ego warp + z-buffered splat)  ->  on-the-fly disk-hop emulation  ->  FC-HarDNet-70
+    -> bilinear upsample + argmax   (task ``bg_forecast`` of panoptic-forecasting_amd)
+Ranks are independent (sequences shard by batch); the only collective is the end-of-run all-gather of
+the PQ accumulators.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-graph] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from panoptic_forecasting_amd import dist as pfdist  # noqa: E402
+from panoptic_forecasting_amd import lib as pflib  # noqa: E402
+from panoptic_forecasting_amd import pq as pfpq  # noqa: E402
+from panoptic_forecasting_amd import synth  # noqa: E402
+from panoptic_forecasting_amd.pc_transform_model import host_inverse  # noqa: E402
+from panoptic_forecasting_amd.registry import build_model  # noqa: E402
+
+H, W, T = 1024, 2048, 3
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0          # HBM3E spec (6.3 TB/s achievable)
+CPU_THREADS = 32                # torch-CPU threads for the baseline leg (more oversubscribes these small convs)
+CPU_BUDGET_S = 20.0             # stop starting new baseline frames after this much CPU time
+
+
+def calibrated_state_dict():
+    with open(os.path.join(ROOT, 'tests', 'golden', 'calib_seed1234.json')) as f:
+        calib = json.load(f)
+    return synth.make_state_dict(seed=1234, calib=calib)
+
+
+def model_params():
+    return {'task': 'bg_forecast', 'no_gpu': False, 'load_model': None, 'load_best_model': False,
+            'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])],
+                     'min_depth': 0.1, 'max_depth': 200},
+            'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True,
+                      'final_h': H, 'final_w': W, 'emulate_disk_hop': True, 'seg_is_label_id': True}}
+
+
+def make_batch(b, seed0, device):
+    parts = [synth.make_inputs(b=1, t=T, h=H, w=W, seed=seed0 + i, gap_len=3) for i in range(b)]
+    inp = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+    # camera inverses are per-sequence constants prepared with the inputs (host LAPACK)
+    inp['intrinsics_inv'] = host_inverse(inp['intrinsics'])
+    inp['extrinsics_inv'] = host_inverse(inp['extrinsics'])
+    return {k: v.to(device) for k, v in inp.items()}
+
+
+def cpu_baseline(sd, n_frames):
+    """The oracle (CPU port of the reference path) timed on this box's host cores."""
+    import numpy as np
+    from oracle import hardnet_ref
+    from oracle import warp_splat as ow
+    torch.set_num_threads(min(os.cpu_count(), CPU_THREADS))
+    ow.lib()
+    last = None
+    t0 = time.perf_counter()
+    for f in range(n_frames):
+        if f > 0 and time.perf_counter() - t0 > CPU_BUDGET_S:
+            n_frames = f
+            break
+        inp = synth.make_inputs(b=1, t=T, h=H, w=W, seed=f, gap_len=3)
+        segs, deps = [], []
+        for t in range(T):
+            o = ow.predict(inp, only_this_ind=t)
+            tid = torch.from_numpy(synth.ID2TRAINID)[o['seg'].long()]
+            q = ((o['depth'] + 1).clamp(0, 255) * 256).round().numpy().astype(np.uint16)
+            d = torch.from_numpy(q.astype(np.float32)) / 256.0 - 1
+            m = d > 0
+            d[~m] = -1
+            d[m & (d > 200)] = 200
+            d[m & (d < 0.1)] = 0.1
+            segs.append(tid)
+            deps.append(d)
+        seg, dep = torch.stack(segs, 1).long(), torch.stack(deps, 1)
+        last = hardnet_ref.bg_predict(sd, {'seg': seg, 'depth': dep, 'depth_mask': dep > 0}, final_size=(H, W))
+    dt = time.perf_counter() - t0
+    # the generation of synthetic inputs is inside the loop but is <3 % of it
+    return n_frames / dt, dt, last, n_frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=1, help='forecast frames per GPU per step')
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-frames', type=int, default=4)
+    ap.add_argument('--profile-steps', type=int, default=3)
+    args = ap.parse_args()
+
+    rank, world, local = pfdist.init_distributed_mode()
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    pflib.load()   # fails loudly if libpfhip.so is missing
+
+    sd = calibrated_state_dict()
+    model = build_model(model_params())
+    model.load_state_dict(sd)
+    model.eval()
+    B = args.batch
+    batch = make_batch(B, seed0=rank * B, device=dev)
+
+    def step():
+        return model.predict(batch, None)
+
+    out = step()          # builds the plan, sizes the workspaces
+    torch.cuda.synchronize()
+    use_graph = not args.no_graph
+    graph = None
+    if use_graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = step()
+        run = graph.replay
+    else:
+        run = step
+
+    for _ in range(args.warmup):
+        run()
+    if pfdist.is_dist():
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if pfdist.is_dist():
+        torch.distributed.barrier()
+    elapsed = pfdist.max_over_ranks(time.perf_counter() - t0, dev)
+    frames = world * B * args.steps
+    value = frames / elapsed
+
+    # ---- sharded metric exchange: PQ accumulators of this rank's forecasts vs a synthetic ground truth
+    gt = torch.from_numpy(synth.ID2TRAINID).to(dev)[batch['seg'][:, T - 1].long()].long()
+    acc = pfpq.pq_accumulate(out['seg'].long(), gt, 11)
+    allacc = pfdist.gather_accumulators(acc)
+    pq_synth = pfpq.pq_from_acc(allacc.sum(0))['pq']
+
+    # ---- per-kernel timing pass (eager, hipEvents on the launch stream) -> roofline of the dominant kernel
+    roofline = None
+    if rank == 0:
+        pflib.profile(True)
+        for _ in range(args.profile_steps):
+            step()
+        torch.cuda.synchronize()
+        recs = pflib.profile_results()
+        pflib.profile(False)
+        tot = sum(r['ms'] for r in recs)
+        dom = max(recs, key=lambda r: r['ms'])
+        per_launch_ms = dom['ms'] / dom['launches']
+        if dom['flops'] > 0:
+            achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+            roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': achieved / PEAK_FP32_MFMA_TFLOPS}
+        else:
+            achieved = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
+            roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                        'frac': achieved / PEAK_HBM_GBPS}
+        conv = [r for r in recs if r['flops'] > 0]
+        conv_ms = sum(r['ms'] for r in conv)
+        roofline.update({'traffic': None, 'kernel': dom['label'], 'launches_per_step': dom['launches'] // args.profile_steps,
+                         'avg_launch_us': per_launch_ms * 1e3, 'share_of_step': dom['ms'] / tot,
+                         'all_conv_tflops': sum(r['flops'] for r in conv) / (conv_ms * 1e-3) / 1e12 if conv_ms else None,
+                         'kernel_ms_per_step': tot / args.profile_steps})
+        if os.environ.get('PF_BENCH_KERNELS'):
+            for r in sorted(recs, key=lambda r: -r['ms']):
+                print('# %-70s n=%3d %8.3f ms  %7.2f TF/s %8.1f GB/s' % (
+                    r['label'][:70], r['launches'] // args.profile_steps, r['ms'] / args.profile_steps,
+                    r['flops'] / max(r['ms'], 1e-9) / 1e9, r['bytes'] / max(r['ms'], 1e-9) / 1e6), file=sys.stderr)
+
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        fps, secs, ref, n_done = cpu_baseline(sd, args.cpu_frames)
+        cpu = {'value': fps, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': '%d forecast frames @%dx%d (3 C-oracle splats on 1 thread + torch-CPU HarDNet on %d threads each), %.1f s'
+                         % (n_done, H, W, torch.get_num_threads(), secs)}
+        # full-size parity of the LAST cpu frame (seed cpu_frames-1) against the HIP path
+        chk = make_batch(1, seed0=n_done - 1, device=dev)
+        got = model.predict(chk, None)['seg'].long().cpu()
+        agree = float((got == ref['seg']).float().mean())
+        pq_ref = pfpq.pq_from_acc(pfpq.pq_accumulate(got, ref['seg'], 11))['pq']
+        parity = {'argmax_agreement_vs_oracle': agree, 'pq_vs_oracle_as_gt': pq_ref}
+
+    if rank == 0:
+        line = {'metric': 'forecast frames/sec @1024x2048, 3-in->dt=3 bg', 'value': value, 'unit': 'frames/s',
+                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': 'configs[1]: bg short-term forecast, 3 frames in, dt=3, 1024x2048, random-init '
+                                       'calibrated weights; step = 3 warp/splats + HarDNet + upsample/argmax',
+                           'frames_per_gpu_per_step': B, 'launch': 'hipGraph replay' if use_graph else 'eager',
+                           'sharding': 'batch over %d rank(s), no data-path collective' % world},
+                'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity,
+                'pq_gather_check': {'pq_vs_last_input_labels': pq_synth,
+                                    'note': 'random-init weights: value is meaningless, it exercises the sharded PQ all-gather'}}
+        print(json.dumps(line))
+    if pfdist.is_dist():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

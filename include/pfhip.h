@@ -118,6 +118,19 @@ int pf_hardnet_tensor_view(const pf_plan *plan, const char *name, int B, int H, 
 /* Dense-equivalent FLOPs of one forward at (H,W) per sample (2*Cout*Hout*Wout*Cin*k*k summed). */
 int pf_hardnet_flops(const pf_plan *plan, int H, int W, double *flops);
 
+/* ------------------------------------------------------------------------------------------
+ * Opt-in per-launch timing for the roofline report (bench.py).  While enabled, every kernel the
+ * library enqueues is bracketed by hipEvents on ITS launch stream (process-wide state; do not
+ * enable during graph capture).  pf_profile_collect() synchronises the recorded events and returns
+ * the number of distinct kernels; pf_profile_get() returns, per kernel (label = the demangled
+ * symbol rocprofv3 prints), launches, summed duration and the summed ALGORITHMIC flops / bytes of
+ * those launches (SURVEY.md 8d accounting: unique input + output bytes; 2*Cout*H*W*Cin*k*k flops).
+ */
+int pf_profile_enable(int on);
+int pf_profile_collect(void);
+int pf_profile_get(int i, char *label, size_t label_cap, int *launches, double *total_ms, double *flops,
+                   double *bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ from . import hardnet_arch as arch
 from . import lib as _lib
 from . import packing
 from .base_model import BaseModel
+from .pc_transform_model import _as_u8
 
 
 class _Node(nn.Module):
@@ -173,7 +174,7 @@ class BGModel(BaseModel):
             depths = _lib.require_cuda(depths.float().contiguous(), 'depth')
             mask = None
             if not (hop_flags & 2):
-                mask = _lib.require_cuda(depth_masks.to(torch.uint8).contiguous(), 'depth_mask')
+                mask = _lib.require_cuda(_as_u8(depth_masks), 'depth_mask')
             mean, std = self._norm
             rc = L.pf_bg_forward(plan, inps.data_ptr(), int(inps.dtype == torch.int64), depths.data_ptr(), ptr(mask),
                                  mean, std, hop_flags, float(self.min_depth or 0.0), float(self.max_depth or 0.0),

@@ -14,6 +14,7 @@
 // Numerics: exact fp32 (the f32 MFMA is a k-ordered fmaf chain); only the summation order differs
 // from ATen's, which the parity tests bound at 1e-3 abs on O(1) logits.
 #include "conv_mfma.h"
+#include "pf_prof.h"
 
 namespace pf {
 
@@ -183,6 +184,11 @@ static int launch_cfg(const ConvArgs &a0, int B, int cout_blocks, hipStream_t s)
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    char label[96];
+    snprintf(label, sizeof(label), "void pf::conv_mfma_kernel<%d, %d, %d, %d, %d>(pf::ConvArgs)", KS, STRIDE, TWT, NT, KC);
+    const double px = (double)B * a.Hout * a.Wout;
+    ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * KS * KS,
+                 4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * KS * KS));
     hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, TWT, NT, KC>), dim3(a.tilesX * a.tilesY, cout_blocks, B),
                        dim3(256), lds, s, a);
     PF_LAUNCH_CHECK("conv_mfma_kernel");

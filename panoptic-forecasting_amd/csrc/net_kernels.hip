@@ -9,6 +9,7 @@
 //   upsample_kernel    : F.interpolate(bilinear, align_corners) hardnet.py:248-253
 //   head_kernel        : final bilinear upsample + argmax      hardnet.py:372-384, bg_model.py:98
 #include "net_kernels.h"
+#include "pf_prof.h"
 
 namespace pf {
 
@@ -173,6 +174,9 @@ int launch_stem(const StemArgs &a, hipStream_t s) {
     if (a.T * (a.n_cls + 1) * 9 * 16 * sizeof(float) > 60000)
         return fail(PF_EUNSUPPORTED, "stem: T=%d n_cls=%d weights exceed LDS budget", a.T, a.n_cls);
     const size_t lds = (size_t)a.T * (a.n_cls + 1) * 9 * 16 * sizeof(float);
+    const double ipx = (double)a.B * a.T * a.H * a.W, opx = (double)a.B * a.Hout * a.Wout;
+    ProfScope ps(s, "pf::stem_onehot_kernel(pf::StemArgs)", 2.0 * opx * 16 * a.T * (a.n_cls + 1) * 9,
+                 ipx * ((a.seg_is_i64 ? 8 : 1) + 4 + ((a.hop & PF_HOP_DEPTH_U16) ? 0 : 1)) + opx * 16 * 4);
     hipLaunchKernelGGL(stem_onehot_kernel, dim3((a.Wout + 63) / 64, (a.Hout + 3) / 4, a.B), dim3(256), lds, s, a);
     PF_LAUNCH_CHECK("stem_onehot_kernel");
     return PF_OK;
@@ -180,6 +184,7 @@ int launch_stem(const StemArgs &a, hipStream_t s) {
 
 int launch_avgpool2(const float *src, float *dst, int planes, int Hin, int Win, hipStream_t s) {
     const int Ho = Hin / 2, Wo = Win / 2;
+    ProfScope ps(s, "pf::avgpool2_kernel", 0, 4.0 * planes * ((double)Hin * Win + (double)Ho * Wo));
     hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for((size_t)planes * Ho * Wo)), dim3(256), 0, s, src, dst, planes,
                        Hin, Win, Ho, Wo);
     PF_LAUNCH_CHECK("avgpool2_kernel");
@@ -187,6 +192,7 @@ int launch_avgpool2(const float *src, float *dst, int planes, int Hin, int Win, 
 }
 
 int launch_upsample(const float *src, float *dst, int planes, int Hin, int Win, int Hout, int Wout, hipStream_t s) {
+    ProfScope ps(s, "pf::upsample_kernel", 0, 4.0 * planes * ((double)Hin * Win + (double)Hout * Wout));
     hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((size_t)planes * Hout * Wout)), dim3(256), 0, s, src, dst,
                        planes, Hin, Win, Hout, Wout);
     PF_LAUNCH_CHECK("upsample_kernel");
@@ -194,6 +200,9 @@ int launch_upsample(const float *src, float *dst, int planes, int Hin, int Win, 
 }
 
 int launch_head(const HeadArgs &a, hipStream_t s) {
+    const double opx = (double)a.B * a.Hout * a.Wout;
+    ProfScope ps(s, "pf::head_kernel(pf::HeadArgs)", 0, 4.0 * a.B * a.C * a.Hin * a.Win + opx * (a.out_is_i64 ? 8 : 1) +
+                                                          (a.out_logits ? opx * a.C * 4 : 0));
     hipLaunchKernelGGL(head_kernel, dim3(grid_for((size_t)a.B * a.Hout * a.Wout)), dim3(256), 0, s, a);
     PF_LAUNCH_CHECK("head_kernel");
     return PF_OK;

@@ -20,6 +20,7 @@
 //                                                 gives these depth max+1 which is > every valid z)
 //   EMPTY   : 0xFFFFFFFFFFFFFFFF                 (memset 0xFF)
 #include "pf_common.h"
+#include "pf_prof.h"
 
 namespace pf {
 
@@ -263,13 +264,25 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     a.chunks = pf::splat_chunks(N);
     hipStream_t s = (hipStream_t)stream;
 
-    PF_HIP_CHECK(hipMemsetAsync(a.zbuf, 0xFF, zbuf_bytes, s));
-    hipLaunchKernelGGL(pf::project_scatter_kernel, dim3(a.chunks, T, B), dim3(pf::kSplatThreads), 0, s, a);
-    PF_LAUNCH_CHECK("project_scatter_kernel");
+    // algorithmic bytes: read depth 4 + mask 1 per source pixel; resolve: seg 1 in, seg 1 + depth 4 out
+    const double src_px = (double)B * T * N, dst_px = (double)B * (per_frame ? T : 1) * N;
+    {
+        pf::ProfScope ps(s, "zbuf_memset", 0, (double)zbuf_bytes);
+        PF_HIP_CHECK(hipMemsetAsync(a.zbuf, 0xFF, zbuf_bytes, s));
+    }
+    {
+        pf::ProfScope ps(s, "pf::project_scatter_kernel(pf::SplatArgs)", 0,
+                         src_px * (5.0 + (out_result2d ? 16.0 : 0.0)));
+        hipLaunchKernelGGL(pf::project_scatter_kernel, dim3(a.chunks, T, B), dim3(pf::kSplatThreads), 0, s, a);
+        PF_LAUNCH_CHECK("project_scatter_kernel");
+    }
     long long rb = (N + pf::kSplatThreads - 1) / pf::kSplatThreads;
     if (rb > 1024) rb = 1024;
-    hipLaunchKernelGGL(pf::resolve_kernel, dim3((unsigned)rb, per_frame ? T : 1, B), dim3(pf::kSplatThreads), 0,
-                       s, a);
-    PF_LAUNCH_CHECK("resolve_kernel");
+    {
+        pf::ProfScope ps(s, "pf::resolve_kernel(pf::SplatArgs)", 0, dst_px * (2.0 * seg_channels + 4.0));
+        hipLaunchKernelGGL(pf::resolve_kernel, dim3((unsigned)rb, per_frame ? T : 1, B), dim3(pf::kSplatThreads),
+                           0, s, a);
+        PF_LAUNCH_CHECK("resolve_kernel");
+    }
     return PF_OK;
 }

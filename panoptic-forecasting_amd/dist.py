@@ -1,0 +1,63 @@
+"""One process per GPU over RCCL — rank discovery and the single metric exchange of the sharded path.
+
+Pattern after reference ``utils/dist.py:12-32`` (env-var rank discovery, backend string ``"nccl"`` —
+which is RCCL on ROCm — ``env://`` rendezvous, one barrier) and ``:79-102`` (``reduce_dict``).  The bg
+forecasting path shards by sample with no data-path collective; the only exchange is the end-of-run
+gather of the [n_cls,4] float64 PQ accumulators (608 B per rank for 19 classes): latency-bound, one
+``all_gather_into_tensor``.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+    return (int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)),
+            int(os.environ.get('LOCAL_RANK', 0)))
+
+
+def init_distributed_mode(backend=None, device=None):
+    """Returns (rank, world_size, local_rank).  No-op for a single process."""
+    rank, world, local = env_rank()
+    if world <= 1:
+        return rank, world, local
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+        device = torch.device('cuda', local)
+    if not dist.is_initialized():
+        kw = {'device_id': device} if backend == 'nccl' and device is not None else {}
+        dist.init_process_group(backend=backend, init_method='env://', rank=rank, world_size=world, **kw)
+    dist.barrier()
+    return rank, world, local
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def shard_indices(n_items, rank, world):
+    """Sample partition of the val list: rank r takes r, r+G, r+2G, ...."""
+    return list(range(rank, n_items, world))
+
+
+def gather_accumulators(acc):
+    """acc [n_cls,4] float64 on this rank -> [world, n_cls, 4] on every rank (identity for 1 process)."""
+    if not is_dist():
+        return acc.unsqueeze(0)
+    world = dist.get_world_size()
+    out = torch.empty((world,) + tuple(acc.shape), dtype=acc.dtype, device=acc.device)
+    dist.all_gather_into_tensor(out, acc.contiguous())
+    return out
+
+
+def max_over_ranks(x, device):
+    if not is_dist():
+        return float(x)
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -27,7 +27,32 @@ SIGNATURES = {
     'pf_hardnet_tensor_view': (_i, [_vp, _c.c_char_p, _i, _i, _i, _c.POINTER(_sz), _c.POINTER(_i),
                                     _c.POINTER(_i), _c.POINTER(_i)]),
     'pf_hardnet_flops': (_i, [_vp, _i, _i, _c.POINTER(_c.c_double)]),
+    'pf_profile_enable': (_i, [_i]),
+    'pf_profile_collect': (_i, []),
+    'pf_profile_get': (_i, [_i, _c.c_char_p, _sz, _c.POINTER(_i), _c.POINTER(_c.c_double),
+                            _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
 }
+
+
+def profile(enable):
+    check(load().pf_profile_enable(int(enable)), 'pf_profile_enable')
+
+
+def profile_results():
+    """[{label, launches, ms, flops, bytes}] for everything enqueued since profile(True)."""
+    L = load()
+    n = L.pf_profile_collect()
+    if n < 0:
+        check(n, 'pf_profile_collect')
+    out = []
+    for i in range(n):
+        buf = ctypes.create_string_buffer(160)
+        la, ms, fl, by = _i(), _c.c_double(), _c.c_double(), _c.c_double()
+        check(L.pf_profile_get(i, buf, 160, ctypes.byref(la), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)),
+              'pf_profile_get')
+        out.append({'label': buf.value.decode(), 'launches': la.value, 'ms': ms.value, 'flops': fl.value,
+                    'bytes': by.value})
+    return out
 
 _lib = None
 
@@ -40,6 +65,9 @@ def load():
     """Load libpfhip.so (once) and type its entry points; raises if it is not built."""
     global _lib
     if _lib is None:
+        # torch bundles its own HIP runtime: it must be the one already mapped when libpfhip.so resolves
+        # libamdhip64 (loading ours first pulls /opt/rocm's copy and torch then sees "no ROCm-capable device")
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise PfError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                           '(make -C panoptic-forecasting_amd/csrc). There is no fallback path.' % LIB_PATH)

@@ -17,6 +17,13 @@ def host_inverse(m):
     return torch.inverse(m.detach().float().cpu()).to(m.device)
 
 
+def _as_u8(mask):
+    """bool tensors are one 0/1 byte per element: reinterpret instead of converting."""
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)
+    return mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
+
+
 class WarpSplat:
     """Workspace-caching front end of ``pf_warp_splat``."""
 
@@ -39,8 +46,7 @@ class WarpSplat:
         T = t_total - t_first if T is None else T
         dev = depth.device
         depth = _lib.require_cuda(depth.float(), 'depth')
-        mask = _lib.require_cuda(depth_mask.to(torch.uint8) if depth_mask.dtype != torch.uint8
-                                 else depth_mask, 'depth_mask')
+        mask = _lib.require_cuda(_as_u8(depth_mask), 'depth_mask')
         seg_dtype = seg.dtype
         seg8 = _lib.require_cuda(seg if seg.dtype == torch.uint8 else seg.to(torch.uint8), 'seg')
         Kinv = host_inverse(K) if Kinv is None else Kinv
