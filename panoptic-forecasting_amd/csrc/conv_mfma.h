@@ -23,6 +23,9 @@ struct ConvArgs {
     int dst_ctotal, dst_choff;
     int Cin, Cout, Hin, Win, Hout, Wout;
     int tilesX, tilesY, nchunks, relu;
+    // fast path (conv_dma.hip) only:
+    const float *zero_page;  // >= 16 B of zeros (source of out-of-image / padding DMA pieces)
+    int ntiles;              // ceil(Cout/16)
 };
 
 // Tiling choice for one conv (depends on shape only; fixed at plan time for the weight packing).
@@ -39,7 +42,13 @@ ConvTiling choose_tiling(int ks, int stride, int cin, int cout, int wout_hint);
 // OIHW fp32 -> [cout_block][chunk][kgroup][tap][nt][64 lanes] with
 //   value = W[(cb*nt+t)*16 + (lane&15)][chunk*kc + kg*4 + (lane>>4)][tap]  (0 outside Cin/Cout)
 void pack_conv_weights(const float *w_oihw, int cin, int cout, const ConvTiling &t, float *out);
-// Enqueue one conv for a batch of B images.
+// Enqueue one conv for a batch of B images (generic path: any stride/width).
 int launch_conv(const ConvArgs &a, const ConvTiling &t, int B, hipStream_t stream);
+
+// Fast path (stride 1, Win % 4 == 0): a.wpk must point at pack_conv_weights_tiled() output and
+// a.nchunks = ceil(Cin / kc) with kc = dma_kc(ks).
+inline int dma_kc(int ks) { return ks == 3 ? 16 : 32; }
+void pack_conv_weights_tiled(const float *w_oihw, int cin, int cout, int ks, int kc, float *out);
+int launch_conv_dma(const ConvArgs &a, int ks, int B, hipStream_t stream);
 
 }  // namespace pf

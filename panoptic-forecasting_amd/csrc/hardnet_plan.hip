@@ -18,6 +18,8 @@ struct ConvPlan {
     size_t wpk_off = 0;   // floats into dev_weights
     size_t bias_off = 0;  // floats (padded to 16*n_tiles)
     size_t raw_off = 0;   // folded OIHW copy (stem only)
+    size_t tiled_off = 0; // per-cout-tile packing for the DMA fast path (stride 1 only)
+    int tiled_chunks = 0;
 };
 
 struct pf_plan {
@@ -143,9 +145,18 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.dst_choff = (int)o.dst_choff;
             a.Cin = (int)o.cin; a.Cout = (int)o.cout;
             a.Hin = in.h; a.Win = in.w; a.Hout = out.h; a.Wout = out.w;
-            a.nchunks = p->conv[i].tiling.nchunks;
             a.relu = (int)o.relu;
-            if ((rc = launch_conv(a, p->conv[i].tiling, B, s))) return rc;
+            a.zero_page = p->dev_weights;   // first 64 floats of the weight arena are zeros
+            a.ntiles = ((int)o.cout + 15) / 16;
+            if (o.stride == 1 && (in.w & 3) == 0) {
+                a.wpk = p->dev_weights + p->conv[i].tiled_off;
+                a.nchunks = p->conv[i].tiled_chunks;
+                rc = launch_conv_dma(a, (int)o.k, B, s);
+            } else {
+                a.nchunks = p->conv[i].tiling.nchunks;
+                rc = launch_conv(a, p->conv[i].tiling, B, s);
+            }
+            if (rc) return rc;
         } else if (o.kind == OP_POOL) {
             if ((rc = launch_avgpool2(tptr(o.src[0].tensor), tptr(o.dst), B * (int)o.cin, in.h, in.w, s))) return rc;
         } else if (o.kind == OP_UPSAMPLE) {
@@ -190,7 +201,7 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
     const size_t n_w = (bytes - h.weights_off) / sizeof(float);
 
     // validate + tile the weights on the host
-    std::vector<float> host;
+    std::vector<float> host(64, 0.f);   // zero page
     p->conv.resize(p->ops.size());
     for (size_t i = 0; i < p->ops.size(); ++i) {
         const BlobOp &o = p->ops[i];
@@ -223,6 +234,13 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
         const size_t nb = (size_t)c.tiling.cout_blocks * c.tiling.nt * 16;
         host.resize(host.size() + nb, 0.f);
         memcpy(host.data() + c.bias_off, wts + o.b_off, o.cout * sizeof(float));
+        if (o.stride == 1) {
+            const int kc = dma_kc((int)o.k);
+            c.tiled_chunks = ((int)o.cin + kc - 1) / kc;
+            c.tiled_off = host.size();
+            host.resize(host.size() + (size_t)((o.cout + 15) / 16) * c.tiled_chunks * (kc / 4) * o.k * o.k * 64);
+            pack_conv_weights_tiled(wts + o.w_off, (int)o.cin, (int)o.cout, (int)o.k, kc, host.data() + c.tiled_off);
+        }
         if (o.kind == OP_STEM) {
             c.raw_off = host.size();
             host.insert(host.end(), wts + o.w_off, wts + o.w_off + (size_t)o.cout * o.cin * o.k * o.k);
