@@ -1,44 +1,54 @@
-// Warp + z-buffered splat for gfx950 (MI355X).
+// Warp + z-buffered splat for gfx950 (MI355X) — binned, LDS-resident z-buffer (no global atomics).
 //
 // Replaces reference panoptic_forecasting/models/pc_transform/pc_transform_model.py:41-150:
 // unproject (:41-59), camera->vehicle (:63), ego warp (:68), vehicle->camera + projection (:71-78),
 // validity (:83-89), sentinel (:105), 4-corner bins (:106-117), torch_scatter.scatter_min (:118-119)
 // and the winner gather (:120-139).
 //
-// Two kernels, both HBM/L2-bound integer+fp32 work (no MFMA):
-//   project_scatter : 1 thread per source pixel.  Exact-order fp32 chain (this file is compiled with
-//                     -ffp-contract=off; every product and sum is rounded separately, divides are IEEE)
-//                     -> (u',v',z), validity, up to 4 de-duplicated bins, one 64-bit atomicMin per bin
-//                     on a packed key  [ z bits | element index e ]  so "min depth, ties -> lowest e"
-//                     is a single unsigned compare.  Block-level max(z) is written as a partial
-//                     (no same-address atomics).
-//   resolve         : 1 thread per destination pixel decodes the winning key into (seg, depth).
+// The first version scattered with 64-bit global atomicMin: 3.0 ms per 1024x2048 frame triple, because
+// agent-scope atomics are executed memory-side across the 8 non-coherent XCD L2s
+// (profiles/r01_a_first_path_kernel_stats.txt).  This version is a two-pass binning rasteriser:
 //
-// Key encoding (valid points have z > 0 so the raw fp32 bits are monotone as unsigned):
-//   valid   : hi = bits(z)           lo = e
-//   invalid : hi = 0xFFFFFFF0        lo = e     (sorts after every valid z, before EMPTY; the reference
-//                                                 gives these depth max+1 which is > every valid z)
-//   EMPTY   : 0xFFFFFFFFFFFFFFFF                 (memset 0xFF)
+//   bin_kernel     one workgroup per 16x64 SOURCE tile: exact-order fp32 projection (this file is built with
+//                  -ffp-contract=off; every product/sum rounded separately, IEEE divides), block max(z)
+//                  partial, the bounding box of the destination bins its VALID points reach, a byte mark per
+//                  bin reached by an INVALID point (plain stores of the constant 1 — no atomics needed),
+//                  optional result2d.
+//   raster_kernel  one workgroup per 32x64 DESTINATION tile: scans the bounding boxes, re-projects only the
+//                  source tiles that can reach it, and resolves "min depth, ties -> lowest element index"
+//                  with 64-bit ds_min on a packed key in a 16 KB LDS z-buffer it alone owns; then writes
+//                  seg/depth for its pixels.  The z-buffer never exists in HBM.
+//
+// Packed key (valid points have z > 0, so raw fp32 bits are monotone as unsigned):
+//     [ bits(z) : 32 | e : 32 ],  e = r*P + t*N + n  (corner replica r, P = T*N)   — pc_transform_model.py:112
+// Invalid points all carry the same depth (max+1, :105) and a zeroed payload (:133), so which of them wins a
+// bin is unobservable: a per-bin "touched by an invalid point" byte reproduces the reference output exactly
+// (seg 0, depth max+1) wherever no valid point lands; untouched bins give seg 0, depth -1 (:136-138).
 #include "pf_common.h"
 #include "pf_prof.h"
 
 namespace pf {
 
-constexpr unsigned kInvalidHi = 0xFFFFFFF0u;
 constexpr unsigned long long kEmpty = ~0ull;
-constexpr int kSplatThreads = 256;
+constexpr int kThreads = 256;
+constexpr int kSrcTH = 16, kSrcTW = 64;   // source tile (pixels); 256 threads x 4 consecutive pixels
+constexpr int kDstTH = 32, kDstTW = 64;   // destination tile owned by one raster workgroup
+constexpr int kScan = 256;                // bounding boxes tested per scan batch
 
 struct SplatArgs {
     const float *depth;
     const uint8_t *mask;
     const uint8_t *seg;
     const float *Kinv, *E, *Tt, *Einv, *K;
-    unsigned long long *zbuf;  // [B*G][N]
-    unsigned *zmax_part;       // [T][B][chunks] order-preserving u32 of float
+    int4 *bbox;           // [B][T][src tiles]  (x0min, y0min, x1max, y1max) of valid points' bins
+    unsigned *zmax_part;  // [T][B][src tiles]  order-preserving u32 of the block max(z)
+    uint8_t *inv_mark;    // [B*G][N]           1 where an invalid point lands
     uint8_t *out_seg;
     float *out_depth;
     long long *out_r2d;
-    int B, T_total, t_first, T, H, W, C, per_frame, chunks;
+    int B, T_total, t_first, T, H, W, C, per_frame;
+    int stx, sty;         // source tiles per row / column
+    int dtx, dty;         // destination tiles per row / column
 };
 
 __device__ __forceinline__ unsigned float_to_ordered(float f) {
@@ -66,111 +76,170 @@ __device__ __forceinline__ float dot4(const float *m, float a, float b, float c,
     return acc;
 }
 
-__global__ __launch_bounds__(kSplatThreads) void project_scatter_kernel(SplatArgs a) {
-    const int chunk = blockIdx.x, tl = blockIdx.y, b = blockIdx.z;
-    const int t = a.t_first + tl;
-    const long long N = (long long)a.H * a.W;
-    const long long P = a.per_frame ? N : (long long)a.T * N;
-    const long long ebase = a.per_frame ? 0 : (long long)tl * N;
-
-    // wave-uniform matrices -> scalar registers
+struct Camera {
     float Kinv[9], E[16], Tm[16], Einv[16], K[9];
+};
+
+__device__ __forceinline__ void load_camera(const SplatArgs &a, int b, int t, Camera &c) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { Kinv[i] = a.Kinv[b * 9 + i]; K[i] = a.K[b * 9 + i]; }
+    for (int i = 0; i < 9; ++i) {
+        c.Kinv[i] = a.Kinv[b * 9 + i];
+        c.K[i] = a.K[b * 9 + i];
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        E[i] = a.E[b * 16 + i];
-        Einv[i] = a.Einv[b * 16 + i];
-        Tm[i] = a.Tt[((long long)b * a.T_total + t) * 16 + i];
-    }
-    const long long in_base = ((long long)b * a.T_total + t) * N;
-    unsigned long long *zb = a.zbuf + ((long long)b * (a.per_frame ? a.T : 1) + (a.per_frame ? tl : 0)) * N;
-    long long *r2d = a.out_r2d ? a.out_r2d + ((long long)b * a.T + tl) * N * 2 : nullptr;
-
-    const long long per_chunk = (N + a.chunks - 1) / a.chunks;
-    const long long n0 = (long long)chunk * per_chunk;
-    const long long n1 = n0 + per_chunk < N ? n0 + per_chunk : N;
-    const float Wf = (float)a.W, Hf = (float)a.H;
-    float zmax = -INFINITY;
-
-    for (long long n = n0 + threadIdx.x; n < n1; n += kSplatThreads) {
-        const int y = (int)(n / a.W), x = (int)(n - (long long)y * a.W);
-        const float d = a.depth[in_base + n];
-        const bool m = a.mask[in_base + n] != 0;
-        const float u = (float)x, v = (float)y;
-        // :54  ray = Kinv · (u, v, 1)
-        const float r0 = dot3(Kinv + 0, u, v, 1.0f), r1 = dot3(Kinv + 3, u, v, 1.0f),
-                    r2 = dot3(Kinv + 6, u, v, 1.0f);
-        // :55-59  camera point (homogeneous)
-        const float c0 = __fmul_rn(r0, d), c1 = __fmul_rn(r1, d), c2 = __fmul_rn(r2, d);
-        // :63  vehicle frame
-        const float v0 = dot4(E + 0, c0, c1, c2, 1.0f), v1 = dot4(E + 4, c0, c1, c2, 1.0f),
-                    v2 = dot4(E + 8, c0, c1, c2, 1.0f), v3 = dot4(E + 12, c0, c1, c2, 1.0f);
-        // :68  target vehicle frame
-        const float w0 = dot4(Tm + 0, v0, v1, v2, v3), w1 = dot4(Tm + 4, v0, v1, v2, v3),
-                    w2 = dot4(Tm + 8, v0, v1, v2, v3), w3 = dot4(Tm + 12, v0, v1, v2, v3);
-        // :71-72  back to the camera, homogeneous divide
-        const float e0 = dot4(Einv + 0, w0, w1, w2, w3), e1 = dot4(Einv + 4, w0, w1, w2, w3),
-                    e2 = dot4(Einv + 8, w0, w1, w2, w3), e3 = dot4(Einv + 12, w0, w1, w2, w3);
-        const float px = __fdiv_rn(e0, e3), py = __fdiv_rn(e1, e3), z = __fdiv_rn(e2, e3);
-        // :74-78  projection
-        const float q0 = dot3(K + 0, px, py, z), q1 = dot3(K + 3, px, py, z), q2 = dot3(K + 6, px, py, z);
-        const float uu = __fdiv_rn(q0, q2), vv = __fdiv_rn(q1, q2);
-
-        zmax = fmaxf(zmax, z);  // :105 max runs over valid and invalid points alike
-        const bool inb = (uu >= 0.0f) && (uu < Wf) && (vv >= 0.0f) && (vv < Hf);  // :83-86
-        const bool valid = m && (z > 0.0f) && inb;                                  // :87-89
-        const unsigned hi = valid ? __float_as_uint(z) : kInvalidHi;
-
-        // :106-114 floor/ceil then clamp (clamping in float first keeps the int conversion in range)
-        const float fu = floorf(uu), cu = ceilf(uu), fv = floorf(vv), cv = ceilf(vv);
-        const int x0 = (int)fminf(fmaxf(fu, 0.0f), Wf - 1.0f), x1 = (int)fminf(fmaxf(cu, 0.0f), Wf - 1.0f);
-        const int y0 = (int)fminf(fmaxf(fv, 0.0f), Hf - 1.0f), y1 = (int)fminf(fmaxf(cv, 0.0f), Hf - 1.0f);
-        if (r2d) {
-            r2d[n * 2] = x0;
-            r2d[n * 2 + 1] = y0;
-        }
-        // replicas r = 0:(x0,y0) 1:(x0,y1) 2:(x1,y0) 3:(x1,y1); e = r*P + t*N + n  (:112)
-        // a replica landing on the bin of a lower replica of the same point can never win: skip it
-        const unsigned long long e0k = (unsigned long long)(ebase + n);
-        const unsigned long long khi = (unsigned long long)hi << 32;
-        const long long b00 = (long long)y0 * a.W + x0;
-        atomicMin(&zb[b00], khi | e0k);
-        if (y1 != y0) atomicMin(&zb[(long long)y1 * a.W + x0], khi | (e0k + (unsigned long long)P));
-        if (x1 != x0) {
-            atomicMin(&zb[(long long)y0 * a.W + x1], khi | (e0k + 2ull * P));
-            if (y1 != y0) atomicMin(&zb[(long long)y1 * a.W + x1], khi | (e0k + 3ull * P));
-        }
-    }
-
-    // block max(z) -> one partial per block (plain store, no same-address atomics)
-    __shared__ float red[kSplatThreads / 64];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = zmax;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float m = red[0];
-#pragma unroll
-        for (int i = 1; i < kSplatThreads / 64; ++i) m = fmaxf(m, red[i]);
-        a.zmax_part[((long long)tl * a.B + b) * a.chunks + chunk] = float_to_ordered(m);
+        c.E[i] = a.E[b * 16 + i];
+        c.Einv[i] = a.Einv[b * 16 + i];
+        c.Tm[i] = a.Tt[((long long)b * a.T_total + t) * 16 + i];
     }
 }
 
-__global__ __launch_bounds__(kSplatThreads) void resolve_kernel(SplatArgs a) {
-    const int tl = blockIdx.y, b = blockIdx.z;  // tl = 0 unless per_frame
-    const long long N = (long long)a.H * a.W;
-    const long long P = a.per_frame ? N : (long long)a.T * N;
-    const int G = a.per_frame ? a.T : 1;
+struct Proj {
+    float z;
+    int x0, y0, x1, y1;  // clamped floor/ceil bins
+    bool valid;
+};
 
-    // sentinel = max(z over the whole predict call) + 1  (:105); per frame in per_frame mode
-    __shared__ unsigned red[kSplatThreads / 64];
+// pc_transform_model.py:54-114 for one pixel.  Used by BOTH kernels so they agree bit for bit.
+__device__ __forceinline__ Proj project(const Camera &c, int x, int y, float d, bool m, float Wf, float Hf) {
+    const float u = (float)x, v = (float)y;
+    const float r0 = dot3(c.Kinv + 0, u, v, 1.0f), r1 = dot3(c.Kinv + 3, u, v, 1.0f), r2 = dot3(c.Kinv + 6, u, v, 1.0f);
+    const float c0 = __fmul_rn(r0, d), c1 = __fmul_rn(r1, d), c2 = __fmul_rn(r2, d);                    // :55-59
+    const float v0 = dot4(c.E + 0, c0, c1, c2, 1.0f), v1 = dot4(c.E + 4, c0, c1, c2, 1.0f),
+                v2 = dot4(c.E + 8, c0, c1, c2, 1.0f), v3 = dot4(c.E + 12, c0, c1, c2, 1.0f);           // :63
+    const float w0 = dot4(c.Tm + 0, v0, v1, v2, v3), w1 = dot4(c.Tm + 4, v0, v1, v2, v3),
+                w2 = dot4(c.Tm + 8, v0, v1, v2, v3), w3 = dot4(c.Tm + 12, v0, v1, v2, v3);             // :68
+    const float e0 = dot4(c.Einv + 0, w0, w1, w2, w3), e1 = dot4(c.Einv + 4, w0, w1, w2, w3),
+                e2 = dot4(c.Einv + 8, w0, w1, w2, w3), e3 = dot4(c.Einv + 12, w0, w1, w2, w3);         // :71
+    const float px = __fdiv_rn(e0, e3), py = __fdiv_rn(e1, e3), z = __fdiv_rn(e2, e3);                // :72-73
+    const float q0 = dot3(c.K + 0, px, py, z), q1 = dot3(c.K + 3, px, py, z), q2 = dot3(c.K + 6, px, py, z);  // :74
+    const float uu = __fdiv_rn(q0, q2), vv = __fdiv_rn(q1, q2);                                       // :75-78
+    Proj p;
+    p.z = z;
+    const bool inb = (uu >= 0.0f) && (uu < Wf) && (vv >= 0.0f) && (vv < Hf);                          // :83-86
+    p.valid = m && (z > 0.0f) && inb;                                                                 // :87-89
+    // :106-114 floor/ceil then clamp (clamping in float first keeps the int conversion in range)
+    p.x0 = (int)fminf(fmaxf(floorf(uu), 0.0f), Wf - 1.0f);
+    p.x1 = (int)fminf(fmaxf(ceilf(uu), 0.0f), Wf - 1.0f);
+    p.y0 = (int)fminf(fmaxf(floorf(vv), 0.0f), Hf - 1.0f);
+    p.y1 = (int)fminf(fmaxf(ceilf(vv), 0.0f), Hf - 1.0f);
+    return p;
+}
+
+// 4 consecutive pixels of a row (x multiple of 4): vector loads when the row allows it
+__device__ __forceinline__ void load4(const SplatArgs &a, long long base, int x, int y, float d[4], bool m[4]) {
+    const long long i = base + (long long)y * a.W + x;
+    if ((a.W & 3) == 0 && x + 3 < a.W) {
+        const float4 dv = *reinterpret_cast<const float4 *>(a.depth + i);
+        const uchar4 mv = *reinterpret_cast<const uchar4 *>(a.mask + i);
+        d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
+        m[0] = mv.x != 0; m[1] = mv.y != 0; m[2] = mv.z != 0; m[3] = mv.w != 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool in = x + k < a.W;
+            d[k] = in ? a.depth[i + k] : 1.0f;
+            m[k] = in ? a.mask[i + k] != 0 : false;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
+    const int tile = blockIdx.x, tl = blockIdx.y, b = blockIdx.z;
+    const int t = a.t_first + tl;
+    const int ty0 = (tile / a.stx) * kSrcTH, tx0 = (tile % a.stx) * kSrcTW;
+    const long long N = (long long)a.H * a.W;
+    Camera cam;
+    load_camera(a, b, t, cam);
+    const long long in_base = ((long long)b * a.T_total + t) * N;
+    const int g = a.per_frame ? tl : 0, G = a.per_frame ? a.T : 1;
+    uint8_t *mark = a.inv_mark + ((long long)b * G + g) * N;
+    long long *r2d = a.out_r2d ? a.out_r2d + ((long long)b * a.T + tl) * N * 2 : nullptr;
+    const float Wf = (float)a.W, Hf = (float)a.H;
+
+    const int y = ty0 + (threadIdx.x >> 4), x = tx0 + (threadIdx.x & 15) * 4;
+    float zmax = -INFINITY;
+    int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
+    if (y < a.H && x < a.W) {
+        float d[4];
+        bool m[4];
+        load4(a, in_base, x, y, d, m);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (x + k >= a.W) break;
+            const Proj p = project(cam, x + k, y, d[k], m[k], Wf, Hf);
+            zmax = fmaxf(zmax, p.z);   // :105 max runs over valid and invalid points alike
+            if (r2d) {
+                const long long n = (long long)y * a.W + x + k;
+                r2d[n * 2] = p.x0;      // :147 floor/floor corner after the clamp
+                r2d[n * 2 + 1] = p.y0;
+            }
+            if (p.valid) {
+                bx0 = min(bx0, p.x0); by0 = min(by0, p.y0);
+                bx1 = max(bx1, p.x1); by1 = max(by1, p.y1);
+            } else {
+                // every invalid point carries depth max+1 and payload 0: marking its bins is enough
+                mark[(long long)p.y0 * a.W + p.x0] = 1;
+                mark[(long long)p.y1 * a.W + p.x0] = 1;
+                mark[(long long)p.y0 * a.W + p.x1] = 1;
+                mark[(long long)p.y1 * a.W + p.x1] = 1;
+            }
+        }
+    }
+    // block reductions: max z, bounding box
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        zmax = fmaxf(zmax, __shfl_xor(zmax, o));
+        bx0 = min(bx0, __shfl_xor(bx0, o)); by0 = min(by0, __shfl_xor(by0, o));
+        bx1 = max(bx1, __shfl_xor(bx1, o)); by1 = max(by1, __shfl_xor(by1, o));
+    }
+    __shared__ float zred[kThreads / 64];
+    __shared__ int bred[kThreads / 64][4];
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        zred[w] = zmax;
+        bred[w][0] = bx0; bred[w][1] = by0; bred[w][2] = bx1; bred[w][3] = by1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) {
+            zmax = fmaxf(zmax, zred[w]);
+            bx0 = min(bx0, bred[w][0]); by0 = min(by0, bred[w][1]);
+            bx1 = max(bx1, bred[w][2]); by1 = max(by1, bred[w][3]);
+        }
+        const long long ntile = (long long)a.stx * a.sty;
+        a.zmax_part[((long long)tl * a.B + b) * ntile + tile] = float_to_ordered(zmax);
+        a.bbox[((long long)b * a.T + tl) * ntile + tile] = make_int4(bx0, by0, bx1, by1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
+    __shared__ unsigned long long zb[kDstTH * kDstTW];   // 16 KB
+    __shared__ unsigned short list[kScan];
+    __shared__ int list_n;
+    __shared__ unsigned red[kThreads / 64];
     __shared__ float sentinel_s;
+
+    const int dtile = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+    const int G = a.per_frame ? a.T : 1, Tg = a.per_frame ? 1 : a.T;
+    const int dy0 = (dtile / a.dtx) * kDstTH, dx0 = (dtile % a.dtx) * kDstTW;
+    const int dy1 = min(dy0 + kDstTH, a.H) - 1, dx1 = min(dx0 + kDstTW, a.W) - 1;
+    const long long N = (long long)a.H * a.W;
+    const long long P = (long long)Tg * N;
+    const int ntile = a.stx * a.sty;
+    const float Wf = (float)a.W, Hf = (float)a.H;
+
+    for (int i = threadIdx.x; i < kDstTH * kDstTW; i += kThreads) zb[i] = kEmpty;
+
+    // sentinel = max(z over the whole predict call) + 1 (:105); one frame's points in per_frame mode
     {
-        const unsigned *part = a.zmax_part + (a.per_frame ? (long long)tl * a.B * a.chunks : 0);
-        const int cnt = (a.per_frame ? 1 : a.T) * a.B * a.chunks;
+        const unsigned *part = a.zmax_part + (a.per_frame ? (long long)g * a.B * ntile : 0);
+        const int cnt = Tg * a.B * ntile;
         unsigned m = 0;
-        for (int i = threadIdx.x; i < cnt; i += kSplatThreads) m = max(m, part[i]);
+        for (int i = threadIdx.x; i < cnt; i += kThreads) m = max(m, part[i]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -178,45 +247,104 @@ __global__ __launch_bounds__(kSplatThreads) void resolve_kernel(SplatArgs a) {
         if (threadIdx.x == 0) {
             unsigned mm = red[0];
 #pragma unroll
-            for (int i = 1; i < kSplatThreads / 64; ++i) mm = max(mm, red[i]);
+            for (int i = 1; i < kThreads / 64; ++i) mm = max(mm, red[i]);
             sentinel_s = __fadd_rn(ordered_to_float(mm), 1.0f);
         }
-        __syncthreads();
     }
-    const float sentinel = sentinel_s;
 
-    const unsigned long long *zb = a.zbuf + ((long long)b * G + tl) * N;
-    const long long out_base = ((long long)b * G + tl) * N;
-    const long long seg_base = ((long long)b * a.T_total + a.t_first + (a.per_frame ? tl : 0)) * N;
+    // ---- rasterise: every source tile whose valid-point bounding box touches this destination tile
+    for (int tt = 0; tt < Tg; ++tt) {
+        const int tl = a.per_frame ? g : tt;     // local frame index
+        const int t = a.t_first + tl;
+        Camera cam;
+        load_camera(a, b, t, cam);
+        const int4 *boxes = a.bbox + ((long long)b * a.T + tl) * ntile;
+        const long long in_base = ((long long)b * a.T_total + t) * N;
+        const unsigned long long ebase = (unsigned long long)tt * N;
+        for (int s0 = 0; s0 < ntile; s0 += kScan) {
+            __syncthreads();
+            if (threadIdx.x == 0) list_n = 0;
+            __syncthreads();
+            const int s = s0 + threadIdx.x;
+            if (s < ntile) {
+                const int4 bb = boxes[s];
+                if (bb.x <= dx1 && bb.z >= dx0 && bb.y <= dy1 && bb.w >= dy0) list[atomicAdd(&list_n, 1)] = (unsigned short)threadIdx.x;
+            }
+            __syncthreads();
+            const int n_hit = list_n;
+            for (int li = 0; li < n_hit; ++li) {
+                const int st = s0 + list[li];
+                const int y = (st / a.stx) * kSrcTH + (threadIdx.x >> 4);
+                const int x = (st % a.stx) * kSrcTW + (threadIdx.x & 15) * 4;
+                if (y >= a.H || x >= a.W) continue;
+                float d[4];
+                bool m[4];
+                load4(a, in_base, x, y, d, m);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (x + k >= a.W) break;
+                    const Proj p = project(cam, x + k, y, d[k], m[k], Wf, Hf);
+                    if (!p.valid) continue;
+                    // replicas r = 0:(x0,y0) 1:(x0,y1) 2:(x1,y0) 3:(x1,y1); e = r*P + t*N + n  (:112).  A replica
+                    // on the bin of a lower replica of the same point can never win the tie-break: skip it.
+                    const unsigned long long e0 = ebase + (unsigned long long)((long long)y * a.W + x + k);
+                    const unsigned long long khi = (unsigned long long)__float_as_uint(p.z) << 32;
+                    const bool in_x0 = p.x0 >= dx0 && p.x0 <= dx1, in_x1 = p.x1 >= dx0 && p.x1 <= dx1 && p.x1 != p.x0;
+                    const bool in_y0 = p.y0 >= dy0 && p.y0 <= dy1, in_y1 = p.y1 >= dy0 && p.y1 <= dy1 && p.y1 != p.y0;
+                    if (in_x0 && in_y0) atomicMin(&zb[(p.y0 - dy0) * kDstTW + (p.x0 - dx0)], khi | e0);
+                    if (in_x0 && in_y1) atomicMin(&zb[(p.y1 - dy0) * kDstTW + (p.x0 - dx0)], khi | (e0 + (unsigned long long)P));
+                    if (in_x1 && in_y0) atomicMin(&zb[(p.y0 - dy0) * kDstTW + (p.x1 - dx0)], khi | (e0 + 2ull * P));
+                    if (in_x1 && in_y1) atomicMin(&zb[(p.y1 - dy0) * kDstTW + (p.x1 - dx0)], khi | (e0 + 3ull * P));
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- resolve this tile's pixels (:120-139)
+    const float sentinel = sentinel_s;
+    const uint8_t *mark = a.inv_mark + ((long long)b * G + g) * N;
+    const long long out_base = ((long long)b * G + g) * N;
+    const long long seg_base = ((long long)b * a.T_total + a.t_first + (a.per_frame ? g : 0)) * N;
     const int C = a.C;
-    for (long long n = (long long)blockIdx.x * kSplatThreads + threadIdx.x; n < N;
-         n += (long long)gridDim.x * kSplatThreads) {
-        const unsigned long long key = zb[n];
-        float dep = -1.0f;  // :136-138
+    for (int i = threadIdx.x; i < kDstTH * kDstTW; i += kThreads) {
+        const int y = dy0 + i / kDstTW, x = dx0 + i % kDstTW;
+        if (y >= a.H || x >= a.W) continue;
+        const long long n = (long long)y * a.W + x;
+        const unsigned long long key = zb[i];
+        float dep;
         long long src = -1;
         if (key != kEmpty) {
-            const unsigned hi = (unsigned)(key >> 32);
-            const long long p = (long long)(key & 0xFFFFFFFFull) % P;  // e -> point index t*N + n
-            if (hi == kInvalidHi) {
-                dep = sentinel;  // won by an invalid point: seg 0 (:133), depth max+1 (:105)
-            } else {
-                dep = __uint_as_float(hi);
-                src = seg_base + p;  // frames are contiguous: t*N + n indexes [t_first.., H, W]
-            }
+            dep = __uint_as_float((unsigned)(key >> 32));
+            src = seg_base + (long long)((key & 0xFFFFFFFFull) % (unsigned long long)P);   // e -> t*N + n
+        } else {
+            dep = mark[n] ? sentinel : -1.0f;   // won by an invalid point (:105,:133) / never touched (:136-138)
         }
         a.out_depth[out_base + n] = dep;
         if (C == 1) {
             a.out_seg[out_base + n] = src >= 0 ? a.seg[src] : (uint8_t)0;
         } else {
-            for (int c = 0; c < C; ++c)
-                a.out_seg[(out_base + n) * C + c] = src >= 0 ? a.seg[src * C + c] : (uint8_t)0;
+            for (int c = 0; c < C; ++c) a.out_seg[(out_base + n) * C + c] = src >= 0 ? a.seg[src * C + c] : (uint8_t)0;
         }
     }
 }
 
-static int splat_chunks(long long N) {
-    long long c = (N + 1023) / 1024;
-    return (int)(c < 1 ? 1 : (c > 512 ? 512 : c));
+struct SplatLayout {
+    size_t bbox_off, zmax_off, mark_off, mark_bytes, total;
+    int stx, sty, dtx, dty;
+};
+
+static SplatLayout splat_layout(int B, int T, int H, int W, int per_frame) {
+    SplatLayout L;
+    L.stx = (W + kSrcTW - 1) / kSrcTW; L.sty = (H + kSrcTH - 1) / kSrcTH;
+    L.dtx = (W + kDstTW - 1) / kDstTW; L.dty = (H + kDstTH - 1) / kDstTH;
+    const size_t ntile = (size_t)L.stx * L.sty, N = (size_t)H * W;
+    L.bbox_off = 0;
+    L.zmax_off = align_up(L.bbox_off + (size_t)B * T * ntile * sizeof(int4), 256);
+    L.mark_off = align_up(L.zmax_off + (size_t)B * T * ntile * sizeof(unsigned), 256);
+    L.mark_bytes = (size_t)B * (per_frame ? T : 1) * N;
+    L.total = align_up(L.mark_off + L.mark_bytes, 256);
+    return L;
 }
 
 }  // namespace pf
@@ -224,12 +352,9 @@ static int splat_chunks(long long N) {
 extern "C" int pf_warp_splat_workspace(int B, int T, int H, int W, int per_frame, size_t *bytes) {
     if (!bytes || B <= 0 || T <= 0 || H <= 0 || W <= 0)
         return pf::fail(PF_EINVAL, "pf_warp_splat_workspace: bad dims B=%d T=%d H=%d W=%d", B, T, H, W);
-    const long long N = (long long)H * W;
-    if (4ll * T * N >= (1ll << 32))
+    if (4ll * T * H * W >= (1ll << 32))
         return pf::fail(PF_EUNSUPPORTED, "pf_warp_splat: 4*T*H*W must be < 2^32 (element index packs in 32 bits)");
-    const size_t zbuf = (size_t)B * (per_frame ? T : 1) * N * sizeof(unsigned long long);
-    const size_t part = (size_t)T * B * pf::splat_chunks(N) * sizeof(unsigned);
-    *bytes = pf::align_up(zbuf, 256) + pf::align_up(part, 256);
+    *bytes = pf::splat_layout(B, T, H, W, per_frame).total;
     return PF_OK;
 }
 
@@ -251,38 +376,35 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     if (ws_bytes < need)
         return pf::fail(PF_EWORKSPACE, "pf_warp_splat: workspace %zu B < required %zu B", ws_bytes, need);
 
-    const long long N = (long long)H * W;
+    const pf::SplatLayout L = pf::splat_layout(B, T, H, W, per_frame);
     pf::SplatArgs a;
     a.depth = depth; a.mask = depth_mask; a.seg = seg;
     a.Kinv = Kinv; a.E = E; a.Tt = T_tgt; a.Einv = Einv; a.K = K;
-    const size_t zbuf_bytes = (size_t)B * (per_frame ? T : 1) * N * sizeof(unsigned long long);
-    a.zbuf = (unsigned long long *)ws;
-    a.zmax_part = (unsigned *)((char *)ws + pf::align_up(zbuf_bytes, 256));
+    a.bbox = (int4 *)((char *)ws + L.bbox_off);
+    a.zmax_part = (unsigned *)((char *)ws + L.zmax_off);
+    a.inv_mark = (uint8_t *)ws + L.mark_off;
     a.out_seg = out_seg; a.out_depth = out_depth; a.out_r2d = (long long *)out_result2d;
     a.B = B; a.T_total = T_total; a.t_first = t_first; a.T = T; a.H = H; a.W = W; a.C = seg_channels;
     a.per_frame = per_frame ? 1 : 0;
-    a.chunks = pf::splat_chunks(N);
+    a.stx = L.stx; a.sty = L.sty; a.dtx = L.dtx; a.dty = L.dty;
     hipStream_t s = (hipStream_t)stream;
+    const int G = per_frame ? T : 1;
 
-    // algorithmic bytes: read depth 4 + mask 1 per source pixel; resolve: seg 1 in, seg 1 + depth 4 out
-    const double src_px = (double)B * T * N, dst_px = (double)B * (per_frame ? T : 1) * N;
+    // algorithmic bytes: source side depth 4 + mask 1 B/px; destination side seg 1 in, seg 1 + depth 4 out
+    const double src_px = (double)B * T * H * W, dst_px = (double)B * G * H * W;
     {
-        pf::ProfScope ps(s, "zbuf_memset", 0, (double)zbuf_bytes);
-        PF_HIP_CHECK(hipMemsetAsync(a.zbuf, 0xFF, zbuf_bytes, s));
+        pf::ProfScope ps(s, "inv_mark_memset", 0, (double)L.mark_bytes);
+        PF_HIP_CHECK(hipMemsetAsync(a.inv_mark, 0, L.mark_bytes, s));
     }
     {
-        pf::ProfScope ps(s, "pf::project_scatter_kernel(pf::SplatArgs)", 0,
-                         src_px * (5.0 + (out_result2d ? 16.0 : 0.0)));
-        hipLaunchKernelGGL(pf::project_scatter_kernel, dim3(a.chunks, T, B), dim3(pf::kSplatThreads), 0, s, a);
-        PF_LAUNCH_CHECK("project_scatter_kernel");
+        pf::ProfScope ps(s, "pf::bin_kernel(pf::SplatArgs)", 0, src_px * (5.0 + (out_result2d ? 16.0 : 0.0)));
+        hipLaunchKernelGGL(pf::bin_kernel, dim3(L.stx * L.sty, T, B), dim3(pf::kThreads), 0, s, a);
+        PF_LAUNCH_CHECK("bin_kernel");
     }
-    long long rb = (N + pf::kSplatThreads - 1) / pf::kSplatThreads;
-    if (rb > 1024) rb = 1024;
     {
-        pf::ProfScope ps(s, "pf::resolve_kernel(pf::SplatArgs)", 0, dst_px * (2.0 * seg_channels + 4.0));
-        hipLaunchKernelGGL(pf::resolve_kernel, dim3((unsigned)rb, per_frame ? T : 1, B), dim3(pf::kSplatThreads),
-                           0, s, a);
-        PF_LAUNCH_CHECK("resolve_kernel");
+        pf::ProfScope ps(s, "pf::raster_kernel(pf::SplatArgs)", 0, dst_px * (2.0 * seg_channels + 4.0));
+        hipLaunchKernelGGL(pf::raster_kernel, dim3(L.dtx * L.dty, G, B), dim3(pf::kThreads), 0, s, a);
+        PF_LAUNCH_CHECK("raster_kernel");
     }
     return PF_OK;
 }
