@@ -3,6 +3,7 @@
 // Replaces the module walk of reference hardnet.py:353-387 (hardnet.forward) and the glue of
 // bg_model.py:61-71,91-102.  The op table comes from the blob (packing.py / hardnet_arch.py); nothing
 // about FC-HarDNet-70 is hard-coded here, so single-op test networks use the same code.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -10,6 +11,7 @@
 #include "conv_mfma.h"
 #include "net_kernels.h"
 #include "pf_blob.h"
+#include "pf_prof.h"
 
 using namespace pf;
 
@@ -106,10 +108,16 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         return t == input ? const_cast<float *>(dense_x) : reinterpret_cast<float *>((char *)ws + off[t]);
     };
 
+    static const bool tag_ops = getenv("PF_PROFILE_OPS") != nullptr;
     for (size_t i = 0; i < p->ops.size(); ++i) {
         const BlobOp &o = p->ops[i];
         const Dims in = d[o.src[0].tensor];
         const Dims out = o.kind == OP_HEAD ? in : d[o.dst];
+        if (tag_ops && prof_enabled()) {
+            char tag[96];
+            snprintf(tag, sizeof(tag), "%02zu %s %u->%u %dx%d", i, p->tensors[o.dst].name, o.cin, o.cout, out.h, out.w);
+            prof_set_tag(tag);
+        }
         if (o.kind == OP_STEM && stem) {
             StemArgs a = *stem;
             a.w = p->dev_weights + p->conv[i].raw_off;
@@ -173,6 +181,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             if ((rc = launch_head(a, s))) return rc;
         }
     }
+    if (tag_ops) prof_set_tag(nullptr);
     return PF_OK;
 }
 

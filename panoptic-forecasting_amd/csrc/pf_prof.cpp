@@ -22,6 +22,7 @@ bool g_on = false;
 std::vector<Rec> g_recs;
 std::vector<std::string> g_labels;
 std::vector<Agg> g_agg;
+std::string g_tag;
 
 int label_id(const char *l) {
     for (size_t i = 0; i < g_labels.size(); ++i)
@@ -42,11 +43,16 @@ void clear_locked() {
 
 bool prof_enabled() { return g_on; }
 
+void prof_set_tag(const char *tag) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_tag = tag ? tag : "";
+}
+
 void prof_begin(hipStream_t s, const char *label, double flops, double bytes) {
     std::lock_guard<std::mutex> lk(g_mu);
     Rec r;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    r.label = label_id(label);
+    r.label = g_tag.empty() ? label_id(label) : label_id((std::string(label) + " @" + g_tag).c_str());
     r.flops = flops;
     r.bytes = bytes;
     (void)hipEventRecord(r.a, s);

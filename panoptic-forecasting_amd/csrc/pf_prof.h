@@ -8,6 +8,8 @@ namespace pf {
 bool prof_enabled();
 void prof_begin(hipStream_t s, const char *label, double flops, double bytes);
 void prof_end(hipStream_t s);
+// optional per-op tag (set by the executor when PF_PROFILE_OPS=1): labels become "<kernel> @<tag>"
+void prof_set_tag(const char *tag);
 
 struct ProfScope {
     hipStream_t s;

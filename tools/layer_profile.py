@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Per-op timing of one bg_forecast step (hipEvents via the library's profiling hooks).
+
+    PF_PROFILE_OPS=1 python tools/layer_profile.py [--batch B] [--steps 5]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('PF_PROFILE_OPS', '1')
+import bench  # noqa: E402
+from panoptic_forecasting_amd import lib as pflib  # noqa: E402
+from panoptic_forecasting_amd.registry import build_model  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=1)
+ap.add_argument('--steps', type=int, default=5)
+args = ap.parse_args()
+model = build_model(bench.model_params())
+model.load_state_dict(bench.calibrated_state_dict())
+batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
+for _ in range(3):
+    model.predict(batch, None)
+torch.cuda.synchronize()
+pflib.profile(True)
+for _ in range(args.steps):
+    model.predict(batch, None)
+torch.cuda.synchronize()
+recs = pflib.profile_results()
+pflib.profile(False)
+tot = sum(r['ms'] for r in recs) / args.steps
+print('total kernel time per step: %.3f ms  (B=%d)' % (tot, args.batch))
+recs.sort(key=lambda r: r['label'].split('@')[-1])
+for r in recs:
+    ms = r['ms'] / args.steps
+    k, _, tag = r['label'].partition(' @')
+    k = k.replace('void pf::', '').replace('(pf::ConvArgs)', '').replace('pf::', '')
+    print('%-44s %-34s %8.1f us %7.1f TF/s %8.0f GB/s' % (tag[:44], k[:34], ms * 1e3, r['flops'] / args.steps / max(ms, 1e-9) / 1e9,
+                                                          r['bytes'] / args.steps / max(ms, 1e-9) / 1e6))
