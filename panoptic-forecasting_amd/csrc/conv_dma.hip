@@ -1,17 +1,17 @@
-// Fast-path fp32 MFMA convolution (stride 1, input width % 4 == 0): LDS-DMA staging + in-workgroup K split.
+// Fast-path fp32 MFMA convolution (input width % 4 == 0): double-buffered LDS-DMA staging + in-workgroup K split.
 //
 // Same GEMM view as conv_mfma.hip (M = 16-pixel row segments, N = 16-cout tiles, K = 4 input channels per
-// v_mfma_f32_16x16x4_f32), re-organised around what the first profile showed (profiles/r01_a_*): the old
-// kernel spent its time in register-staged 4-byte gathers and starved the chip on the low-resolution
-// layers (2-32 workgroups).  Here:
+// v_mfma_f32_16x16x4_f32), re-organised around what the profiles showed (profiles/r01_*): the first kernel
+// spent its time in register-staged 4-byte gathers and starved the chip on the low-resolution layers.
 //   * staging is asynchronous global->LDS DMA in 16-byte pieces (global_load_lds_dwordx4): the halo tile is
 //     stored with a 4-float left apron so every row piece is 16-B aligned in HBM and in LDS; out-of-image
 //     pieces and padding read a zero page.  No VGPR round trip, no ds_write.
-//   * a workgroup is WM x WK waves: WM waves tile 64 pixels each, WK waves split the input-channel chunks
-//     (K) among themselves and are summed through LDS in the epilogue, so a 16x32 or 32x64 layer still
-//     fills the machine ((WM,WK) = (4,1) | (2,2) | (1,4), picked per layer at launch).
-//   * weights are packed per 16-cout tile so the number of cout tiles per workgroup (NT) is also a
-//     launch-time choice (fewer, fatter workgroups at high resolution; more at low resolution).
+//   * two LDS buffers: the DMA of round r+1 is in flight while round r is multiplied; one barrier per round.
+//   * a workgroup is WM x WK waves: WM waves tile 64 pixels each, WK waves split the input-channel chunks (K)
+//     among themselves and are summed through LDS in the epilogue, so a 16x32 or 32x64 layer still fills the
+//     machine ((WM,WK) = (4,1) | (2,2) | (1,4), picked per layer at launch by a small cost model).
+//   * weights are packed per 16-cout tile so the number of cout tiles per workgroup (NT) is a launch-time
+//     choice too (fat workgroups at high resolution, many at low resolution).
 #include "conv_mfma.h"
 #include "pf_prof.h"
 
@@ -19,24 +19,25 @@ namespace pf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int WM, int WK, int NT>
+template <int KS, int STRIDE, int WM, int WK, int NT>
 struct DmaCfg {
-    static constexpr int KC = KS == 3 ? 16 : 32;      // input channels per chunk
+    static constexpr int KC = dma_kc_ct(KS, STRIDE);  // input channels per stage
     static constexpr int MP = 4;                      // M-tiles (16 px) per wave
     static constexpr int TWT = WM == 1 ? 1 : 2;       // tile width in M-tiles
     static constexpr int TW = 16 * TWT;
-    static constexpr int TH = WM * MP / TWT;          // WM=4: 8x32, WM=2: 4x32, WM=1: 4x16 pixels
+    static constexpr int TH = WM * MP / TWT;          // WM=4: 8x32, WM=2: 4x32, WM=1: 4x16 output pixels
     static constexpr int APRON = KS == 3 ? 4 : 0;     // left apron (floats) keeping rows 16-B aligned
-    static constexpr int IW = TW + 2 * APRON;
-    static constexpr int IH = TH + (KS == 3 ? 2 : 0);
+    static constexpr int IW = TW * STRIDE + 2 * APRON;
+    static constexpr int IH = (TH - 1) * STRIDE + KS;
     static constexpr int RAW = IH * IW;
-    static constexpr int PLANE = (RAW + 15) / 32 * 32 + 16;  // == 16 (mod 32): conflict-free A reads
+    static constexpr int PLANE = (RAW + 15) / 32 * 32 + 16;  // == 16 (mod 32): conflict-free stride-1 A reads
     static constexpr int PP = PLANE / 4, RP = RAW / 4, RW = IW / 4;  // 16-B pieces per plane / real / per row
     static constexpr int KS2 = KS * KS;
     static constexpr int WFRAG = (KC / 4) * KS2 * 64;  // floats per (cout tile, chunk)
     static constexpr int SLOT = KC * PLANE + NT * WFRAG;  // floats per K-split slot
+    static constexpr int BUF = WK * SLOT;
     static constexpr int RED = (WK - 1) * WM * MP * NT * 256;
-    static constexpr int LDS_FLOATS = WK * SLOT > RED ? WK * SLOT : RED;
+    static constexpr int LDS_FLOATS = 2 * BUF > RED ? 2 * BUF : RED;
     static_assert(PLANE % 4 == 0 && PLANE >= RAW && PLANE % 32 == 16, "plane stride");
 };
 
@@ -45,16 +46,17 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int KS, int WM, int WK, int NT>
-__global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
-    using C = DmaCfg<KS, WM, WK, NT>;
+template <int KS, int STRIDE, int WM, int WK, int NT>
+__global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
+    using C = DmaCfg<KS, STRIDE, WM, WK, NT>;
+    constexpr int NTHR = 64 * WM * WK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wk = wave / WM;
     const int tileY = blockIdx.x / a.tilesX, tileX = blockIdx.x - tileY * a.tilesX;
     const int tile0 = blockIdx.y * NT, b = blockIdx.z;   // first cout tile of this workgroup
-    const int iy0 = tileY * C::TH - KS / 2, ix0 = tileX * C::TW - C::APRON;
+    const int iy0 = tileY * C::TH * STRIDE - KS / 2, ix0 = tileX * C::TW * STRIDE - C::APRON;
 
     f32x4 acc[C::MP][NT];
 #pragma unroll
@@ -67,58 +69,72 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
     for (int m = 0; m < C::MP; ++m) {
         const int mt = wm * C::MP + m;
         const int ty = mt / C::TWT, tx0 = (mt % C::TWT) * 16;
-        abase[m] = (lane >> 4) * C::PLANE + ty * C::IW + tx0 + (lane & 15) + (C::APRON - KS / 2);
+        abase[m] = (lane >> 4) * C::PLANE + ty * STRIDE * C::IW + (tx0 + (lane & 15)) * STRIDE + (C::APRON - KS / 2);
     }
 
     const size_t in_plane = (size_t)a.Hin * a.Win;
     const float *zero = a.zero_page;
     const int nrounds = (a.nchunks + WK - 1) / WK;
 
-    for (int round = 0; round < nrounds; ++round) {
-        __syncthreads();  // previous round fully consumed
-        // ---- stage WK chunks (inputs + weights) with 16-B DMA pieces; piece p of a region lands at p*16 B
+    // issue the DMA of one round (WK chunks: inputs + weights) into buffer `buf`; piece p lands at p*16 B
+    auto stage = [&](int round, float *buf) {
 #pragma unroll
         for (int s = 0; s < WK; ++s) {
             const int chunk = round * WK + s;
             if (chunk >= a.nchunks) break;
-            float *slot = smem + s * C::SLOT;
+            float *slot = buf + s * C::SLOT;
             constexpr int NPI = C::KC * C::PP;
 #pragma unroll
-            for (int it = 0; it < (NPI + 255) / 256; ++it) {
-                const int p = it * 256 + tid;
+            for (int it = 0; it < (NPI + NTHR - 1) / NTHR; ++it) {
+                const int p = it * NTHR + tid;
                 if (p < NPI) {
                     const int cl = p / C::PP, q = p - cl * C::PP;
                     const int row = q / C::RW, j = q - row * C::RW;
                     const int c = chunk * C::KC + cl, gy = iy0 + row, gx = ix0 + j * 4;
                     const float *g = zero;
                     if (q < C::RP && c < a.Cin && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) {
-                        int sidx = 0;
-                        while (sidx + 1 < a.n_src && c >= a.src_cstart[sidx + 1]) ++sidx;
-                        const size_t ch = (size_t)b * a.src_ctotal[sidx] + a.src_choff[sidx] + (c - a.src_cstart[sidx]);
-                        g = a.src[sidx] + ch * in_plane + (size_t)gy * a.Win + gx;
+                        // source-range lookup as a select chain over kernel-argument scalars: a dynamically
+                        // indexed a.src[sidx] becomes a vector load whose vmcnt wait serialises the DMA queue
+                        const float *sp = a.src[0];
+                        int ctot = a.src_ctotal[0], coff = a.src_choff[0];
+#pragma unroll
+                        for (int k = 1; k < kConvMaxSrc; ++k) {
+                            const bool take = k < a.n_src && c >= a.src_cstart[k];
+                            sp = take ? a.src[k] : sp;
+                            ctot = take ? a.src_ctotal[k] : ctot;
+                            coff = take ? a.src_choff[k] - a.src_cstart[k] : coff;
+                        }
+                        const size_t ch = (size_t)b * ctot + coff + c;
+                        g = sp + ch * in_plane + (size_t)gy * a.Win + gx;
                     }
-                    dma16(g, slot + (it * 256 + wave * 64) * 4);
+                    dma16(g, slot + (it * NTHR + wave * 64) * 4);
                 }
             }
             constexpr int NPW = NT * C::WFRAG / 4;
             float *wslot = slot + C::KC * C::PLANE;
 #pragma unroll
-            for (int it = 0; it < (NPW + 255) / 256; ++it) {
-                const int p = it * 256 + tid;
+            for (int it = 0; it < (NPW + NTHR - 1) / NTHR; ++it) {
+                const int p = it * NTHR + tid;
                 if (p < NPW) {
                     const int n = p / (C::WFRAG / 4), q = p - n * (C::WFRAG / 4);
                     const float *g = zero;
                     if (tile0 + n < a.ntiles)
                         g = a.wpk + ((size_t)(tile0 + n) * a.nchunks + chunk) * C::WFRAG + q * 4;
-                    dma16(g, wslot + (it * 256 + wave * 64) * 4);
+                    dma16(g, wslot + (it * NTHR + wave * 64) * 4);
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // ---- MFMA: wave (wm, wk) consumes slot wk
+    };
+
+    stage(0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int round = 0; round < nrounds; ++round) {
+        float *cur = smem + (round & 1) * C::BUF;
+        if (round + 1 < nrounds) stage(round + 1, smem + ((round + 1) & 1) * C::BUF);   // in flight during the MFMAs
         if (round * WK + wk < a.nchunks) {
-            const float *in_s = smem + wk * C::SLOT;
+            const float *in_s = cur + wk * C::SLOT;
             const float *w_s = in_s + C::KC * C::PLANE;
 #pragma unroll
             for (int kg = 0; kg < C::KC / 4; ++kg) {
@@ -138,11 +154,12 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next round landed
+        __syncthreads();                                    // ... and everyone is done with `cur`
     }
 
     // ---- K-split reduction through LDS: waves wk>0 publish, wave wk==0 sums
     if (WK > 1) {
-        __syncthreads();
         f32x4 *red = reinterpret_cast<f32x4 *>(smem);
         if (wk > 0) {
 #pragma unroll
@@ -164,6 +181,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
 
     // ---- epilogue (same fragment map as conv_mfma.hip): bias + ReLU, NCHW float4 stores
     const size_t out_plane = (size_t)a.Hout * a.Wout;
+    const bool vec = (a.Wout & 3) == 0;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int co = (tile0 + n) * 16 + (lane & 15);
@@ -175,67 +193,83 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
             const int mt = wm * C::MP + m;
             const int oy = tileY * C::TH + mt / C::TWT;
             const int ox = tileX * C::TW + (mt % C::TWT) * 16 + (lane >> 4) * 4;
-            if (oy >= a.Hout || ox >= a.Wout) continue;   // Wout % 4 == 0 on this path
+            if (oy >= a.Hout || ox >= a.Wout) continue;
             f32x4 v = acc[m][n];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] += bias;
                 if (a.relu) v[r] = fmaxf(v[r], 0.f);
             }
-            *reinterpret_cast<f32x4 *>(dplane + (size_t)oy * a.Wout + ox) = v;
+            float *p = dplane + (size_t)oy * a.Wout + ox;
+            if (vec && ox + 3 < a.Wout) {
+                *reinterpret_cast<f32x4 *>(p) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ox + r < a.Wout) p[r] = v[r];
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int KS, int WM, int WK, int NT>
+template <int KS, int STRIDE, int WM, int WK, int NT>
 static int launch_dma_cfg(const ConvArgs &a0, int B, hipStream_t s) {
-    using C = DmaCfg<KS, WM, WK, NT>;
+    using C = DmaCfg<KS, STRIDE, WM, WK, NT>;
     ConvArgs a = a0;
     a.tilesX = (a.Wout + C::TW - 1) / C::TW;
     a.tilesY = (a.Hout + C::TH - 1) / C::TH;
     const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_dma_kernel<KS, WM, WK, NT>),
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_dma_kernel<KS, STRIDE, WM, WK, NT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     char label[96];
-    snprintf(label, sizeof(label), "void pf::conv_dma_kernel<%d, %d, %d, %d>(pf::ConvArgs)", KS, WM, WK, NT);
+    snprintf(label, sizeof(label), "void pf::conv_dma_kernel<%d, %d, %d, %d, %d>(pf::ConvArgs)", KS, STRIDE, WM, WK, NT);
     const double px = (double)B * a.Hout * a.Wout;
     ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * KS * KS,
                  4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * KS * KS));
-    hipLaunchKernelGGL((conv_dma_kernel<KS, WM, WK, NT>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B),
-                       dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_dma_kernel<KS, STRIDE, WM, WK, NT>),
+                       dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(64 * WM * WK), lds, s, a);
     PF_LAUNCH_CHECK("conv_dma_kernel");
     return PF_OK;
 }
 
-static void tile_dims(int wm, int &th, int &tw) {
-    tw = wm == 1 ? 16 : 32;
-    th = wm * 4 / (tw / 16);
+// Cost model (shader cycles) for one (WM, WK, NT) shape: the larger of the chip-wide MFMA time and the serial
+// time of one workgroup times the number of workgroup waves; calibrated against profiles/r01_b_*.
+static double shape_cost(const ConvArgs &a, int ks, int stride, int B, int wm, int wk, int nt) {
+    const int kc = dma_kc(ks, stride), ks2 = ks * ks;
+    const int tw = wm == 1 ? 16 : 32, th = wm * 4 / (tw / 16);
+    const double px_tiles = (double)B * ((a.Hout + th - 1) / th) * ((a.Wout + tw - 1) / tw);
+    const int cblocks = (a.ntiles + nt - 1) / nt;
+    const double wgs = px_tiles * cblocks;
+    const int nchunks = (a.Cin + kc - 1) / kc, rounds = (nchunks + wk - 1) / wk;
+    const double mfma_round = (kc / 4) * ks2 * 4.0 * nt * 32.0;            // cycles of MFMA issue per wave per round
+    const int iw = tw * stride + (ks == 3 ? 8 : 0), ih = (th - 1) * stride + ks;
+    const double lds_bytes = 2.0 * wk * (kc * (ih * iw + 32) + nt * (kc / 4) * ks2 * 64) * 4.0;
+    int occ = (int)(160.0 * 1024 / lds_bytes);
+    occ = occ < 1 ? 1 : (occ > 4 ? 4 : occ);
+    const double stage_round = 1800.0;                                      // exposed DMA latency per round, cycles
+    const double wg_serial = 3000.0 + rounds * (mfma_round + stage_round / (occ > 1 ? 2 : 1)) + (wk > 1 ? 1500.0 : 0.0);
+    const double waves = (double)(long)((wgs + 256.0 * occ - 1) / (256.0 * occ));
+    const double serial = waves * wg_serial;
+    // all MFMA work (padded cout tiles included; each chunk is multiplied by the WM pixel waves once)
+    const double chip = wgs * wm * nchunks * mfma_round / (1024.0 * 0.85);
+    return serial > chip ? serial : chip;
 }
 
-// Pick (WM, WK, NT): fill >= ~2 workgroups per CU if the layer allows it, then prefer fat workgroups.
-static void pick_shape(const ConvArgs &a, int B, int &wm, int &wk, int &nt) {
-    const int ntiles = a.ntiles;
-    double best = -1;
+static void pick_shape(const ConvArgs &a, int ks, int stride, int B, int &wm, int &wk, int &nt) {
+    double best = 1e300;
     const int wms[3] = {4, 2, 1};
     for (int i = 0; i < 3; ++i) {
-        int th, tw;
-        tile_dims(wms[i], th, tw);
-        const long px_tiles = (long)B * ((a.Hout + th - 1) / th) * ((a.Wout + tw - 1) / tw);
         const int wki = 4 / wms[i];
         const int ntmax = wki == 4 ? 2 : 4;
-        for (int n = 1; n <= ntmax && n <= ntiles; ++n) {
-            const long wgs = px_tiles * ((ntiles + n - 1) / n);
-            const double fill = wgs >= 512 ? 1.0 : (double)wgs / 512.0;
-            // padded cout tiles are wasted MFMAs; fat tiles amortise staging
-            const double eff = (double)ntiles / (((ntiles + n - 1) / n) * n);
-            const double score = fill * 100.0 + eff * 5.0 + wms[i] * 1.0 + n * 0.5;
-            if (score > best) {
-                best = score;
+        for (int n = 1; n <= ntmax && n <= a.ntiles; ++n) {
+            const double c = shape_cost(a, ks, stride, B, wms[i], wki, n);
+            if (c < best * 0.999) {
+                best = c;
                 wm = wms[i];
                 wk = wki;
                 nt = n;
@@ -244,19 +278,22 @@ static void pick_shape(const ConvArgs &a, int B, int &wm, int &wk, int &nt) {
     }
 }
 
-int launch_conv_dma(const ConvArgs &a, int ks, int B, hipStream_t s) {
+int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t s) {
     int wm = 4, wk = 1, nt = 1;
-    pick_shape(a, B, wm, wk, nt);
-#define PF_CASE(KS_, WM_, WK_, NT_) \
-    if (ks == KS_ && wm == WM_ && nt == NT_) return launch_dma_cfg<KS_, WM_, WK_, NT_>(a, B, s);
-    PF_CASE(3, 4, 1, 1) PF_CASE(3, 4, 1, 2) PF_CASE(3, 4, 1, 3) PF_CASE(3, 4, 1, 4)
-    PF_CASE(3, 2, 2, 1) PF_CASE(3, 2, 2, 2) PF_CASE(3, 2, 2, 3) PF_CASE(3, 2, 2, 4)
-    PF_CASE(3, 1, 4, 1) PF_CASE(3, 1, 4, 2)
-    PF_CASE(1, 4, 1, 1) PF_CASE(1, 4, 1, 2) PF_CASE(1, 4, 1, 3) PF_CASE(1, 4, 1, 4)
-    PF_CASE(1, 2, 2, 1) PF_CASE(1, 2, 2, 2) PF_CASE(1, 2, 2, 3) PF_CASE(1, 2, 2, 4)
-    PF_CASE(1, 1, 4, 1) PF_CASE(1, 1, 4, 2)
+    pick_shape(a, ks, stride, B, wm, wk, nt);
+#define PF_CASE(KS_, ST_, WM_, WK_, NT_) \
+    if (ks == KS_ && stride == ST_ && wm == WM_ && nt == NT_) return launch_dma_cfg<KS_, ST_, WM_, WK_, NT_>(a, B, s);
+    PF_CASE(3, 1, 4, 1, 1) PF_CASE(3, 1, 4, 1, 2) PF_CASE(3, 1, 4, 1, 3) PF_CASE(3, 1, 4, 1, 4)
+    PF_CASE(3, 1, 2, 2, 1) PF_CASE(3, 1, 2, 2, 2) PF_CASE(3, 1, 2, 2, 3) PF_CASE(3, 1, 2, 2, 4)
+    PF_CASE(3, 1, 1, 4, 1) PF_CASE(3, 1, 1, 4, 2)
+    PF_CASE(3, 2, 4, 1, 1) PF_CASE(3, 2, 4, 1, 2) PF_CASE(3, 2, 4, 1, 3) PF_CASE(3, 2, 4, 1, 4)
+    PF_CASE(3, 2, 2, 2, 1) PF_CASE(3, 2, 2, 2, 2) PF_CASE(3, 2, 2, 2, 3) PF_CASE(3, 2, 2, 2, 4)
+    PF_CASE(3, 2, 1, 4, 1) PF_CASE(3, 2, 1, 4, 2)
+    PF_CASE(1, 1, 4, 1, 1) PF_CASE(1, 1, 4, 1, 2) PF_CASE(1, 1, 4, 1, 3) PF_CASE(1, 1, 4, 1, 4)
+    PF_CASE(1, 1, 2, 2, 1) PF_CASE(1, 1, 2, 2, 2) PF_CASE(1, 1, 2, 2, 3) PF_CASE(1, 1, 2, 2, 4)
+    PF_CASE(1, 1, 1, 4, 1) PF_CASE(1, 1, 1, 4, 2)
 #undef PF_CASE
-    return fail(PF_EUNSUPPORTED, "conv_dma: no kernel for ks=%d wm=%d nt=%d", ks, wm, nt);
+    return fail(PF_EUNSUPPORTED, "conv_dma: no kernel for ks=%d stride=%d wm=%d nt=%d", ks, stride, wm, nt);
 }
 
 // per-tile packing: [cout tile][chunk][kgroup][tap][64 lanes]

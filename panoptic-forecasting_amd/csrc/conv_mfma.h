@@ -45,10 +45,11 @@ void pack_conv_weights(const float *w_oihw, int cin, int cout, const ConvTiling 
 // Enqueue one conv for a batch of B images (generic path: any stride/width).
 int launch_conv(const ConvArgs &a, const ConvTiling &t, int B, hipStream_t stream);
 
-// Fast path (stride 1, Win % 4 == 0): a.wpk must point at pack_conv_weights_tiled() output and
-// a.nchunks = ceil(Cin / kc) with kc = dma_kc(ks).
-inline int dma_kc(int ks) { return ks == 3 ? 16 : 32; }
+// Fast path (Win % 4 == 0): a.wpk must point at pack_conv_weights_tiled() output and
+// a.nchunks = ceil(Cin / kc) with kc = dma_kc(ks, stride) input channels per double-buffered stage.
+constexpr int dma_kc_ct(int ks, int stride) { return ks == 1 ? 16 : (stride == 2 ? 4 : 8); }
+inline int dma_kc(int ks, int stride) { return dma_kc_ct(ks, stride); }
 void pack_conv_weights_tiled(const float *w_oihw, int cin, int cout, int ks, int kc, float *out);
-int launch_conv_dma(const ConvArgs &a, int ks, int B, hipStream_t stream);
+int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t stream);
 
 }  // namespace pf

@@ -156,10 +156,10 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.relu = (int)o.relu;
             a.zero_page = p->dev_weights;   // first 64 floats of the weight arena are zeros
             a.ntiles = ((int)o.cout + 15) / 16;
-            if (o.stride == 1 && (in.w & 3) == 0) {
+            if ((in.w & 3) == 0) {
                 a.wpk = p->dev_weights + p->conv[i].tiled_off;
                 a.nchunks = p->conv[i].tiled_chunks;
-                rc = launch_conv_dma(a, (int)o.k, B, s);
+                rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s);
             } else {
                 a.nchunks = p->conv[i].tiling.nchunks;
                 rc = launch_conv(a, p->conv[i].tiling, B, s);
@@ -243,8 +243,8 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
         const size_t nb = (size_t)c.tiling.cout_blocks * c.tiling.nt * 16;
         host.resize(host.size() + nb, 0.f);
         memcpy(host.data() + c.bias_off, wts + o.b_off, o.cout * sizeof(float));
-        if (o.stride == 1) {
-            const int kc = dma_kc((int)o.k);
+        {
+            const int kc = dma_kc((int)o.k, (int)o.stride);
             c.tiled_chunks = ((int)o.cin + kc - 1) / kc;
             c.tiled_off = host.size();
             host.resize(host.size() + (size_t)((o.cout + 15) / 16) * c.tiled_chunks * (kc / 4) * o.k * o.k * 64);
