@@ -15,6 +15,10 @@
 #include "conv_mfma.h"
 #include "pf_prof.h"
 
+#ifndef PF_ABLATE
+#define PF_ABLATE 0
+#endif
+
 namespace pf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -132,8 +136,15 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
 
     for (int round = 0; round < nrounds; ++round) {
         float *cur = smem + (round & 1) * C::BUF;
+#if PF_ABLATE == 1   /* no staging after the prologue: MFMA + LDS-read time only */
+#else
         if (round + 1 < nrounds) stage(round + 1, smem + ((round + 1) & 1) * C::BUF);   // in flight during the MFMAs
+#endif
+#if PF_ABLATE == 2   /* staging only */
+        if (round * WK + wk < a.nchunks && a.relu == 12345) {
+#else
         if (round * WK + wk < a.nchunks) {
+#endif
             const float *in_s = cur + wk * C::SLOT;
             const float *w_s = in_s + C::KC * C::PLANE;
 #pragma unroll
@@ -257,7 +268,10 @@ static double shape_cost(const ConvArgs &a, int ks, int stride, int B, int wm, i
     const double serial = waves * wg_serial;
     // all MFMA work (padded cout tiles included; each chunk is multiplied by the WM pixel waves once)
     const double chip = wgs * wm * nchunks * mfma_round / (1024.0 * 0.85);
-    return serial > chip ? serial : chip;
+    // LDS-DMA volume: measured ~5.4 TB/s chip-wide from L2/MALL (ablation run, 2.1 GHz => ~2500 B/cycle)
+    const double dma = wgs * nchunks * (kc * (ih * iw + 32.0) + nt * (kc / 4) * ks2 * 64.0) * 4.0 / 2500.0;
+    double c = serial > chip ? serial : chip;
+    return c > dma ? c : dma;
 }
 
 static void pick_shape(const ConvArgs &a, int ks, int stride, int B, int &wm, int &wk, int &nt) {
@@ -266,7 +280,7 @@ static void pick_shape(const ConvArgs &a, int ks, int stride, int B, int &wm, in
     for (int i = 0; i < 3; ++i) {
         const int wki = 4 / wms[i];
         const int ntmax = wki == 4 ? 2 : 4;
-        for (int n = 1; n <= ntmax && n <= a.ntiles; ++n) {
+        for (int n = ntmax < a.ntiles ? ntmax : a.ntiles; n >= 1; --n) {   // ties go to the fatter workgroup
             const double c = shape_cost(a, ks, stride, B, wms[i], wki, n);
             if (c < best * 0.999) {
                 best = c;

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libpfhip.so')
+LIB_PATH = os.environ.get('PF_LIBPFHIP') or os.path.join(_HERE, 'csrc', 'libpfhip.so')   # env override: A/B builds
 
 _c = ctypes
 _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
