@@ -10,14 +10,14 @@
 // (profiles/r01_a_first_path_kernel_stats.txt).  This version is a two-pass binning rasteriser:
 //
 //   bin_kernel     one workgroup per 16x64 SOURCE tile: exact-order fp32 projection (this file is built with
-//                  -ffp-contract=off; every product/sum rounded separately, IEEE divides), block max(z)
-//                  partial, the bounding box of the destination bins its VALID points reach, a byte mark per
-//                  bin reached by an INVALID point (plain stores of the constant 1 — no atomics needed),
-//                  optional result2d.
-//   raster_kernel  one workgroup per 32x64 DESTINATION tile: scans the bounding boxes, re-projects only the
-//                  source tiles that can reach it, and resolves "min depth, ties -> lowest element index"
-//                  with 64-bit ds_min on a packed key in a 16 KB LDS z-buffer it alone owns; then writes
-//                  seg/depth for its pixels.  The z-buffer never exists in HBM.
+//                  -ffp-contract=off; every product/sum rounded separately, IEEE divides), stored as 8 B per
+//                  point {bits(z), packed bins}; block max(z) partial; the bounding box of the destination bins
+//                  its VALID points reach; a byte mark per bin reached by an INVALID point (plain stores of the
+//                  constant 1 - no atomics needed); optional result2d.
+//   raster_kernel  one workgroup per 32x128 DESTINATION tile: scans the bounding boxes, re-reads the stored
+//                  projections (8 B/point) of only the source tiles that can reach it, and resolves "min depth,
+//                  ties -> lowest element index" with 64-bit ds_min on a packed key in a 32 KB LDS z-buffer it
+//                  alone owns; then writes seg/depth for its pixels.  The z-buffer never exists in HBM.
 //
 // Packed key (valid points have z > 0, so raw fp32 bits are monotone as unsigned):
 //     [ bits(z) : 32 | e : 32 ],  e = r*P + t*N + n  (corner replica r, P = T*N)   — pc_transform_model.py:112
@@ -32,7 +32,7 @@ namespace pf {
 constexpr unsigned long long kEmpty = ~0ull;
 constexpr int kThreads = 256;
 constexpr int kSrcTH = 16, kSrcTW = 64;   // source tile (pixels); 256 threads x 4 consecutive pixels
-constexpr int kDstTH = 32, kDstTW = 64;   // destination tile owned by one raster workgroup
+constexpr int kDstTH = 32, kDstTW = 128;  // destination tile owned by one raster workgroup (32 KB LDS)
 constexpr int kScan = 256;                // bounding boxes tested per scan batch
 
 struct SplatArgs {
@@ -43,6 +43,7 @@ struct SplatArgs {
     int4 *bbox;           // [B][T][src tiles]  (x0min, y0min, x1max, y1max) of valid points' bins
     unsigned *zmax_part;  // [T][B][src tiles]  order-preserving u32 of the block max(z)
     uint8_t *inv_mark;    // [B*G][N]           1 where an invalid point lands
+    uint2 *proj;          // [B][T][N]          {bits(z), x0 | y0<<13 | (x1!=x0)<<26 | (y1!=y0)<<27 | valid<<28}
     uint8_t *out_seg;
     float *out_depth;
     long long *out_r2d;
@@ -165,11 +166,17 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
         float d[4];
         bool m[4];
         load4(a, in_base, x, y, d, m);
+        uint2 *pj = a.proj + ((long long)b * a.T + tl) * N + (long long)y * a.W + x;
+        unsigned pk[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (x + k >= a.W) break;
             const Proj p = project(cam, x + k, y, d[k], m[k], Wf, Hf);
             zmax = fmaxf(zmax, p.z);   // :105 max runs over valid and invalid points alike
+            pk[2 * k] = __float_as_uint(p.z);
+            pk[2 * k + 1] = (unsigned)p.x0 | ((unsigned)p.y0 << 13) | ((unsigned)(p.x1 != p.x0) << 26) |
+                            ((unsigned)(p.y1 != p.y0) << 27) | ((unsigned)p.valid << 28);
+            if ((a.W & 3) != 0) pj[k] = make_uint2(pk[2 * k], pk[2 * k + 1]);
             if (r2d) {
                 const long long n = (long long)y * a.W + x + k;
                 r2d[n * 2] = p.x0;      // :147 floor/floor corner after the clamp
@@ -185,6 +192,10 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
                 mark[(long long)p.y0 * a.W + p.x1] = 1;
                 mark[(long long)p.y1 * a.W + p.x1] = 1;
             }
+        }
+        if ((a.W & 3) == 0) {   // the raster pass re-reads these instead of re-projecting (coalesced 32 B per thread)
+            reinterpret_cast<uint4 *>(pj)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            reinterpret_cast<uint4 *>(pj)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
         }
     }
     // block reductions: max z, bounding box
@@ -230,7 +241,6 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
     const long long N = (long long)a.H * a.W;
     const long long P = (long long)Tg * N;
     const int ntile = a.stx * a.sty;
-    const float Wf = (float)a.W, Hf = (float)a.H;
 
     for (int i = threadIdx.x; i < kDstTH * kDstTW; i += kThreads) zb[i] = kEmpty;
 
@@ -255,11 +265,8 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
     // ---- rasterise: every source tile whose valid-point bounding box touches this destination tile
     for (int tt = 0; tt < Tg; ++tt) {
         const int tl = a.per_frame ? g : tt;     // local frame index
-        const int t = a.t_first + tl;
-        Camera cam;
-        load_camera(a, b, t, cam);
         const int4 *boxes = a.bbox + ((long long)b * a.T + tl) * ntile;
-        const long long in_base = ((long long)b * a.T_total + t) * N;
+        const uint2 *pbase = a.proj + ((long long)b * a.T + tl) * N;
         const unsigned long long ebase = (unsigned long long)tt * N;
         for (int s0 = 0; s0 < ntile; s0 += kScan) {
             __syncthreads();
@@ -277,24 +284,35 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
                 const int y = (st / a.stx) * kSrcTH + (threadIdx.x >> 4);
                 const int x = (st % a.stx) * kSrcTW + (threadIdx.x & 15) * 4;
                 if (y >= a.H || x >= a.W) continue;
-                float d[4];
-                bool m[4];
-                load4(a, in_base, x, y, d, m);
+                const uint2 *pj = pbase + (long long)y * a.W + x;
+                unsigned pk[8];
+                if ((a.W & 3) == 0) {
+                    const uint4 q0 = reinterpret_cast<const uint4 *>(pj)[0], q1 = reinterpret_cast<const uint4 *>(pj)[1];
+                    pk[0] = q0.x; pk[1] = q0.y; pk[2] = q0.z; pk[3] = q0.w;
+                    pk[4] = q1.x; pk[5] = q1.y; pk[6] = q1.z; pk[7] = q1.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint2 q = x + k < a.W ? pj[k] : make_uint2(0u, 0u);
+                        pk[2 * k] = q.x; pk[2 * k + 1] = q.y;
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (x + k >= a.W) break;
-                    const Proj p = project(cam, x + k, y, d[k], m[k], Wf, Hf);
-                    if (!p.valid) continue;
+                    const unsigned f = pk[2 * k + 1];
+                    if (!((f >> 28) & 1u)) continue;   // invalid points were handled by the byte marks
+                    const int px0 = (int)(f & 8191u), py0 = (int)((f >> 13) & 8191u);
+                    const int px1 = px0 + (int)((f >> 26) & 1u), py1 = py0 + (int)((f >> 27) & 1u);
                     // replicas r = 0:(x0,y0) 1:(x0,y1) 2:(x1,y0) 3:(x1,y1); e = r*P + t*N + n  (:112).  A replica
                     // on the bin of a lower replica of the same point can never win the tie-break: skip it.
                     const unsigned long long e0 = ebase + (unsigned long long)((long long)y * a.W + x + k);
-                    const unsigned long long khi = (unsigned long long)__float_as_uint(p.z) << 32;
-                    const bool in_x0 = p.x0 >= dx0 && p.x0 <= dx1, in_x1 = p.x1 >= dx0 && p.x1 <= dx1 && p.x1 != p.x0;
-                    const bool in_y0 = p.y0 >= dy0 && p.y0 <= dy1, in_y1 = p.y1 >= dy0 && p.y1 <= dy1 && p.y1 != p.y0;
-                    if (in_x0 && in_y0) atomicMin(&zb[(p.y0 - dy0) * kDstTW + (p.x0 - dx0)], khi | e0);
-                    if (in_x0 && in_y1) atomicMin(&zb[(p.y1 - dy0) * kDstTW + (p.x0 - dx0)], khi | (e0 + (unsigned long long)P));
-                    if (in_x1 && in_y0) atomicMin(&zb[(p.y0 - dy0) * kDstTW + (p.x1 - dx0)], khi | (e0 + 2ull * P));
-                    if (in_x1 && in_y1) atomicMin(&zb[(p.y1 - dy0) * kDstTW + (p.x1 - dx0)], khi | (e0 + 3ull * P));
+                    const unsigned long long khi = (unsigned long long)pk[2 * k] << 32;
+                    const bool in_x0 = px0 >= dx0 && px0 <= dx1, in_x1 = px1 >= dx0 && px1 <= dx1 && px1 != px0;
+                    const bool in_y0 = py0 >= dy0 && py0 <= dy1, in_y1 = py1 >= dy0 && py1 <= dy1 && py1 != py0;
+                    if (in_x0 && in_y0) atomicMin(&zb[(py0 - dy0) * kDstTW + (px0 - dx0)], khi | e0);
+                    if (in_x0 && in_y1) atomicMin(&zb[(py1 - dy0) * kDstTW + (px0 - dx0)], khi | (e0 + (unsigned long long)P));
+                    if (in_x1 && in_y0) atomicMin(&zb[(py0 - dy0) * kDstTW + (px1 - dx0)], khi | (e0 + 2ull * P));
+                    if (in_x1 && in_y1) atomicMin(&zb[(py1 - dy0) * kDstTW + (px1 - dx0)], khi | (e0 + 3ull * P));
                 }
             }
         }
@@ -330,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
 }
 
 struct SplatLayout {
-    size_t bbox_off, zmax_off, mark_off, mark_bytes, total;
+    size_t bbox_off, zmax_off, mark_off, mark_bytes, proj_off, total;
     int stx, sty, dtx, dty;
 };
 
@@ -343,7 +361,8 @@ static SplatLayout splat_layout(int B, int T, int H, int W, int per_frame) {
     L.zmax_off = align_up(L.bbox_off + (size_t)B * T * ntile * sizeof(int4), 256);
     L.mark_off = align_up(L.zmax_off + (size_t)B * T * ntile * sizeof(unsigned), 256);
     L.mark_bytes = (size_t)B * (per_frame ? T : 1) * N;
-    L.total = align_up(L.mark_off + L.mark_bytes, 256);
+    L.proj_off = align_up(L.mark_off + L.mark_bytes, 256);
+    L.total = align_up(L.proj_off + (size_t)B * T * N * sizeof(uint2), 256);
     return L;
 }
 
@@ -354,6 +373,8 @@ extern "C" int pf_warp_splat_workspace(int B, int T, int H, int W, int per_frame
         return pf::fail(PF_EINVAL, "pf_warp_splat_workspace: bad dims B=%d T=%d H=%d W=%d", B, T, H, W);
     if (4ll * T * H * W >= (1ll << 32))
         return pf::fail(PF_EUNSUPPORTED, "pf_warp_splat: 4*T*H*W must be < 2^32 (element index packs in 32 bits)");
+    if (H > 8192 || W > 8192)
+        return pf::fail(PF_EUNSUPPORTED, "pf_warp_splat: H and W must be <= 8192 (13-bit bin coordinates)");
     *bytes = pf::splat_layout(B, T, H, W, per_frame).total;
     return PF_OK;
 }
@@ -383,6 +404,7 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     a.bbox = (int4 *)((char *)ws + L.bbox_off);
     a.zmax_part = (unsigned *)((char *)ws + L.zmax_off);
     a.inv_mark = (uint8_t *)ws + L.mark_off;
+    a.proj = (uint2 *)((char *)ws + L.proj_off);
     a.out_seg = out_seg; a.out_depth = out_depth; a.out_r2d = (long long *)out_result2d;
     a.B = B; a.T_total = T_total; a.t_first = t_first; a.T = T; a.H = H; a.W = W; a.C = seg_channels;
     a.per_frame = per_frame ? 1 : 0;
