@@ -131,6 +131,15 @@ int pf_profile_collect(void);
 int pf_profile_get(int i, char *label, size_t label_cap, int *launches, double *total_ms, double *flops,
                    double *bytes);
 
+/* Tuning/diagnostic hook (tools/tune_convs.py, tests): force the convolution kernel and tile shape of every
+ * stride-1 conv the library launches from now on.  kind 0 = automatic (default); 1 = conv_dma (p0 = WM in
+ * {1,2,4}, p1 = NT); 2 = conv_wave (p0 = rows per tile in {1,2,4}, p1 = NT in {1,2}, p2 = K-split waves in
+ * {2,4,8,16}).  Shapes that are not built fall back to the automatic choice.  Process-wide, not thread-safe. */
+int pf_debug_force_conv(int kind, int p0, int p1, int p2);
+/* Instrumented builds only (make libpfhip_probe.so, env PF_PROBE=1): the 64 in-kernel timestamps (shader clock)
+ * written by workgroup 0 / wave 0 of the last conv_wave launch; PF_EINVAL when nothing was recorded. */
+int pf_debug_probe_read(long long *host64);
+
 #ifdef __cplusplus
 }
 #endif

@@ -292,9 +292,14 @@ static void pick_shape(const ConvArgs &a, int ks, int stride, int B, int &wm, in
     }
 }
 
-int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t s) {
+int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t s, int force_wm, int force_nt) {
     int wm = 4, wk = 1, nt = 1;
     pick_shape(a, ks, stride, B, wm, wk, nt);
+    if (force_wm > 0) {
+        wm = force_wm;
+        wk = 4 / wm;
+        nt = force_nt < a.ntiles ? force_nt : a.ntiles;
+    }
 #define PF_CASE(KS_, ST_, WM_, WK_, NT_) \
     if (ks == KS_ && stride == ST_ && wm == WM_ && nt == NT_) return launch_dma_cfg<KS_, ST_, WM_, WK_, NT_>(a, B, s);
     PF_CASE(3, 1, 4, 1, 1) PF_CASE(3, 1, 4, 1, 2) PF_CASE(3, 1, 4, 1, 3) PF_CASE(3, 1, 4, 1, 4)

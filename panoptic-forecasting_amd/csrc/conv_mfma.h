@@ -16,6 +16,8 @@ struct ConvArgs {
     int src_ctotal[kConvMaxSrc];     // channels of the tensor the range lives in
     int src_choff[kConvMaxSrc];      // first channel of the range inside that tensor
     int src_cstart[kConvMaxSrc + 1]; // prefix sums of range lengths (conv input channel numbering)
+    int src_chunk0[kConvMaxSrc + 1]; // conv_wave only: first K chunk of each range ([n_src] = nchunks); every range is
+                                     // padded to whole chunks so that a chunk never straddles two tensors
     int n_src;
     const float *wpk;  // packed weights, see pack_conv_weights()
     const float *bias; // [n_tiles_total*16], zero padded
@@ -26,6 +28,7 @@ struct ConvArgs {
     // fast path (conv_dma.hip) only:
     const float *zero_page;  // >= 16 B of zeros (source of out-of-image / padding DMA pieces)
     int ntiles;              // ceil(Cout/16)
+    long long *probe;        // PF_PROBE builds only: in-kernel timestamps of workgroup 0 / wave 0 (else nullptr)
 };
 
 // Tiling choice for one conv (depends on shape only; fixed at plan time for the weight packing).
@@ -50,6 +53,27 @@ int launch_conv(const ConvArgs &a, const ConvTiling &t, int B, hipStream_t strea
 constexpr int dma_kc_ct(int ks, int stride) { return ks == 1 ? 16 : (stride == 2 ? 4 : 8); }
 inline int dma_kc(int ks, int stride) { return dma_kc_ct(ks, stride); }
 void pack_conv_weights_tiled(const float *w_oihw, int cin, int cout, int ks, int kc, float *out);
-int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t stream);
+// force_wm/force_nt > 0 override the cost model (tuning runs)
+int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t stream, int force_wm = 0, int force_nt = 0);
+
+// Wave-autonomous path (conv_wave.hip; stride 1, Win % 4 == 0): a.wpk must point at pack_conv_weights_wave()
+// output and a.nchunks = ceil(Cin / wave_kc(ks)).  Tile = mh rows x 16 pixels, nt cout tiles, wk-way K split.
+constexpr int wave_kc_ct(int ks) { return ks == 1 ? 32 : 8; }
+inline int wave_kc(int ks) { return wave_kc_ct(ks); }
+// src_ch[n_src]: channels of each input range (sum = cin); K order = ranges in order, each padded to whole chunks
+int wave_chunks(const int *src_ch, int n_src, int ks);
+void pack_conv_weights_wave(const float *w_oihw, int cin, int cout, int ks, const int *src_ch, int n_src, float *out);
+size_t wave_packed_floats(const int *src_ch, int n_src, int cout, int ks);
+int launch_conv_wave(const ConvArgs &a, int ks, int mh, int nt, int wk, int B, hipStream_t stream);
+
+// Kernel/shape choice for one stride-1 conv (conv_select.cpp): kind 1 = conv_dma (p0 = WM, p1 = NT),
+// kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK).
+struct ConvChoice {
+    int kind, p0, p1, p2;
+};
+ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B);
+long long *probe_buffer();
+// tuning hook (pf_debug_force_conv): kind 0 = automatic
+extern ConvChoice g_conv_force;
 
 }  // namespace pf

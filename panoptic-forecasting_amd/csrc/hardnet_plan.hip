@@ -20,8 +20,10 @@ struct ConvPlan {
     size_t wpk_off = 0;   // floats into dev_weights
     size_t bias_off = 0;  // floats (padded to 16*n_tiles)
     size_t raw_off = 0;   // folded OIHW copy (stem only)
-    size_t tiled_off = 0; // per-cout-tile packing for the DMA fast path (stride 1 only)
+    size_t tiled_off = 0; // per-cout-tile packing for the DMA fast path
     int tiled_chunks = 0;
+    size_t wave_off = 0;  // fragment-order packing for the wave-autonomous path (stride 1 only)
+    int wave_chunks = 0;
 };
 
 struct pf_plan {
@@ -156,10 +158,28 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.relu = (int)o.relu;
             a.zero_page = p->dev_weights;   // first 64 floats of the weight arena are zeros
             a.ntiles = ((int)o.cout + 15) / 16;
+            static const bool probe_on = getenv("PF_PROBE") != nullptr;
+            a.probe = probe_on ? probe_buffer() : nullptr;
             if ((in.w & 3) == 0) {
-                a.wpk = p->dev_weights + p->conv[i].tiled_off;
-                a.nchunks = p->conv[i].tiled_chunks;
-                rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s);
+                ConvChoice ch = choose_conv((int)o.k, (int)o.stride, a.Cin, a.Cout, a.Hout, a.Wout, B);
+                if (g_conv_force.kind == 2 && o.stride == 1) ch = g_conv_force;
+                if (g_conv_force.kind == 1) ch = g_conv_force;
+                rc = PF_EUNSUPPORTED;
+                if (ch.kind == 2) {
+                    a.wpk = p->dev_weights + p->conv[i].wave_off;
+                    a.nchunks = p->conv[i].wave_chunks;
+                    const int kc = wave_kc((int)o.k);
+                    a.src_chunk0[0] = 0;
+                    for (int j = 0; j < kConvMaxSrc; ++j)
+                        a.src_chunk0[j + 1] = a.src_chunk0[j] + (j < a.n_src ? ((int)o.src[j].ch + kc - 1) / kc : 0);
+                    rc = launch_conv_wave(a, (int)o.k, ch.p0, ch.p1 < a.ntiles ? ch.p1 : a.ntiles, ch.p2, B, s);
+                    if (rc == PF_EUNSUPPORTED && g_conv_force.kind == 2) ch = ConvChoice{1, 0, 0, 0};   // forced shape not built
+                }
+                if (ch.kind != 2) {
+                    a.wpk = p->dev_weights + p->conv[i].tiled_off;
+                    a.nchunks = p->conv[i].tiled_chunks;
+                    rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s, ch.p0, ch.p1);
+                }
             } else {
                 a.nchunks = p->conv[i].tiling.nchunks;
                 rc = launch_conv(a, p->conv[i].tiling, B, s);
@@ -249,6 +269,15 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
             c.tiled_off = host.size();
             host.resize(host.size() + (size_t)((o.cout + 15) / 16) * c.tiled_chunks * (kc / 4) * o.k * o.k * 64);
             pack_conv_weights_tiled(wts + o.w_off, (int)o.cin, (int)o.cout, (int)o.k, kc, host.data() + c.tiled_off);
+        }
+        if (o.stride == 1) {
+            int src_ch[kMaxSrc];
+            for (uint32_t j = 0; j < o.n_src; ++j) src_ch[j] = (int)o.src[j].ch;
+            c.wave_chunks = wave_chunks(src_ch, (int)o.n_src, (int)o.k);
+            c.wave_off = host.size();
+            host.resize(host.size() + wave_packed_floats(src_ch, (int)o.n_src, (int)o.cout, (int)o.k));
+            pack_conv_weights_wave(wts + o.w_off, (int)o.cin, (int)o.cout, (int)o.k, src_ch, (int)o.n_src,
+                                   host.data() + c.wave_off);
         }
         if (o.kind == OP_STEM) {
             c.raw_off = host.size();

@@ -50,9 +50,10 @@ def gather_accumulators(acc):
     if not is_dist():
         return acc.unsqueeze(0)
     world = dist.get_world_size()
-    out = torch.empty((world,) + tuple(acc.shape), dtype=acc.dtype, device=acc.device)
+    # concatenated along dim 0 (the layout every backend accepts), viewed back as [world, ...]
+    out = torch.empty((world * acc.shape[0],) + tuple(acc.shape[1:]), dtype=acc.dtype, device=acc.device)
     dist.all_gather_into_tensor(out, acc.contiguous())
-    return out
+    return out.view((world,) + tuple(acc.shape))
 
 
 def max_over_ranks(x, device):

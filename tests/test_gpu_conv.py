@@ -91,3 +91,42 @@ def test_pool_and_upsample(h, w):
     assert (net.tensor('pool').cpu() - pooled).abs().max() <= 1e-6
     assert (net.tensor('up').cpu() - up).abs().max() <= 1e-5
     net.close()
+
+
+@pytest.fixture
+def force_conv():
+    from panoptic_forecasting_amd import lib as pflib
+    L = pflib.load()
+    yield lambda kind, p0, p1, p2: pflib.check(L.pf_debug_force_conv(kind, p0, p1, p2), 'pf_debug_force_conv')
+    L.pf_debug_force_conv(0, 0, 0, 0)
+
+
+FORCED = [(1, wm, nt, 0) for wm in (4, 2, 1) for nt in (1, 2, 3, 4) if not (wm == 1 and nt > 2)] + \
+         [(2, mh, nt, wk) for mh in (1, 2, 4) for nt in (1, 2) for wk in (2, 4, 8, 16)]
+
+
+@pytest.mark.parametrize('force', FORCED, ids=lambda f: 'k%d_%d_%d_%d' % f)
+def test_every_kernel_shape(force, force_conv):
+    """Each template instantiation of conv_dma / conv_wave, forced through pf_debug_force_conv, on a
+    HarDBlock-style three-source 3x3 conv, a wide 1x1 conv and a tiny image (edge tiles, K tail)."""
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    g = torch.Generator().manual_seed(11)
+    b, h, w = 2, 20, 40
+    x = torch.randn(b, 45, h, w, generator=g)
+    spec = MiniSpec(45)
+    spec.conv('A', [arch.Src(0, 30, 10), arch.Src(0, 0, 18), arch.Src(0, 2, 43)], 37, 3)     # cin 71: K tail, 3 cout tiles
+    spec.conv('B', [arch.Src(0, 0, 45)], 70, 1, relu=False)
+    spec.conv('C', [arch.Src(0, 5, 9)], 10, 3)
+    P = {}
+    for name, cin, cout, k in [('A', 71, 37, 3), ('B', 45, 70, 1), ('C', 9, 10, 3)]:
+        P[name] = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.randn(cout, generator=g))
+    force_conv(*force)
+    net = MiniNet(spec, P).run(x.cuda())
+    ra = F.relu(F.conv2d(torch.cat([x[:, 30:40], x[:, 0:18], x[:, 2:45]], 1), *P['A'], padding=1))
+    rb = F.conv2d(x, *P['B'])
+    rc = F.relu(F.conv2d(x[:, 5:14], *P['C'], padding=1))
+    for name, ref in (('A', ra), ('B', rb), ('C', rc)):
+        err = (net.tensor(name).cpu() - ref).abs().max().item()
+        assert err <= _tol(ref), (name, err, _tol(ref))
+    net.close()

@@ -1,0 +1,92 @@
+"""Host-side pieces either side of the device path, against the reference's own outputs (fixtures)."""
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+from oracle import hop
+from panoptic_forecasting_amd import ego, hardnet_arch as arch, packing, pq, synth
+
+
+def test_ego_chain_matches_reference_data_utils():
+    z = np.load(os.path.join(GOLDEN, 'g1_ego.npz'))
+    assert np.array_equal(ego.camera_extrinsics(synth.CS_EXTRINSIC), z['E'])
+    assert np.array_equal(ego.intrinsics_matrix(synth.CS_FX, synth.CS_FY, synth.CS_U0, synth.CS_V0), z['K'])
+    for (speed, yaw, dt), want in zip(z['step_cases'], z['steps']):
+        assert np.array_equal(ego.now_T_prev(speed, yaw, dt), want)
+    # cumulative product order of pc_transform_dataset.py:219-231 (target 19, inputs [10,13,16])
+    steps = [ego.now_T_prev(10.0 + 0.1 * k, 0.02 - 0.001 * k, 1 / 17.0 + 1e-4 * k) for k in range(1, 30)]
+    cum = ego.cumulative_target_T(steps[:19])
+    assert np.array_equal(cum[np.array([10, 13, 16])], z['chain'])
+
+
+def test_hop_restatement_matches_fixture():
+    z = np.load(os.path.join(GOLDEN, 'g2_glue.npz'))
+    q = hop.export_depth_u16(torch.from_numpy(z['depth_in']))
+    assert np.array_equal(q, z['depth_u16'])
+    d, m = hop.load_depth(q)
+    assert np.array_equal(d.numpy().view(np.uint32), z['depth_dec'].view(np.uint32))
+    assert np.array_equal(m.numpy(), z['mask_dec'])
+    oh = hop.onehot(torch.from_numpy(z['seg']))
+    assert np.array_equal(oh.numpy().astype(np.uint8), z['onehot'])
+
+
+def test_label_table_is_consistent():
+    lut = hop.id2trainid_lut()
+    assert np.array_equal(lut, synth.ID2TRAINID)
+    assert np.array_equal(lut[synth.TRAINID2ID], np.arange(19))
+    assert (lut[:34] == 255).sum() == 34 - 19
+
+
+def test_bn_fold_equals_conv_then_bn():
+    g = torch.Generator().manual_seed(5)
+    sd = {'p.conv.weight': torch.randn(6, 5, 3, 3, generator=g), 'p.norm.weight': torch.rand(6, generator=g) + 0.5,
+          'p.norm.bias': torch.randn(6, generator=g), 'p.norm.running_mean': torch.randn(6, generator=g),
+          'p.norm.running_var': torch.rand(6, generator=g) + 0.5}
+    w, b = packing.fold_conv_bn(sd, 'p')
+    x = torch.randn(2, 5, 9, 11, generator=g)
+    ref = torch.nn.functional.batch_norm(torch.nn.functional.conv2d(x, sd['p.conv.weight'], padding=1),
+                                         sd['p.norm.running_mean'], sd['p.norm.running_var'], sd['p.norm.weight'],
+                                         sd['p.norm.bias'], training=False, eps=1e-5)
+    got = torch.nn.functional.conv2d(x, w, b, padding=1)
+    assert (got - ref).abs().max() < 1e-5
+
+
+def test_blob_roundtrip_header_and_tables():
+    import struct
+    sd = synth.make_state_dict(seed=3)
+    blob = packing.pack_blob(sd, 36, 11)
+    magic, ver, n_t, n_o, in_ch, n_cls, _, t_off, o_off, w_off, total = struct.unpack_from('<8sIIIIII4Q', blob, 0)
+    spec = arch.Spec(36, 11)
+    assert magic == packing.MAGIC and ver == packing.VERSION and total == len(blob)
+    assert (n_t, n_o, in_ch, n_cls) == (len(spec.tensors), len(spec.ops), 36, 11)
+    n_w = sum(o.cout * o.cin * o.k * o.k + o.cout for o in spec.conv_ops())
+    assert len(blob) - w_off == 4 * n_w
+    assert len(spec.conv_ops()) == 70 and n_w - sum(o.cout for o in spec.conv_ops()) + 0 > 4_000_000
+
+
+def test_pq_identity_and_known_case():
+    gt = torch.zeros(1, 4, 8, dtype=torch.long)
+    gt[:, :, 4:] = 1
+    gt[:, 0, 0] = 255                      # void pixel is ignored
+    acc = pq.pq_accumulate(gt.clone().clamp(max=1), gt, 3)
+    r = pq.pq_from_acc(acc)
+    assert abs(r['pq'] - 100.0) < 1e-9 and r['n_classes'] == 2
+    pred = gt.clone().clamp(max=1)
+    pred[:, :, 4:6] = 0                    # class 1 loses half its area -> IoU 0.5 (not > 0.5): FP+FN; class 0 IoU=15/23
+    r2 = pq.pq_from_acc(pq.pq_accumulate(pred, gt, 3))
+    want0 = (15.0 / 23.0) / 1.0            # TP for class 0 (IoU>0.5)
+    want1 = 0.0
+    assert abs(r2['pq'] - 100.0 * (want0 + want1) / 2) < 1e-9
+
+
+def test_pq_accumulators_add_across_shards():
+    g = torch.Generator().manual_seed(0)
+    pred = torch.randint(0, 11, (6, 32, 64), generator=g)
+    gt = torch.randint(0, 12, (6, 32, 64), generator=g)
+    gt[gt == 11] = 255
+    whole = pq.pq_accumulate(pred, gt, 11)
+    parts = pq.pq_accumulate(pred[0::2], gt[0::2], 11) + pq.pq_accumulate(pred[1::2], gt[1::2], 11)
+    assert torch.equal(whole[:, 1:], parts[:, 1:])                 # integer counts add exactly
+    assert (whole[:, 0] - parts[:, 0]).abs().max() < 1e-12

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs ON the GPU box (via gpurun): kernel trace + separate PMC passes of the bench command.
+#   tools/profile_gpu.sh <tag> [bench args...]
+# Outputs under gpurun_out/<tag>/ ; summarise locally with tools/profile_summarise.py <tag>.
+set -u
+TAG=${1:-prof}; shift || true
+REPO=$PWD
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph $*"
+cd /tmp
+# 1. kernel trace + stats (timing)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BENCH > "$OUT/bench_trace.log" 2>"$OUT/trace.err"
+# 2. PMC passes, one counter set per run (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o p -- $BENCH > "$OUT/bench_pmc_$C.log" 2>"$OUT/pmc_$C.err"
+  # calibration on a known byte count: a 256 MiB float4 device copy (reads 256 MiB, writes 256 MiB)
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/cal_$C" -o c -- python $REPO/tools/pmc_calib.py > "$OUT/cal_$C.log" 2>&1
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -o p -- $BENCH > "$OUT/bench_pmc_mfma.log" 2>"$OUT/pmc_mfma.err"
+# keep only the CSVs (sizes are bounded by the 64 MiB pull limit)
+find "$OUT" -name '*.db' -delete
+ls -R "$OUT" | head -50

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Time every conv kernel shape on every layer of one bg_forecast step (in situ, per-op hipEvent timing) and print
+the best shape per layer.   python tools/tune_convs.py [--batch B] [--steps 3] [--json out.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ['PF_PROFILE_OPS'] = '1'
+import bench  # noqa: E402
+from panoptic_forecasting_amd import lib as pflib  # noqa: E402
+from panoptic_forecasting_amd.registry import build_model  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=1)
+ap.add_argument('--steps', type=int, default=3)
+ap.add_argument('--json', default=None)
+ap.add_argument('--height', type=int, default=bench.H)
+ap.add_argument('--width', type=int, default=bench.W)
+args = ap.parse_args()
+bench.H, bench.W = args.height, args.width
+L = pflib.load()
+model = build_model(bench.model_params())
+model.load_state_dict(bench.calibrated_state_dict())
+batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
+
+CONFIGS = [(0, 0, 0, 0)] + [(1, wm, nt, 0) for wm in (4, 2, 1) for nt in (1, 2, 3, 4) if not (wm == 1 and nt > 2)] + \
+          [(2, mh, nt, wk) for mh in (1, 2, 4) for nt in (1, 2) for wk in (2, 4, 8, 16)]
+
+
+def run(cfg):
+    L.pf_debug_force_conv(*cfg)
+    for _ in range(2):
+        model.predict(batch, None)
+    torch.cuda.synchronize()
+    pflib.profile(True)
+    for _ in range(args.steps):
+        model.predict(batch, None)
+    torch.cuda.synchronize()
+    recs = pflib.profile_results()
+    pflib.profile(False)
+    out = {}
+    for r in recs:
+        k, _, tag = r['label'].partition(' @')
+        if tag and 'conv' in k:
+            out[tag] = (r['ms'] / args.steps * 1e3, k.replace('void pf::', '').replace('(pf::ConvArgs)', ''), r['flops'] / args.steps)
+    return out
+
+
+table = {}
+for cfg in CONFIGS:
+    res = run(cfg)
+    for tag, (us, kern, fl) in res.items():
+        table.setdefault(tag, {})[cfg] = (us, kern, fl)
+L.pf_debug_force_conv(0, 0, 0, 0)
+
+tot_auto = tot_best = 0.0
+rows = []
+for tag in sorted(table):
+    d = table[tag]
+    auto = d[(0, 0, 0, 0)]
+    # a forced shape that is not built falls back to auto: only count entries whose kernel name matches the request
+    cands = {c: v for c, v in d.items() if c[0] == 0 or (c[0] == 1 and 'conv_dma' in v[1]) or (c[0] == 2 and 'conv_wave' in v[1])}
+    best = min(cands, key=lambda c: cands[c][0])
+    tot_auto += auto[0]
+    tot_best += cands[best][0]
+    bw = min((c for c in cands if c[0] == 2), key=lambda c: cands[c][0], default=None)
+    bd = min((c for c in cands if c[0] == 1), key=lambda c: cands[c][0], default=None)
+    rows.append({'tag': tag, 'auto_us': auto[0], 'auto_kernel': auto[1], 'best': list(best), 'best_us': cands[best][0],
+                 'best_wave': list(bw) if bw else None, 'best_wave_us': cands[bw][0] if bw else None,
+                 'best_dma': list(bd) if bd else None, 'best_dma_us': cands[bd][0] if bd else None,
+                 'gflop': auto[2] / 1e9,
+                 'all': {'%d,%d,%d,%d' % c: round(v[0], 2) for c, v in sorted(cands.items())}})
+    print('%-44s auto %7.1f us (%s) | best %-14s %7.1f us %6.1f TF/s | wave %-14s %7.1f | dma %-12s %7.1f' % (
+        tag[:44], auto[0], auto[1][-22:], best, cands[best][0], auto[2] / cands[best][0] / 1e6,
+        bw, cands[bw][0] if bw else -1, bd, cands[bd][0] if bd else -1))
+print('conv total: auto %.1f us -> best-per-layer %.1f us  (B=%d)' % (tot_auto, tot_best, args.batch))
+if args.json:
+    with open(args.json, 'w') as f:
+        json.dump({'batch': args.batch, 'h': args.height, 'w': args.width, 'rows': rows}, f, indent=1)
