@@ -5,10 +5,54 @@ namespace pf {
 
 ConvChoice g_conv_force = {0, 0, 0, 0};
 
+namespace {
+struct Tuned {
+    int ks, cin, cout, hout, wout, B;
+    ConvChoice c;
+};
+// Measured winners for the shapes of the 1024x2048 bg network (tools/tune_convs.py --emit on an MI355X); rows are
+// only kept where they beat the cost model by > 3 %.
+const Tuned kTuned[] = {
+#include "conv_tuned.inc"
+};
+
+// LDS bytes of a conv_wave workgroup (mirrors WaveCfg in conv_wave.hip)
+size_t wave_lds_bytes(int ks, int mh, int nt, int wk) {
+    const int kc = wave_kc(ks), ih = mh + ks - 1, iw = 16 + (ks == 3 ? 8 : 0);
+    const int raw = ih * iw, plane = (raw + 15) / 32 * 32 + 16, nit = (kc * (plane / 4) + 63) / 64;
+    const size_t ring = (size_t)wk * 2 * nit * 256, red = (size_t)wk * mh * nt * 256;
+    return 4 * (ring > red ? ring : red);
+}
+}  // namespace
+
 ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B) {
-    (void)ks; (void)cin; (void)cout; (void)hout; (void)wout; (void)B;
-    if (stride != 1) return ConvChoice{1, 0, 0, 0};
-    return ConvChoice{1, 0, 0, 0};   // conv_dma with its own cost model
+    if (stride != 1) return ConvChoice{1, 0, 0, 0};           // conv_dma, shape by its cost model
+    for (const Tuned &t : kTuned)
+        if (t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == B) return t.c;
+    // Untuned shape.  Images of >= 256x512 pixels keep the barrier-synchronised kernel (its big shared tiles move the
+    // fewest bytes); below that the wave-autonomous kernel wins everywhere it was measured.  Pick the tile with the
+    // most operand reuse (rows x cout tiles) that still puts >= 2 waves on every SIMD of the chip.
+    const long px = (long)B * hout * wout;
+    if (px >= 131072) return ConvChoice{1, 0, 0, 0};
+    const int ntiles = (cout + 15) / 16;
+    ConvChoice best{2, 1, 1, 8};
+    long best_reuse = -1, best_waves = -1;
+    const int mhs[3] = {4, 2, 1}, wks[3] = {2, 4, 8};
+    for (int mh : mhs)
+        for (int nt = 2; nt >= 1; --nt) {
+            if (nt > ntiles) continue;
+            for (int wk : wks) {
+                if (wave_lds_bytes(ks, mh, nt, wk) > 64 * 1024) continue;
+                const long waves = (long)B * ((hout + mh - 1) / mh) * ((wout + 15) / 16) * ((ntiles + nt - 1) / nt) * wk;
+                const long reuse = waves >= 2048 ? mh * nt : 0;
+                if (reuse > best_reuse || (reuse == best_reuse && reuse == 0 && waves > best_waves)) {
+                    best = ConvChoice{2, mh, nt, wk};
+                    best_reuse = reuse;
+                    best_waves = waves;
+                }
+            }
+        }
+    return best;
 }
 
 }  // namespace pf

@@ -155,23 +155,29 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
 
     const int abase = (lane >> 4) * C::PLANE + (lane & 15) + (C::APRON - KS / 2);
 
+    // A operands are fetched one (k-group, tap) step ahead of the MFMAs that use them, so the LDS latency of step
+    // s+1 is covered by the MP*NT MFMAs of step s instead of stalling the matrix pipe at every step.
     auto compute = [&](const float *buf, const WFrag(&w)[NT]) {
+        auto aload = [&](int idx, float(&af)[MH]) {
+            const int kg = idx / C::KS2, tap = idx - kg * C::KS2;
+            const int ky = tap / KS, kx = tap - ky * KS;
 #pragma unroll
-        for (int kg = 0; kg < C::KG; ++kg) {
+            for (int m = 0; m < MH; ++m) af[m] = buf[abase + kg * 4 * C::PLANE + (m + ky) * C::IW + kx];
+        };
+        float a0[MH], a1[MH];
+        aload(0, a0);
 #pragma unroll
-            for (int tap = 0; tap < C::KS2; ++tap) {
-                const int ky = tap / KS, kx = tap - ky * KS;
-                const int idx = kg * C::KS2 + tap;
-                float af[MH];
+        for (int idx = 0; idx < C::NV; ++idx) {
+            float(&cur)[MH] = (idx & 1) ? a1 : a0;
+            float(&nxt)[MH] = (idx & 1) ? a0 : a1;
+            if (idx + 1 < C::NV) aload(idx + 1, nxt);
 #pragma unroll
-                for (int m = 0; m < MH; ++m) af[m] = buf[abase + kg * 4 * C::PLANE + (m + ky) * C::IW + kx];
+            for (int m = 0; m < MH; ++m)
 #pragma unroll
-                for (int m = 0; m < MH; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        acc[m][n][idx % C::NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                            af[m], idx < 4 * C::NQ ? w[n].q[idx / 4][idx % 4] : w[n].r[idx % 4], acc[m][n][idx % C::NA], 0, 0, 0);
-            }
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n][idx % C::NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        cur[m], idx < 4 * C::NQ ? w[n].q[(idx / 4) % (C::NQ ? C::NQ : 1)][idx % 4] : w[n].r[idx % 2],
+                        acc[m][n][idx % C::NA], 0, 0, 0);
         }
     };
 

@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=1)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--json', default=None)
+ap.add_argument('--emit', default=None, help='append the winners as C table rows to this .inc file')
 ap.add_argument('--height', type=int, default=bench.H)
 ap.add_argument('--width', type=int, default=bench.W)
 args = ap.parse_args()
@@ -80,6 +81,25 @@ for tag in sorted(table):
         tag[:44], auto[0], auto[1][-22:], best, cands[best][0], auto[2] / cands[best][0] / 1e6,
         bw, cands[bw][0] if bw else -1, bd, cands[bd][0] if bd else -1))
 print('conv total: auto %.1f us -> best-per-layer %.1f us  (B=%d)' % (tot_auto, tot_best, args.batch))
+if args.emit:
+    import re
+    with open(args.emit, 'a') as f:
+        f.write('    // B=%d, %dx%d input: tools/tune_convs.py on MI355X (best-per-layer %.0f us vs cost-model %.0f us)\n'
+                % (args.batch, args.height, args.width, tot_best, tot_auto))
+        seen = set()
+        for r in rows:
+            m = re.match(r'\d+ (\S+) (\d+)->(\d+) (\d+)x(\d+)', r['tag'])
+            cin, cout, h, w = int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5))
+            ks = 1 if ('conv1x1' in r['tag'] or 'finalConv' in r['tag'] or re.match(r'\d+ base\.(5|8|11|14|17) ', r['tag'])) else 3
+            key = (ks, cin, cout, h, w, args.batch)
+            if key in seen:
+                continue
+            seen.add(key)
+            b = r['best']
+            if b[0] == 0 or r['best_us'] > 0.97 * r['auto_us']:     # within noise of the cost model: keep the model
+                continue
+            f.write('    {%d, %d, %d, %d, %d, %d, {%d, %d, %d, %d}},   // %s: %.1f -> %.1f us\n'
+                    % (ks, cin, cout, h, w, args.batch, b[0], b[1], b[2], b[3], m.group(1), r['auto_us'], r['best_us']))
 if args.json:
     with open(args.json, 'w') as f:
         json.dump({'batch': args.batch, 'h': args.height, 'w': args.width, 'rows': rows}, f, indent=1)
