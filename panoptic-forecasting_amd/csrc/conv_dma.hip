@@ -12,7 +12,7 @@
 //     machine ((WM,WK) = (4,1) | (2,2) | (1,4), picked per layer at launch by a small cost model).
 //   * weights are packed per 16-cout tile so the number of cout tiles per workgroup (NT) is a launch-time
 //     choice too (fat workgroups at high resolution, many at low resolution).
-#include "conv_mfma.h"
+#include "conv_epilogue.h"
 #include "pf_prof.h"
 
 #ifndef PF_ABLATE
@@ -45,18 +45,18 @@ struct DmaCfg {
     static_assert(PLANE % 4 == 0 && PLANE >= RAW && PLANE % 32 == 16, "plane stride");
 };
 
-__device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
+typedef __attribute__((address_space(3))) void *dma_lds_ptr_t;
+[[maybe_unused]] constexpr unsigned kDmaOob = 0x80000000u;   // voffset >= num_records: the DMA writes zeros (conv zero padding)
 
 template <int KS, int STRIDE, int WM, int WK, int NT>
 __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // device-only builtin types in the body; the host pass only needs the stub
     using C = DmaCfg<KS, STRIDE, WM, WK, NT>;
     constexpr int NTHR = 64 * WM * WK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wk = wave / WM;
     const int tileY = blockIdx.x / a.tilesX, tileX = blockIdx.x - tileY * a.tilesX;
     const int tile0 = blockIdx.y * NT, b = blockIdx.z;   // first cout tile of this workgroup
@@ -76,75 +76,82 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
         abase[m] = (lane >> 4) * C::PLANE + ty * STRIDE * C::IW + (tx0 + (lane & 15)) * STRIDE + (C::APRON - KS / 2);
     }
 
-    const size_t in_plane = (size_t)a.Hin * a.Win;
-    const float *zero = a.zero_page;
-    const int nrounds = (a.nchunks + WK - 1) / WK;
+    // ---- per-thread constants of the staging pattern (16-B piece p = it*NTHR + tid of a slot): byte offset of the
+    //      piece from the chunk's first channel plane (inputs) / from the chunk's weight block (weights); pieces that
+    //      fall outside the image, the channel range or the cout range get an out-of-range offset and read as zeros
+    constexpr int NPI = C::KC * C::PP, NITI = (NPI + NTHR - 1) / NTHR;
+    constexpr int NPW = NT * C::WFRAG / 4, NITW = (NPW + NTHR - 1) / NTHR;
+    const unsigned in_plane = (unsigned)a.Hin * a.Win;
+    unsigned voff[NITI], woff[NITW];
+    int pcl[NITI];
+#pragma unroll
+    for (int it = 0; it < NITI; ++it) {
+        const int p = it * NTHR + tid;
+        const int cl = p / C::PP, q = p - cl * C::PP;
+        const int row = q / C::RW, j = q - row * C::RW;
+        const int gy = iy0 + row, gx = ix0 + j * 4;
+        const bool ok = p < NPI && q < C::RP && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        voff[it] = ok ? (cl * in_plane + (unsigned)(gy * a.Win + gx)) * 4u : kDmaOob;
+        pcl[it] = cl;
+    }
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+        const int p = it * NTHR + tid;
+        const int n = p / (C::WFRAG / 4), q = p - n * (C::WFRAG / 4);
+        woff[it] = (p < NPW && tile0 + n < a.ntiles) ? ((unsigned)(tile0 + n) * a.nchunks * C::WFRAG + q * 4) * 4u : kDmaOob;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wpk, 0, 0x7FFFFFFF, 0x00020000);
 
-    // issue the DMA of one round (WK chunks: inputs + weights) into buffer `buf`; piece p lands at p*16 B
+    const int cb = a.chunk_begin, nrounds = (a.chunk_end - cb + WK - 1) / WK;
+
+    // issue the DMA of one round (WK chunks: inputs + weights) into buffer `buf`.  Which tensor a chunk reads, its
+    // first channel and how many of its KC channels exist are workgroup-uniform: select chains on the scalar ALU.
     auto stage = [&](int round, float *buf) {
 #pragma unroll
         for (int s = 0; s < WK; ++s) {
-            const int chunk = round * WK + s;
-            if (chunk >= a.nchunks) break;
+            const int chunk = cb + round * WK + s;
+            if (chunk >= a.chunk_end) break;
             float *slot = buf + s * C::SLOT;
-            constexpr int NPI = C::KC * C::PP;
+            const float *sp = a.src[0];
+            int ctot = a.src_ctotal[0], coff = a.src_choff[0], ch0 = 0, cend = a.src_cstart[1], c0 = 0;
 #pragma unroll
-            for (int it = 0; it < (NPI + NTHR - 1) / NTHR; ++it) {
-                const int p = it * NTHR + tid;
-                if (p < NPI) {
-                    const int cl = p / C::PP, q = p - cl * C::PP;
-                    const int row = q / C::RW, j = q - row * C::RW;
-                    const int c = chunk * C::KC + cl, gy = iy0 + row, gx = ix0 + j * 4;
-                    const float *g = zero;
-                    if (q < C::RP && c < a.Cin && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) {
-                        // source-range lookup as a select chain over kernel-argument scalars: a dynamically
-                        // indexed a.src[sidx] becomes a vector load whose vmcnt wait serialises the DMA queue
-                        const float *sp = a.src[0];
-                        int ctot = a.src_ctotal[0], coff = a.src_choff[0];
-#pragma unroll
-                        for (int k = 1; k < kConvMaxSrc; ++k) {
-                            const bool take = k < a.n_src && c >= a.src_cstart[k];
-                            sp = take ? a.src[k] : sp;
-                            ctot = take ? a.src_ctotal[k] : ctot;
-                            coff = take ? a.src_choff[k] - a.src_cstart[k] : coff;
-                        }
-                        const size_t ch = (size_t)b * ctot + coff + c;
-                        g = sp + ch * in_plane + (size_t)gy * a.Win + gx;
-                    }
-                    dma16(g, slot + (it * NTHR + wave * 64) * 4);
-                }
+            for (int k = 1; k < kConvMaxSrc; ++k) {
+                const bool take = k < a.n_src && chunk >= a.src_chunk0[k];
+                sp = take ? a.src[k] : sp;
+                ctot = take ? a.src_ctotal[k] : ctot;
+                coff = take ? a.src_choff[k] : coff;
+                ch0 = take ? a.src_chunk0[k] : ch0;
+                c0 = take ? a.src_cstart[k] : c0;
+                cend = take ? a.src_cstart[k + 1] : cend;
             }
-            constexpr int NPW = NT * C::WFRAG / 4;
+            const int lc = chunk - ch0;
+            const int nvalid = (cend - c0) - lc * C::KC;
+            const unsigned soff = (unsigned)(coff + lc * C::KC) * in_plane * 4u;
+            const __amdgpu_buffer_rsrc_t r =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(sp + (size_t)b * ctot * in_plane), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+            for (int it = 0; it < NITI; ++it)
+                if (it * NTHR + tid < NPI)   // lanes past the slot's input region are masked off (they would overwrite the weights)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (dma_lds_ptr_t)(slot + (it * NTHR + wave * 64) * 4), 16,
+                                                             pcl[it] < nvalid ? voff[it] : kDmaOob, soff, 0, 0);
             float *wslot = slot + C::KC * C::PLANE;
+            const unsigned wsoff = (unsigned)chunk * C::WFRAG * 4u;
 #pragma unroll
-            for (int it = 0; it < (NPW + NTHR - 1) / NTHR; ++it) {
-                const int p = it * NTHR + tid;
-                if (p < NPW) {
-                    const int n = p / (C::WFRAG / 4), q = p - n * (C::WFRAG / 4);
-                    const float *g = zero;
-                    if (tile0 + n < a.ntiles)
-                        g = a.wpk + ((size_t)(tile0 + n) * a.nchunks + chunk) * C::WFRAG + q * 4;
-                    dma16(g, wslot + (it * NTHR + wave * 64) * 4);
-                }
-            }
+            for (int it = 0; it < NITW; ++it)
+                if (it * NTHR + tid < NPW)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (dma_lds_ptr_t)(wslot + (it * NTHR + wave * 64) * 4), 16,
+                                                             woff[it], wsoff, 0, 0);
         }
     };
 
-    stage(0, smem);
+    if (nrounds > 0) stage(0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int round = 0; round < nrounds; ++round) {
         float *cur = smem + (round & 1) * C::BUF;
-#if PF_ABLATE == 1   /* no staging after the prologue: MFMA + LDS-read time only */
-#else
         if (round + 1 < nrounds) stage(round + 1, smem + ((round + 1) & 1) * C::BUF);   // in flight during the MFMAs
-#endif
-#if PF_ABLATE == 2   /* staging only */
-        if (round * WK + wk < a.nchunks && a.relu == 12345) {
-#else
-        if (round * WK + wk < a.nchunks) {
-#endif
+        if (cb + round * WK + wk < a.chunk_end) {
             const float *in_s = cur + wk * C::SLOT;
             const float *w_s = in_s + C::KC * C::PLANE;
 #pragma unroll
@@ -190,37 +197,26 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
                     acc[m][n] += red[((((k - 1) * WM + wm) * C::MP + m) * NT + n) * 64 + lane];
     }
 
-    // ---- epilogue (same fragment map as conv_mfma.hip): bias + ReLU, NCHW float4 stores
-    const size_t out_plane = (size_t)a.Hout * a.Wout;
-    const bool vec = (a.Wout & 3) == 0;
+    // ---- epilogue (conv_epilogue.h): bias, residual, ReLU, optional 2x2 pool (rows ty, ty+1 = M-tiles m, m+TWT)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int co = (tile0 + n) * 16 + (lane & 15);
         if (co >= a.Cout) continue;
-        const float bias = a.bias[co];
-        float *dplane = a.dst + ((size_t)b * a.dst_ctotal + a.dst_choff + co) * out_plane;
 #pragma unroll
         for (int m = 0; m < C::MP; ++m) {
             const int mt = wm * C::MP + m;
             const int oy = tileY * C::TH + mt / C::TWT;
             const int ox = tileX * C::TW + (mt % C::TWT) * 16 + (lane >> 4) * 4;
             if (oy >= a.Hout || ox >= a.Wout) continue;
-            f32x4 v = acc[m][n];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] += bias;
-                if (a.relu) v[r] = fmaxf(v[r], 0.f);
-            }
-            float *p = dplane + (size_t)oy * a.Wout + ox;
-            if (vec && ox + 3 < a.Wout) {
-                *reinterpret_cast<f32x4 *>(p) = v;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (ox + r < a.Wout) p[r] = v[r];
+            if (!a.pool) {
+                epi_store(a, b, co, oy, ox, epi_finish(a, b, co, oy, ox, acc[m][n]));
+            } else if (((m / C::TWT) & 1) == 0 && m + C::TWT < C::MP && oy + 1 < a.Hout) {
+                epi_store_pooled(a, b, co, oy, ox, epi_finish(a, b, co, oy, ox, acc[m][n]),
+                                 epi_finish(a, b, co, oy + 1, ox, acc[(m + C::TWT) % C::MP][n]));
             }
         }
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -256,7 +252,7 @@ static double shape_cost(const ConvArgs &a, int ks, int stride, int B, int wm, i
     const double px_tiles = (double)B * ((a.Hout + th - 1) / th) * ((a.Wout + tw - 1) / tw);
     const int cblocks = (a.ntiles + nt - 1) / nt;
     const double wgs = px_tiles * cblocks;
-    const int nchunks = (a.Cin + kc - 1) / kc, rounds = (nchunks + wk - 1) / wk;
+    const int nchunks = a.chunk_end - a.chunk_begin, rounds = (nchunks + wk - 1) / wk;
     const double mfma_round = (kc / 4) * ks2 * 4.0 * nt * 32.0;            // cycles of MFMA issue per wave per round
     const int iw = tw * stride + (ks == 3 ? 8 : 0), ih = (th - 1) * stride + ks;
     const double lds_bytes = 2.0 * wk * (kc * (ih * iw + 32) + nt * (kc / 4) * ks2 * 64) * 4.0;
@@ -315,18 +311,31 @@ int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t s,
     return fail(PF_EUNSUPPORTED, "conv_dma: no kernel for ks=%d stride=%d wm=%d nt=%d", ks, stride, wm, nt);
 }
 
-// per-tile packing: [cout tile][chunk][kgroup][tap][64 lanes]
-void pack_conv_weights_tiled(const float *w, int cin, int cout, int ks, int kc, float *out) {
-    const int ks2 = ks * ks, ntiles = (cout + 15) / 16, nchunks = (cin + kc - 1) / kc;
+int dma_chunks(const int *src_ch, int n_src, int ks, int stride) {
+    const int kc = dma_kc(ks, stride);
+    int n = 0;
+    for (int j = 0; j < n_src; ++j) n += (src_ch[j] + kc - 1) / kc;
+    return n;
+}
+
+// per-tile packing: [cout tile][chunk][kgroup][tap][64 lanes]; K order = the input ranges in order, each padded to
+// whole chunks (zero weights), so a chunk never straddles two source tensors
+void pack_conv_weights_tiled(const float *w, int cin, int cout, int ks, int kc, const int *src_ch, int n_src, float *out) {
+    const int ks2 = ks * ks, ntiles = (cout + 15) / 16;
     size_t o = 0;
-    for (int t = 0; t < ntiles; ++t)
-        for (int ch = 0; ch < nchunks; ++ch)
-            for (int kg = 0; kg < kc / 4; ++kg)
-                for (int tap = 0; tap < ks2; ++tap)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int co = t * 16 + (lane & 15), ci = ch * kc + kg * 4 + (lane >> 4);
-                        out[o++] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * ks2 + tap] : 0.f;
-                    }
+    for (int t = 0; t < ntiles; ++t) {
+        int c0 = 0;
+        for (int j = 0; j < n_src; ++j) {
+            for (int lc = 0; lc * kc < src_ch[j]; ++lc)
+                for (int kg = 0; kg < kc / 4; ++kg)
+                    for (int tap = 0; tap < ks2; ++tap)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int co = t * 16 + (lane & 15), cl = lc * kc + kg * 4 + (lane >> 4);
+                            out[o++] = (co < cout && cl < src_ch[j]) ? w[((size_t)co * cin + c0 + cl) * ks2 + tap] : 0.f;
+                        }
+            c0 += src_ch[j];
+        }
+    }
 }
 
 }  // namespace pf

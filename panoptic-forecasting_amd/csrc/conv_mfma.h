@@ -16,8 +16,8 @@ struct ConvArgs {
     int src_ctotal[kConvMaxSrc];     // channels of the tensor the range lives in
     int src_choff[kConvMaxSrc];      // first channel of the range inside that tensor
     int src_cstart[kConvMaxSrc + 1]; // prefix sums of range lengths (conv input channel numbering)
-    int src_chunk0[kConvMaxSrc + 1]; // conv_wave only: first K chunk of each range ([n_src] = nchunks); every range is
-                                     // padded to whole chunks so that a chunk never straddles two tensors
+    int src_chunk0[kConvMaxSrc + 1]; // first K chunk of each range ([n_src] = nchunks) in the launched kernel's chunk
+                                     // size; every range is padded to whole chunks: a chunk never straddles tensors
     int n_src;
     const float *wpk;  // packed weights, see pack_conv_weights()
     const float *bias; // [n_tiles_total*16], zero padded
@@ -28,6 +28,14 @@ struct ConvArgs {
     // fast path (conv_dma.hip) only:
     const float *zero_page;  // >= 16 B of zeros (source of out-of-image / padding DMA pieces)
     int ntiles;              // ceil(Cout/16)
+    // fused epilogue stages (conv_epilogue.h); zero-initialised = plain conv
+    int no_bias;             // skip the bias add (the low-resolution half of a commuted upsample+1x1 conv)
+    int pool;                // 2x2 average pool in the epilogue: dst is [B, dst_ctotal, Hout/2, Wout/2]
+    const float *res;        // residual [B, res_ctotal, Hres, Wres], bilinearly upsampled (align_corners) and added
+    int res_ctotal, res_choff, Hres, Wres;
+    float res_sh, res_sw;    // (Hres-1)/(Hout-1), (Wres-1)/(Wout-1)
+    int src_begin, src_end;      // input ranges to accumulate (whole conv: 0, n_src)
+    int chunk_begin, chunk_end;  // = src_chunk0[src_begin], src_chunk0[src_end] (filled at launch)
     long long *probe;        // PF_PROBE builds only: in-kernel timestamps of workgroup 0 / wave 0 (else nullptr)
 };
 
@@ -52,7 +60,8 @@ int launch_conv(const ConvArgs &a, const ConvTiling &t, int B, hipStream_t strea
 // a.nchunks = ceil(Cin / kc) with kc = dma_kc(ks, stride) input channels per double-buffered stage.
 constexpr int dma_kc_ct(int ks, int stride) { return ks == 1 ? 16 : (stride == 2 ? 4 : 8); }
 inline int dma_kc(int ks, int stride) { return dma_kc_ct(ks, stride); }
-void pack_conv_weights_tiled(const float *w_oihw, int cin, int cout, int ks, int kc, float *out);
+int dma_chunks(const int *src_ch, int n_src, int ks, int stride);
+void pack_conv_weights_tiled(const float *w_oihw, int cin, int cout, int ks, int kc, const int *src_ch, int n_src, float *out);
 // force_wm/force_nt > 0 override the cost model (tuning runs)
 int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t stream, int force_wm = 0, int force_nt = 0);
 
@@ -71,7 +80,8 @@ int launch_conv_wave(const ConvArgs &a, int ks, int mh, int nt, int wk, int B, h
 struct ConvChoice {
     int kind, p0, p1, p2;
 };
-ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B);
+// need: bit 1 = even tile rows if conv_wave is chosen (pooling epilogue)
+ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B, int need = 0);
 long long *probe_buffer();
 // tuning hook (pf_debug_force_conv): kind 0 = automatic
 extern ConvChoice g_conv_force;

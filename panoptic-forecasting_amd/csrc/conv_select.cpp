@@ -25,21 +25,24 @@ size_t wave_lds_bytes(int ks, int mh, int nt, int wk) {
 }
 }  // namespace
 
-ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B) {
+ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B, int need) {
     if (stride != 1) return ConvChoice{1, 0, 0, 0};           // conv_dma, shape by its cost model
     for (const Tuned &t : kTuned)
-        if (t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == B) return t.c;
+        if (t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == B &&
+            (!(need & 2) || t.c.kind != 2 || t.c.p0 != 1))
+            return t.c;
     // Untuned shape.  Images of >= 256x512 pixels keep the barrier-synchronised kernel (its big shared tiles move the
     // fewest bytes); below that the wave-autonomous kernel wins everywhere it was measured.  Pick the tile with the
     // most operand reuse (rows x cout tiles) that still puts >= 2 waves on every SIMD of the chip.
     const long px = (long)B * hout * wout;
     if (px >= 131072) return ConvChoice{1, 0, 0, 0};
     const int ntiles = (cout + 15) / 16;
-    ConvChoice best{2, 1, 1, 8};
+    ConvChoice best{2, (need & 2) ? 2 : 1, 1, 8};
     long best_reuse = -1, best_waves = -1;
     const int mhs[3] = {4, 2, 1}, wks[3] = {2, 4, 8};
     for (int mh : mhs)
         for (int nt = 2; nt >= 1; --nt) {
+            if ((need & 2) && mh == 1) continue;
             if (nt > ntiles) continue;
             for (int wk : wks) {
                 if (wave_lds_bytes(ks, mh, nt, wk) > 64 * 1024) continue;

@@ -12,7 +12,7 @@
 //   * the weights of a chunk go L2 -> VGPR directly (fragment order, one dwordx4 per 4 MFMAs): no LDS space,
 //     no ds_read for the B operand, so 16-32 waves fit a CU;
 //   * small tiles (MH = 1 or 2) keep >= 1 wave per SIMD even for a 16x32 image.
-#include "conv_mfma.h"
+#include "conv_epilogue.h"
 #include "pf_prof.h"
 
 #ifndef PF_PROBE
@@ -182,25 +182,26 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
     };
 
     // ---- main loop: this wave's chunks wk, wk+WK, ...; two-stage ring, registers double-buffered by hand
-    const int nmine = a.nchunks > wk ? (a.nchunks - wk + WK - 1) / WK : 0;
+    const int cb = a.chunk_begin, nch = a.chunk_end - cb;
+    const int nmine = nch > wk ? (nch - wk + WK - 1) / WK : 0;
     WFrag w0[NT], w1[NT];
     PROBE();
     // The prefetch is issued unconditionally (past the end it re-reads this wave's last chunk into the idle stage):
     // straight-line code lets the compiler's vmcnt bookkeeping stay exact - a branch around the prefetch makes it
     // fall back to vmcnt(0) before the MFMAs and the pipeline degenerates to load -> wait -> compute.
-    const int last = wk + (nmine - 1) * WK;
+    const int first = cb + wk, last = first + (nmine - 1) * WK;
     if (nmine > 0) {
-        issue(wk, ring, w0);
+        issue(first, ring, w0);
         PROBE();
         for (int i = 0; i < nmine; i += 2) {
-            issue(min(wk + (i + 1) * WK, last), ring + C::STAGE, w1);
+            issue(min(first + (i + 1) * WK, last), ring + C::STAGE, w1);
             PROBE();
             wait_vm<C::NL>();
             PROBE();
             compute(ring, w0);
             PROBE();
             if (i + 1 < nmine) {
-                issue(min(wk + (i + 2) * WK, last), ring, w0);
+                issue(min(first + (i + 2) * WK, last), ring, w0);
                 PROBE();
                 wait_vm<C::NL>();
                 PROBE();
@@ -226,31 +227,27 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
     __syncthreads();
     PROBE();
 
-    const size_t out_plane = (size_t)a.Hout * a.Wout;
-    const bool vec = (a.Wout & 3) == 0;
+    // unit = one output fragment (or, when pooling, the fragments of rows m, m+1): summed and finished by one wave
+    const int rows = a.pool ? 2 : 1;
 #pragma unroll
-    for (int mn = 0; mn < MH * NT; ++mn) {
-        if (mn % WK != wk) continue;
-        const int m = mn / NT, n = mn - m * NT;
-        f32x4 v = red[(mn * WK) * 64 + lane];
-#pragma unroll
-        for (int k = 1; k < WK; ++k) v += red[(mn * WK + k) * 64 + lane];
+    for (int u = 0; u < MH * NT; ++u) {
+        if (u % WK != wk || u >= (MH / rows) * NT) continue;
+        const int m = (u / NT) * rows, n = u % NT;
         const int co = (tile0 + n) * 16 + (lane & 15);
         const int oy = oy0 + m, ox = ox0 + (lane >> 4) * 4;
         if (co >= a.Cout || oy >= a.Hout || ox >= a.Wout) continue;
-        const float bias = a.bias[co];
+        auto total = [&](int mm) {
+            const int mn = mm * NT + n;
+            f32x4 v = red[(mn * WK) * 64 + lane];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[r] += bias;
-            if (a.relu) v[r] = fmaxf(v[r], 0.f);
-        }
-        float *p = a.dst + ((size_t)b * a.dst_ctotal + a.dst_choff + co) * out_plane + (size_t)oy * a.Wout + ox;
-        if (vec && ox + 3 < a.Wout) {
-            *reinterpret_cast<f32x4 *>(p) = v;
+            for (int k = 1; k < WK; ++k) v += red[(mn * WK + k) * 64 + lane];
+            return v;
+        };
+        const f32x4 top = epi_finish(a, b, co, oy, ox, total(m));
+        if (a.pool) {
+            if (MH > 1 && oy + 1 < a.Hout) epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, total(MH > 1 ? m + 1 : m)));
         } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (ox + r < a.Wout) p[r] = v[r];
+            epi_store(a, b, co, oy, ox, top);
         }
     }
 #endif

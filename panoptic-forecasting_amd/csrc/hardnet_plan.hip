@@ -31,6 +31,7 @@ struct pf_plan {
     std::vector<BlobTensor> tensors;
     std::vector<BlobOp> ops;
     std::vector<ConvPlan> conv;  // parallel to ops
+    std::vector<int> readers;    // per tensor: number of ops that read it
     float *dev_weights = nullptr;
     uint8_t *dev_lut = nullptr;
     size_t dev_floats = 0;
@@ -111,6 +112,86 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
     };
 
     static const bool tag_ops = getenv("PF_PROFILE_OPS") != nullptr;
+    static const bool fuse = getenv("PF_NO_FUSE") == nullptr;    // A/B switch for the fused epilogue stages
+
+    auto fill_conv_args = [&](const BlobOp &o, size_t i, const Dims &in, const Dims &out, ConvArgs &a) {
+        memset(&a, 0, sizeof(a));
+        a.n_src = (int)o.n_src;
+        int c0 = 0;
+        for (int j = 0; j < a.n_src; ++j) {
+            a.src[j] = tptr(o.src[j].tensor);
+            a.src_ctotal[j] = (int)p->tensors[o.src[j].tensor].channels;
+            a.src_choff[j] = (int)o.src[j].choff;
+            a.src_cstart[j] = c0;
+            c0 += (int)o.src[j].ch;
+        }
+        for (int j = a.n_src; j <= kConvMaxSrc; ++j) a.src_cstart[j] = c0;
+        a.bias = p->dev_weights + p->conv[i].bias_off;
+        a.dst = tptr(o.dst);
+        a.dst_ctotal = (int)p->tensors[o.dst].channels;
+        a.dst_choff = (int)o.dst_choff;
+        a.Cin = (int)o.cin; a.Cout = (int)o.cout;
+        a.Hin = in.h; a.Win = in.w; a.Hout = out.h; a.Wout = out.w;
+        a.relu = (int)o.relu;
+        a.zero_page = p->dev_weights;   // first 64 floats of the weight arena are zeros
+        a.ntiles = ((int)o.cout + 15) / 16;
+        a.src_begin = 0;
+        a.src_end = a.n_src;
+        static const bool probe_on = getenv("PF_PROBE") != nullptr;
+        a.probe = probe_on ? probe_buffer() : nullptr;
+    };
+    // need: bit 1 = even tile rows (pooling epilogue), bit 2 = fused stage (not available on the generic path)
+    auto launch_conv_op = [&](const BlobOp &o, size_t i, ConvArgs &a, int need) -> int {
+        if ((a.Win & 3) != 0) {
+            if (need) return fail(PF_EUNSUPPORTED, "fused conv on a width that is not a multiple of 4");
+            a.wpk = p->dev_weights + p->conv[i].wpk_off;
+            a.nchunks = p->conv[i].tiling.nchunks;
+            return launch_conv(a, p->conv[i].tiling, B, s);
+        }
+        ConvChoice ch = choose_conv((int)o.k, (int)o.stride, a.Cin, a.Cout, a.Hout, a.Wout, B, need);
+        if (g_conv_force.kind == 2 && o.stride == 1) {
+            ch = g_conv_force;
+            if ((need & 2) && ch.p0 == 1) ch.p0 = 2;
+        }
+        if (g_conv_force.kind == 1) ch = g_conv_force;
+        int rc = PF_EUNSUPPORTED;
+        auto set_chunks = [&](int kc) {
+            a.src_chunk0[0] = 0;
+            for (int j = 0; j < kConvMaxSrc; ++j)
+                a.src_chunk0[j + 1] = a.src_chunk0[j] + (j < a.n_src ? ((int)o.src[j].ch + kc - 1) / kc : 0);
+            a.chunk_begin = a.src_chunk0[a.src_begin];
+            a.chunk_end = a.src_chunk0[a.src_end];
+        };
+        if (ch.kind == 2) {
+            a.wpk = p->dev_weights + p->conv[i].wave_off;
+            a.nchunks = p->conv[i].wave_chunks;
+            set_chunks(wave_kc((int)o.k));
+            rc = launch_conv_wave(a, (int)o.k, ch.p0, ch.p1 < a.ntiles ? ch.p1 : a.ntiles, ch.p2, B, s);
+            if (rc == PF_EUNSUPPORTED && g_conv_force.kind == 2) {   // forced shape not built
+                ch = choose_conv((int)o.k, (int)o.stride, a.Cin, a.Cout, a.Hout, a.Wout, B, need);
+                if (ch.kind == 2) rc = launch_conv_wave(a, (int)o.k, ch.p0, ch.p1 < a.ntiles ? ch.p1 : a.ntiles, ch.p2, B, s);
+            }
+        }
+        if (ch.kind != 2) {
+            a.wpk = p->dev_weights + p->conv[i].tiled_off;
+            a.nchunks = p->conv[i].tiled_chunks;
+            set_chunks(dma_kc((int)o.k, (int)o.stride));
+            rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s, ch.p0, ch.p1);
+        }
+        return rc;
+    };
+    // Opt-in (PF_FUSE_UP=1): correct and tested, but the per-lane bilinear gather of the residual in the epilogue
+    // (16 uncoalesced loads per fragment) currently costs more than the upsample pass it removes
+    // (gpurun_out/layers_b4f.txt: transUp.3 + conv1x1_up.3 281 us fused vs 233 us unfused at B=4).
+    static const bool fuse_up = getenv("PF_FUSE_UP") != nullptr;
+    auto can_commute_upsample = [&](size_t i, const Dims &in, const Dims &out) -> bool {
+        if (!fuse || !fuse_up || i + 1 >= p->ops.size()) return false;
+        const BlobOp &o = p->ops[i], &n = p->ops[i + 1];
+        return n.kind == OP_CONV && n.k == 1 && n.stride == 1 && n.n_src == 2 && n.src[0].tensor == o.dst &&
+               n.src[0].choff == 0 && n.src[0].ch == p->tensors[o.dst].channels && p->readers[o.dst] == 1 &&
+               (in.w & 3) == 0 && (out.w & 3) == 0 && n.cout <= p->tensors[o.dst].channels;
+    };
+
     for (size_t i = 0; i < p->ops.size(); ++i) {
         const BlobOp &o = p->ops[i];
         const Dims in = d[o.src[0].tensor];
@@ -136,57 +217,55 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         } else if (o.kind == OP_STEM || o.kind == OP_CONV) {
             if (o.src[0].tensor == input && !dense_x)
                 return fail(PF_EINVAL, "network input is consumed by a generic conv: use pf_hardnet_forward_dense");
+            // conv + AvgPool2d(2,2): pool in the conv epilogue, the full-resolution tensor is never written
+            const BlobOp *pool = nullptr;
+            if (fuse && i + 1 < p->ops.size() && p->ops[i + 1].kind == OP_POOL && o.stride == 1 && (in.w & 3) == 0 &&
+                p->ops[i + 1].src[0].tensor == o.dst && o.dst_choff == 0 && o.cout == p->tensors[o.dst].channels &&
+                p->readers[o.dst] == 1 && out.h >= 2 && out.w >= 2)
+                pool = &p->ops[i + 1];
             ConvArgs a;
-            memset(&a, 0, sizeof(a));
-            a.n_src = (int)o.n_src;
-            int c0 = 0;
-            for (int j = 0; j < a.n_src; ++j) {
-                a.src[j] = tptr(o.src[j].tensor);
-                a.src_ctotal[j] = (int)p->tensors[o.src[j].tensor].channels;
-                a.src_choff[j] = (int)o.src[j].choff;
-                a.src_cstart[j] = c0;
-                c0 += (int)o.src[j].ch;
+            fill_conv_args(o, i, in, out, a);
+            if (pool) {
+                a.pool = 1;
+                a.dst = tptr(pool->dst);
+                a.dst_ctotal = (int)p->tensors[pool->dst].channels;
             }
-            for (int j = a.n_src; j <= kConvMaxSrc; ++j) a.src_cstart[j] = c0;
-            a.wpk = p->dev_weights + p->conv[i].wpk_off;
-            a.bias = p->dev_weights + p->conv[i].bias_off;
-            a.dst = tptr(o.dst);
-            a.dst_ctotal = (int)p->tensors[o.dst].channels;
-            a.dst_choff = (int)o.dst_choff;
-            a.Cin = (int)o.cin; a.Cout = (int)o.cout;
-            a.Hin = in.h; a.Win = in.w; a.Hout = out.h; a.Wout = out.w;
-            a.relu = (int)o.relu;
-            a.zero_page = p->dev_weights;   // first 64 floats of the weight arena are zeros
-            a.ntiles = ((int)o.cout + 15) / 16;
-            static const bool probe_on = getenv("PF_PROBE") != nullptr;
-            a.probe = probe_on ? probe_buffer() : nullptr;
-            if ((in.w & 3) == 0) {
-                ConvChoice ch = choose_conv((int)o.k, (int)o.stride, a.Cin, a.Cout, a.Hout, a.Wout, B);
-                if (g_conv_force.kind == 2 && o.stride == 1) ch = g_conv_force;
-                if (g_conv_force.kind == 1) ch = g_conv_force;
-                rc = PF_EUNSUPPORTED;
-                if (ch.kind == 2) {
-                    a.wpk = p->dev_weights + p->conv[i].wave_off;
-                    a.nchunks = p->conv[i].wave_chunks;
-                    const int kc = wave_kc((int)o.k);
-                    a.src_chunk0[0] = 0;
-                    for (int j = 0; j < kConvMaxSrc; ++j)
-                        a.src_chunk0[j + 1] = a.src_chunk0[j] + (j < a.n_src ? ((int)o.src[j].ch + kc - 1) / kc : 0);
-                    rc = launch_conv_wave(a, (int)o.k, ch.p0, ch.p1 < a.ntiles ? ch.p1 : a.ntiles, ch.p2, B, s);
-                    if (rc == PF_EUNSUPPORTED && g_conv_force.kind == 2) ch = ConvChoice{1, 0, 0, 0};   // forced shape not built
-                }
-                if (ch.kind != 2) {
-                    a.wpk = p->dev_weights + p->conv[i].tiled_off;
-                    a.nchunks = p->conv[i].tiled_chunks;
-                    rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s, ch.p0, ch.p1);
-                }
-            } else {
-                a.nchunks = p->conv[i].tiling.nchunks;
-                rc = launch_conv(a, p->conv[i].tiling, B, s);
-            }
-            if (rc) return rc;
+            if ((rc = launch_conv_op(o, i, a, pool ? 2 : 0))) return rc;
+            if (pool) ++i;   // the pool op is done
         } else if (o.kind == OP_POOL) {
             if ((rc = launch_avgpool2(tptr(o.src[0].tensor), tptr(o.dst), B * (int)o.cin, in.h, in.w, s))) return rc;
+        } else if (o.kind == OP_UPSAMPLE && can_commute_upsample(i, in, out)) {
+            // TransitionUp + 1x1 conv over cat([up(x), skip])  ==  W_skip*skip + up(W_x*x)   (conv_epilogue.h)
+            const BlobOp &n = p->ops[i + 1];
+            const Dims hi = out;   // = size of the skip tensor
+            ConvArgs lo;
+            fill_conv_args(n, i + 1, in, in, lo);
+            lo.src[0] = tptr(o.src[0].tensor);                 // x at the low resolution
+            lo.src_ctotal[0] = (int)p->tensors[o.src[0].tensor].channels;
+            lo.src_choff[0] = (int)o.src[0].choff;
+            lo.dst = tptr(o.dst);                              // scratch: the slot of the (never built) upsampled tensor
+            lo.dst_ctotal = (int)n.cout;
+            lo.dst_choff = 0;
+            lo.relu = 0;
+            lo.no_bias = 1;
+            lo.Cin = (int)n.src[0].ch;
+            lo.src_begin = 0;
+            lo.src_end = 1;
+            if ((rc = launch_conv_op(n, i + 1, lo, 4))) return rc;
+            ConvArgs hi_a;
+            fill_conv_args(n, i + 1, hi, hi, hi_a);
+            hi_a.Cin = (int)n.src[1].ch;
+            hi_a.src_begin = 1;
+            hi_a.src_end = 2;
+            hi_a.res = tptr(o.dst);
+            hi_a.res_ctotal = (int)n.cout;
+            hi_a.res_choff = 0;
+            hi_a.Hres = in.h;
+            hi_a.Wres = in.w;
+            hi_a.res_sh = hi.h > 1 ? (float)(in.h - 1) / (float)(hi.h - 1) : 0.f;
+            hi_a.res_sw = hi.w > 1 ? (float)(in.w - 1) / (float)(hi.w - 1) : 0.f;
+            if ((rc = launch_conv_op(n, i + 1, hi_a, 4))) return rc;
+            ++i;   // the 1x1 conv is done
         } else if (o.kind == OP_UPSAMPLE) {
             if ((rc = launch_upsample(tptr(o.src[0].tensor), tptr(o.dst), B * (int)o.cin, in.h, in.w, out.h, out.w, s)))
                 return rc;
@@ -263,16 +342,17 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
         const size_t nb = (size_t)c.tiling.cout_blocks * c.tiling.nt * 16;
         host.resize(host.size() + nb, 0.f);
         memcpy(host.data() + c.bias_off, wts + o.b_off, o.cout * sizeof(float));
+        int src_ch[kMaxSrc];
+        for (uint32_t j = 0; j < o.n_src; ++j) src_ch[j] = (int)o.src[j].ch;
         {
             const int kc = dma_kc((int)o.k, (int)o.stride);
-            c.tiled_chunks = ((int)o.cin + kc - 1) / kc;
+            c.tiled_chunks = dma_chunks(src_ch, (int)o.n_src, (int)o.k, (int)o.stride);
             c.tiled_off = host.size();
             host.resize(host.size() + (size_t)((o.cout + 15) / 16) * c.tiled_chunks * (kc / 4) * o.k * o.k * 64);
-            pack_conv_weights_tiled(wts + o.w_off, (int)o.cin, (int)o.cout, (int)o.k, kc, host.data() + c.tiled_off);
+            pack_conv_weights_tiled(wts + o.w_off, (int)o.cin, (int)o.cout, (int)o.k, kc, src_ch, (int)o.n_src,
+                                    host.data() + c.tiled_off);
         }
         if (o.stride == 1) {
-            int src_ch[kMaxSrc];
-            for (uint32_t j = 0; j < o.n_src; ++j) src_ch[j] = (int)o.src[j].ch;
             c.wave_chunks = wave_chunks(src_ch, (int)o.n_src, (int)o.k);
             c.wave_off = host.size();
             host.resize(host.size() + wave_packed_floats(src_ch, (int)o.n_src, (int)o.cout, (int)o.k));
@@ -285,6 +365,9 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
         }
         host.resize(align_up(host.size(), 64), 0.f);
     }
+    p->readers.assign(p->tensors.size(), 0);
+    for (const BlobOp &o : p->ops)
+        for (uint32_t j = 0; j < o.n_src; ++j) p->readers[o.src[j].tensor]++;
     p->dev_floats = host.size();
     uint8_t lut[256];
     fill_lut(lut);

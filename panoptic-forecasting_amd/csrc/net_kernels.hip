@@ -9,18 +9,10 @@
 //   upsample_kernel    : F.interpolate(bilinear, align_corners) hardnet.py:248-253
 //   head_kernel        : final bilinear upsample + argmax      hardnet.py:372-384, bg_model.py:98
 #include "net_kernels.h"
+#include "conv_epilogue.h"
 #include "pf_prof.h"
 
 namespace pf {
-
-// align_corners=True source index (ATen area_pixel_compute_scale / compute_source_index)
-__device__ __forceinline__ void lin_coord(int o, float scale, int in_size, int &i0, int &i1, float &l0, float &l1) {
-    const float r = scale * (float)o;
-    i0 = min((int)r, in_size - 1);
-    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
-    l1 = fminf(fmaxf(r - (float)i0, 0.f), 1.f);
-    l0 = 1.f - l1;
-}
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stem_onehot_kernel(StemArgs a) {

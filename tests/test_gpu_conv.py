@@ -130,3 +130,34 @@ def test_every_kernel_shape(force, force_conv):
         err = (net.tensor(name).cpu() - ref).abs().max().item()
         assert err <= _tol(ref), (name, err, _tol(ref))
     net.close()
+
+
+@pytest.mark.parametrize('h,w,b', [(32, 64, 1), (20, 40, 2), (34, 52, 1)])
+def test_fused_pool_and_commuted_upsample(h, w, b):
+    """The executor's fused stages (conv_epilogue.h): 1x1 conv + AvgPool2d in one launch, and
+    TransitionUp + 1x1 conv over cat([up(x), skip]) evaluated as W_skip*skip + up(W_x*x)."""
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    g = torch.Generator().manual_seed(h * 7 + w)
+    x = torch.randn(b, 12, h, w, generator=g)
+    spec = MiniSpec(12)
+    c1 = spec.conv('c1', [arch.Src(0, 0, 12)], 20, 3)
+    c2 = spec.conv('c2', [arch.Src(c1, 0, 20)], 24, 1)
+    p = spec.pool('p', c2)
+    c3 = spec.conv('c3', [arch.Src(p, 0, 24)], 16, 3)
+    up = spec.upsample('up', c3, c1)
+    spec.conv('c4', [arch.Src(up, 0, 16), arch.Src(c1, 0, 20)], 18, 1)
+    P = {}
+    for name, cin, cout, k in [('c1', 12, 20, 3), ('c2', 20, 24, 1), ('c3', 24, 16, 3), ('c4', 36, 18, 1)]:
+        P[name] = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.randn(cout, generator=g))
+    net = MiniNet(spec, P).run(x.cuda())
+    r1 = F.relu(F.conv2d(x, *P['c1'], padding=1))
+    r2 = F.relu(F.conv2d(r1, *P['c2']))
+    rp = F.avg_pool2d(r2, 2, 2)
+    r3 = F.relu(F.conv2d(rp, *P['c3'], padding=1))
+    ru = F.interpolate(r3, size=(h, w), mode='bilinear', align_corners=True)
+    r4 = F.relu(F.conv2d(torch.cat([ru, r1], 1), *P['c4']))
+    assert (net.tensor('p').cpu() - rp).abs().max() <= _tol(rp)
+    assert (net.tensor('c3').cpu() - r3).abs().max() <= _tol(r3)
+    assert (net.tensor('c4').cpu() - r4).abs().max() <= 2 * _tol(r4)
+    net.close()
