@@ -111,6 +111,14 @@ int pf_hardnet_forward_dense(const pf_plan *plan, const float *x, int B, int H, 
                              int out_w, void *out_seg, int out_seg_is_i64, float *out_logits,
                              float *out_orig_logits, void *ws, size_t ws_bytes, void *stream);
 
+/* Process-wide execution options (not thread-safe; set before launching work):
+ *   "fuse_pool"     (default 1) a 1x1 conv followed by AvgPool2d(2,2) (hardnet.py:296) pools in the conv epilogue;
+ *   "fuse_upsample" (default 0) TransitionUp + 1x1 conv over cat([up(x), skip]) (hardnet.py:248-258,365-368) is
+ *                   evaluated as W_skip*skip + up(W_x*x): same result up to fp32 rounding, no upsampled tensor;
+ *   "use_tuned_table" (default 1) per-layer kernel shapes come from the measured table (csrc/conv_tuned.inc) where it
+ *                   has the shape, else from the cost model; 0 = cost model only (tools/tune_convs.py). */
+int pf_set_option(const char *name, int value);
+
 /* Introspection for per-stage parity tests: where tensor `name` (packing.py tensor names, e.g.
  * "base.4.out") lives inside the workspace for this (B,H,W): byte offset, channels, height, width. */
 int pf_hardnet_tensor_view(const pf_plan *plan, const char *name, int B, int H, int W,

@@ -4,6 +4,7 @@
 namespace pf {
 
 ConvChoice g_conv_force = {0, 0, 0, 0};
+int g_opt_use_tuned = 1;   // pf_set_option("use_tuned_table", 0/1)
 
 namespace {
 struct Tuned {
@@ -28,7 +29,7 @@ size_t wave_lds_bytes(int ks, int mh, int nt, int wk) {
 ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B, int need) {
     if (stride != 1) return ConvChoice{1, 0, 0, 0};           // conv_dma, shape by its cost model
     for (const Tuned &t : kTuned)
-        if (t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == B &&
+        if (g_opt_use_tuned && t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == B &&
             (!(need & 2) || t.c.kind != 2 || t.c.p0 != 1))
             return t.c;
     // Untuned shape.  Images of >= 256x512 pixels keep the barrier-synchronised kernel (its big shared tiles move the

@@ -37,6 +37,20 @@ struct pf_plan {
     size_t dev_floats = 0;
 };
 
+namespace pf {
+int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 0;
+extern int g_opt_use_tuned;
+}
+
+extern "C" int pf_set_option(const char *name, int value) {
+    if (!name) return fail(PF_EINVAL, "pf_set_option: null name");
+    if (!strcmp(name, "fuse_pool")) g_opt_fuse_pool = value;
+    else if (!strcmp(name, "fuse_upsample")) g_opt_fuse_upsample = value;
+    else if (!strcmp(name, "use_tuned_table")) g_opt_use_tuned = value;
+    else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);
+    return PF_OK;
+}
+
 namespace {
 
 struct Dims {
@@ -112,7 +126,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
     };
 
     static const bool tag_ops = getenv("PF_PROFILE_OPS") != nullptr;
-    static const bool fuse = getenv("PF_NO_FUSE") == nullptr;    // A/B switch for the fused epilogue stages
+    const bool fuse = g_opt_fuse_pool != 0;      // pf_set_option("fuse_pool", 0/1)
 
     auto fill_conv_args = [&](const BlobOp &o, size_t i, const Dims &in, const Dims &out, ConvArgs &a) {
         memset(&a, 0, sizeof(a));
@@ -180,10 +194,10 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         }
         return rc;
     };
-    // Opt-in (PF_FUSE_UP=1): correct and tested, but the per-lane bilinear gather of the residual in the epilogue
+    // Opt-in (pf_set_option("fuse_upsample", 1)): correct and tested, but the per-lane bilinear gather of the residual in the epilogue
     // (16 uncoalesced loads per fragment) currently costs more than the upsample pass it removes
     // (gpurun_out/layers_b4f.txt: transUp.3 + conv1x1_up.3 281 us fused vs 233 us unfused at B=4).
-    static const bool fuse_up = getenv("PF_FUSE_UP") != nullptr;
+    const bool fuse_up = g_opt_fuse_upsample != 0;   // pf_set_option("fuse_upsample", 0/1)
     auto can_commute_upsample = [&](size_t i, const Dims &in, const Dims &out) -> bool {
         if (!fuse || !fuse_up || i + 1 >= p->ops.size()) return false;
         const BlobOp &o = p->ops[i], &n = p->ops[i + 1];

@@ -27,6 +27,7 @@ SIGNATURES = {
     'pf_hardnet_tensor_view': (_i, [_vp, _c.c_char_p, _i, _i, _i, _c.POINTER(_sz), _c.POINTER(_i),
                                     _c.POINTER(_i), _c.POINTER(_i)]),
     'pf_hardnet_flops': (_i, [_vp, _i, _i, _c.POINTER(_c.c_double)]),
+    'pf_set_option': (_i, [_c.c_char_p, _i]),
     'pf_debug_force_conv': (_i, [_i, _i, _i, _i]),
     'pf_debug_probe_read': (_i, [_c.POINTER(_c.c_longlong)]),
     'pf_profile_enable': (_i, [_i]),

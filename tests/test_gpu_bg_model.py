@@ -125,3 +125,27 @@ def test_cpu_inputs_fail_loudly():
     m = _model(64, 128)
     with pytest.raises(PfError):
         m.predict(synth.make_bg_inputs(b=1, h=64, w=128), None)
+
+
+@pytest.mark.parametrize('opts', [dict(fuse_pool=0, fuse_upsample=0), dict(fuse_pool=1, fuse_upsample=1)],
+                         ids=['unfused', 'all_fused'])
+def test_execution_options_do_not_change_the_result(opts):
+    """pf_set_option: the fused epilogue stages (pool; commuted upsample) vs the oracle, same tolerance."""
+    from oracle import hardnet_ref
+    from panoptic_forecasting_amd import lib as pflib
+    from panoptic_forecasting_amd import synth
+    L = pflib.load()
+    h, w = 128, 256
+    try:
+        for k, v in opts.items():
+            pflib.check(L.pf_set_option(k.encode(), v), 'pf_set_option')
+        m = _model(h, w)
+        inp = synth.make_bg_inputs(b=2, h=h, w=w, seed=21)
+        ref = hardnet_ref.bg_predict(_sd(), inp, final_size=(h, w))
+        out = m.predict({k: v.cuda() for k, v in inp.items()}, None)
+        assert (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max() <= LOGIT_TOL
+        assert (out['seg'].cpu() == ref['seg']).float().mean() >= AGREE
+    finally:
+        L.pf_set_option(b'fuse_pool', 1)
+        L.pf_set_option(b'fuse_upsample', 0)
+    assert L.pf_set_option(b'no_such_option', 1) == -1

@@ -132,8 +132,17 @@ def test_every_kernel_shape(force, force_conv):
     net.close()
 
 
+@pytest.fixture
+def fuse_upsample():
+    from panoptic_forecasting_amd import lib as pflib
+    L = pflib.load()
+    pflib.check(L.pf_set_option(b'fuse_upsample', 1), 'pf_set_option')
+    yield
+    L.pf_set_option(b'fuse_upsample', 0)
+
+
 @pytest.mark.parametrize('h,w,b', [(32, 64, 1), (20, 40, 2), (34, 52, 1)])
-def test_fused_pool_and_commuted_upsample(h, w, b):
+def test_fused_pool_and_commuted_upsample(h, w, b, fuse_upsample):
     """The executor's fused stages (conv_epilogue.h): 1x1 conv + AvgPool2d in one launch, and
     TransitionUp + 1x1 conv over cat([up(x), skip]) evaluated as W_skip*skip + up(W_x*x)."""
     from helpers import MiniNet, MiniSpec

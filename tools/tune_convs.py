@@ -26,6 +26,7 @@ ap.add_argument('--width', type=int, default=bench.W)
 args = ap.parse_args()
 bench.H, bench.W = args.height, args.width
 L = pflib.load()
+pflib.check(L.pf_set_option(b'use_tuned_table', 0), 'pf_set_option')   # 'auto' = the cost model alone
 model = build_model(bench.model_params())
 model.load_state_dict(bench.calibrated_state_dict())
 batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
