@@ -181,10 +181,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.nchunks = p->conv[i].wave_chunks;
             set_chunks(wave_kc((int)o.k));
             rc = launch_conv_wave(a, (int)o.k, ch.p0, ch.p1 < a.ntiles ? ch.p1 : a.ntiles, ch.p2, B, s);
-            if (rc == PF_EUNSUPPORTED && g_conv_force.kind == 2) {   // forced shape not built
-                ch = choose_conv((int)o.k, (int)o.stride, a.Cin, a.Cout, a.Hout, a.Wout, B, need);
-                if (ch.kind == 2) rc = launch_conv_wave(a, (int)o.k, ch.p0, ch.p1 < a.ntiles ? ch.p1 : a.ntiles, ch.p2, B, s);
-            }
+            if (rc == PF_EUNSUPPORTED) ch = ConvChoice{1, 0, 0, 0};   // shape not built: conv_dma with its cost model
         }
         if (ch.kind != 2) {
             a.wpk = p->dev_weights + p->conv[i].tiled_off;

@@ -66,8 +66,17 @@ rows = []
 for tag in sorted(table):
     d = table[tag]
     auto = d[(0, 0, 0, 0)]
-    # a forced shape that is not built falls back to auto: only count entries whose kernel name matches the request
-    cands = {c: v for c, v in d.items() if c[0] == 0 or (c[0] == 1 and 'conv_dma' in v[1]) or (c[0] == 2 and 'conv_wave' in v[1])}
+    # a forced shape that is not built falls back to the automatic choice: keep an entry only if the kernel that ran
+    # (template arguments in its label) is the one that was asked for
+    def ran_as_asked(c, kern):
+        import re as _re
+        nums = [int(x) for x in _re.findall(r'-?\d+', kern.split('<', 1)[1])] if '<' in kern else []
+        if c[0] == 0:
+            return True
+        if c[0] == 1:
+            return 'conv_dma' in kern and len(nums) == 5 and nums[2] == c[1] and nums[4] <= c[2]
+        return 'conv_wave' in kern and len(nums) == 4 and nums[1] == c[1] and nums[2] <= c[2] and nums[3] == c[3]
+    cands = {c: v for c, v in d.items() if ran_as_asked(c, v[1])}
     best = min(cands, key=lambda c: cands[c][0])
     tot_auto += auto[0]
     tot_best += cands[best][0]
