@@ -58,6 +58,18 @@ def make_batch(b, seed0, device):
     return {k: v.to(device) for k, v in inp.items()}
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of `kernel_label` from the committed PMC passes (profiles/pmc_latest.json: FETCH_SIZE +
+    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command and calibrated on a known-size copy,
+    tools/profile_gpu.sh + tools/profile_summarise.py), or None when that kernel was not profiled."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        k = json.load(f).get('kernels', {}).get(kernel_label)
+    return k.get('hbm_bytes_per_launch') if k else None
+
+
 def cpu_baseline(sd, n_frames):
     """The oracle (CPU port of the reference path) timed on this box's host cores."""
     import numpy as np
@@ -96,10 +108,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=1, help='forecast frames per GPU per step')
+    ap.add_argument('--batch', type=int, default=4, help='forecast frames per GPU per step (the reference export loop '
+                    'batches 2; 4 is where this path saturates one MI355X)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-frames', type=int, default=4)
+    ap.add_argument('--cpu-frames', type=int, default=12)
     ap.add_argument('--profile-steps', type=int, default=3)
     args = ap.parse_args()
 
@@ -182,7 +195,7 @@ def main():
                         'frac': achieved / PEAK_HBM_GBPS}
         conv = [r for r in recs if r['flops'] > 0]
         conv_ms = sum(r['ms'] for r in conv)
-        roofline.update({'traffic': None, 'kernel': dom['label'], 'launches_per_step': dom['launches'] // args.profile_steps,
+        roofline.update({'traffic': pmc_traffic(dom['label']), 'kernel': dom['label'], 'launches_per_step': dom['launches'] // args.profile_steps,
                          'avg_launch_us': per_launch_ms * 1e3, 'share_of_step': dom['ms'] / tot,
                          'all_conv_tflops': sum(r['flops'] for r in conv) / (conv_ms * 1e-3) / 1e12 if conv_ms else None,
                          'kernel_ms_per_step': tot / args.profile_steps})

@@ -8,7 +8,7 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph $*"
+BENCH="python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph --profile-steps 1 $*"
 cd /tmp
 # 1. kernel trace + stats (timing)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BENCH > "$OUT/bench_trace.log" 2>"$OUT/trace.err"

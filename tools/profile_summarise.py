@@ -96,8 +96,13 @@ def main(tag, prefix):
             e['calls'] = ks[k][0]
         if 'FETCH_SIZE_bytes' in e and 'WRITE_SIZE_bytes' in e:
             e['hbm_bytes_per_launch'] = e['FETCH_SIZE_bytes'] + e['WRITE_SIZE_bytes']
-    with open(os.path.join(dst, prefix + '_pmc.json'), 'w') as f:
-        json.dump(out, f, indent=1, sort_keys=True)
+    for k, e in out['kernels'].items():
+        # MFMA pipe utilisation: busy cycles summed over the 1024 SIMDs / (per-XCD active cycles summed over 8 XCDs / 8)
+        if e.get('GRBM_GUI_ACTIVE') and 'SQ_VALU_MFMA_BUSY_CYCLES' in e:
+            e['mfma_util'] = e['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * e['GRBM_GUI_ACTIVE'] / 8.0)
+    for name in (prefix + '_pmc.json', 'pmc_latest.json'):
+        with open(os.path.join(dst, name), 'w') as f:
+            json.dump(out, f, indent=1, sort_keys=True)
     print('wrote', prefix + '_kernel_stats.txt', prefix + '_pmc.json')
 
 
