@@ -121,7 +121,10 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    pflib.load()   # fails loudly if libpfhip.so is missing
+    L = pflib.load()   # fails loudly if libpfhip.so is missing
+    for kv in filter(None, os.environ.get('PF_OPTS', '').split(',')):    # A/B runs: PF_OPTS=fuse_upsample=1,...
+        k, v = kv.split('=')
+        pflib.check(L.pf_set_option(k.encode(), int(v)), 'pf_set_option')
 
     sd = calibrated_state_dict()
     model = build_model(model_params())

@@ -12,11 +12,22 @@
 //     machine ((WM,WK) = (4,1) | (2,2) | (1,4), picked per layer at launch by a small cost model).
 //   * weights are packed per 16-cout tile so the number of cout tiles per workgroup (NT) is a launch-time
 //     choice too (fat workgroups at high resolution, many at low resolution).
+#include <cstring>
+
 #include "conv_epilogue.h"
 #include "pf_prof.h"
 
 #ifndef PF_ABLATE
 #define PF_ABLATE 0
+#endif
+
+#ifndef PF_PROBE
+#define PF_PROBE 0
+#endif
+#if PF_PROBE   // 100 MHz wall-clock stamps of workgroup (5, 0, 0), thread 0 (tools/probe_conv.py)
+#define DPROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 5 && blockIdx.y == 0 && blockIdx.z == 0 && a.probe) a.probe[i] = wall_clock64(); } while (0)
+#else
+#define DPROBE(i) do { } while (0)
 #endif
 
 namespace pf {
@@ -48,7 +59,9 @@ struct DmaCfg {
 typedef __attribute__((address_space(3))) void *dma_lds_ptr_t;
 [[maybe_unused]] constexpr unsigned kDmaOob = 0x80000000u;   // voffset >= num_records: the DMA writes zeros (conv zero padding)
 
-template <int KS, int STRIDE, int WM, int WK, int NT>
+// EPI: 0 = bias + ReLU (the common case keeps its register budget), 1 = fused stages of conv_epilogue.h (2x2 pool,
+// upsampled residual) - separate instantiations because the fused epilogue needs ~70 more VGPRs.
+template <int KS, int STRIDE, int WM, int WK, int NT, int EPI>
 __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtin types in the body; the host pass only needs the stub
     using C = DmaCfg<KS, STRIDE, WM, WK, NT>;
@@ -102,7 +115,12 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
     }
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wpk, 0, 0x7FFFFFFF, 0x00020000);
 
+    float biasv[NT];   // fetched now, used in the epilogue: the latency hides behind the main loop
+#pragma unroll
+    for (int n = 0; n < NT; ++n) biasv[n] = epi_bias(a, (tile0 + n) * 16 + (lane & 15));
+
     const int cb = a.chunk_begin, nrounds = (a.chunk_end - cb + WK - 1) / WK;
+    DPROBE(0);
 
     // issue the DMA of one round (WK chunks: inputs + weights) into buffer `buf`.  Which tensor a chunk reads, its
     // first channel and how many of its KC channels exist are workgroup-uniform: select chains on the scalar ALU.
@@ -176,6 +194,18 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
         __syncthreads();                                    // ... and everyone is done with `cur`
     }
 
+    DPROBE(1);
+    // ---- residual window of this tile -> LDS (all waves, before the K-split partners leave)
+    ResWin rw = ResWin();
+    const lds_float *res_lds = nullptr;
+    if (EPI == 1 && a.res && a.res_lds_off >= 0) {
+        rw = res_window(a, tileY * C::TH, C::TH, tileX * C::TW, C::TW);
+        res_stage(a, rw, b, tile0 * 16, NT * 16, (lds_float *)(smem + a.res_lds_off), tid, NTHR);
+        res_lds = (const lds_float *)(smem + a.res_lds_off);
+        if (WK == 1) __syncthreads();   // (WK > 1: the reduction barrier below orders it)
+    }
+
+    DPROBE(2);
     // ---- K-split reduction through LDS: waves wk>0 publish, wave wk==0 sums
     if (WK > 1) {
         f32x4 *red = reinterpret_cast<f32x4 *>(smem);
@@ -197,51 +227,104 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
                     acc[m][n] += red[((((k - 1) * WM + wm) * C::MP + m) * NT + n) * 64 + lane];
     }
 
-    // ---- epilogue (conv_epilogue.h): bias, residual, ReLU, optional 2x2 pool (rows ty, ty+1 = M-tiles m, m+TWT)
+    DPROBE(3);
+    if (EPI == 0) {
+        // ---- plain epilogue: bias + ReLU, NCHW float4 stores
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int co = (tile0 + n) * 16 + (lane & 15);
-        if (co >= a.Cout) continue;
+        for (int n = 0; n < NT; ++n) {
+            const int co = (tile0 + n) * 16 + (lane & 15);
+            if (co >= a.Cout) continue;
+#pragma unroll
+            for (int m = 0; m < C::MP; ++m) {
+                const int mt = wm * C::MP + m;
+                const int oy = tileY * C::TH + mt / C::TWT;
+                const int ox = tileX * C::TW + (mt % C::TWT) * 16 + (lane >> 4) * 4;
+                if (oy >= a.Hout || ox >= a.Wout) continue;
+                f32x4 v = acc[m][n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] += biasv[n];
+                    if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                }
+                epi_store(a, b, co, oy, ox, v);
+            }
+        }
+    } else {
+        // ---- fused epilogue (conv_epilogue.h): bias, residual, ReLU, optional 2x2 pool (rows ty, ty+1 = M-tiles
+        //      m, m+TWT).  Pixel-group outer, channels inner: the residual taps are computed once for all NT tiles.
 #pragma unroll
         for (int m = 0; m < C::MP; ++m) {
             const int mt = wm * C::MP + m;
             const int oy = tileY * C::TH + mt / C::TWT;
             const int ox = tileX * C::TW + (mt % C::TWT) * 16 + (lane >> 4) * 4;
             if (oy >= a.Hout || ox >= a.Wout) continue;
-            if (!a.pool) {
-                epi_store(a, b, co, oy, ox, epi_finish(a, b, co, oy, ox, acc[m][n]));
-            } else if (((m / C::TWT) & 1) == 0 && m + C::TWT < C::MP && oy + 1 < a.Hout) {
-                epi_store_pooled(a, b, co, oy, ox, epi_finish(a, b, co, oy, ox, acc[m][n]),
-                                 epi_finish(a, b, co, oy + 1, ox, acc[(m + C::TWT) % C::MP][n]));
+            const bool pool_top = a.pool && ((m / C::TWT) & 1) == 0 && m + C::TWT < C::MP && oy + 1 < a.Hout;
+            if (a.pool && !pool_top) continue;
+            ResTaps t0, t1;
+            if (res_lds) {
+                t0 = res_taps(a, rw, oy, ox);
+                if (pool_top) t1 = res_taps(a, rw, oy + 1, ox);
             }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = (tile0 + n) * 16 + (lane & 15);
+                if (co >= a.Cout) continue;
+                const lds_float *chan = res_lds ? res_lds + (n * 16 + (lane & 15)) * rw.cs : nullptr;
+                const f32x4 top = epi_finish(a, b, co, oy, ox, acc[m][n], biasv[n], chan, &t0);
+                if (!a.pool) epi_store(a, b, co, oy, ox, top);
+                else epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, acc[(m + C::TWT) % C::MP][n], biasv[n], chan, &t1));
+            }
+            DPROBE(5 + m);
         }
     }
+    DPROBE(4);
 #endif
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int KS, int STRIDE, int WM, int WK, int NT>
-static int launch_dma_cfg(const ConvArgs &a0, int B, hipStream_t s) {
+template <int KS, int STRIDE, int WM, int WK, int NT, int EPI>
+static int launch_dma_epi(const ConvArgs &a0, int B, hipStream_t s) {
     using C = DmaCfg<KS, STRIDE, WM, WK, NT>;
     ConvArgs a = a0;
     a.tilesX = (a.Wout + C::TW - 1) / C::TW;
     a.tilesY = (a.Hout + C::TH - 1) / C::TH;
-    const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_dma_kernel<KS, STRIDE, WM, WK, NT>),
+    size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    a.res_lds_off = -1;
+    if (a.res) {   // staged residual window lives behind the K-split partial sums
+        const size_t need = (size_t)C::RED + (size_t)NT * 16 * res_chan_stride(res_extent(C::TH, a.res_sh), res_extent(C::TW, a.res_sw));
+        static const bool res_global = getenv("PF_RES_GLOBAL") != nullptr;   // debugging: sample the residual from memory
+        if (need * sizeof(float) <= 64 * 1024 && !res_global) {
+            a.res_lds_off = C::RED;
+            if (need * sizeof(float) > lds) lds = need * sizeof(float);
+        }
+    }
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_lds = lds;
     }
     char label[96];
     snprintf(label, sizeof(label), "void pf::conv_dma_kernel<%d, %d, %d, %d, %d>(pf::ConvArgs)", KS, STRIDE, WM, WK, NT);
+    if (a.res) strncat(label, " +res", sizeof(label) - strlen(label) - 1);
+    if (a.pool) strncat(label, " +pool", sizeof(label) - strlen(label) - 1);
+    if (a.no_bias) strncat(label, " lowres-half", sizeof(label) - strlen(label) - 1);
     const double px = (double)B * a.Hout * a.Wout;
     ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * KS * KS,
                  4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * KS * KS));
-    hipLaunchKernelGGL((conv_dma_kernel<KS, STRIDE, WM, WK, NT>),
+    hipLaunchKernelGGL((conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI>),
                        dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(64 * WM * WK), lds, s, a);
     PF_LAUNCH_CHECK("conv_dma_kernel");
     return PF_OK;
+}
+
+template <int KS, int STRIDE, int WM, int WK, int NT>
+static int launch_dma_cfg(const ConvArgs &a, int B, hipStream_t s) {
+    if (a.pool || a.res || a.no_bias) {
+        if (KS == 1 && STRIDE == 1) return launch_dma_epi<KS, STRIDE, WM, WK, NT, (KS == 1 && STRIDE == 1) ? 1 : 0>(a, B, s);
+        return fail(PF_EUNSUPPORTED, "conv_dma: fused epilogue stages are built for 1x1 convs only");
+    }
+    return launch_dma_epi<KS, STRIDE, WM, WK, NT, 0>(a, B, s);
 }
 
 // Cost model (shader cycles) for one (WM, WK, NT) shape: the larger of the chip-wide MFMA time and the serial

@@ -14,6 +14,7 @@ namespace pf {
 
 typedef float epi_f32x4 __attribute__((ext_vector_type(4)));
 typedef float epi_f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) float lds_float;   // explicit LDS pointers: ds_read, not flat loads
 
 // align_corners=True source index (ATen area_pixel_compute_scale / compute_source_index)
 __device__ __forceinline__ void lin_coord(int o, float scale, int in_size, int &i0, int &i1, float &l0, float &l1) {
@@ -24,25 +25,109 @@ __device__ __forceinline__ void lin_coord(int o, float scale, int in_size, int &
     l0 = 1.f - l1;
 }
 
-// raw accumulator sums of (oy, ox..ox+3, co) -> finished activations
-__device__ __forceinline__ epi_f32x4 epi_finish(const ConvArgs &a, int b, int co, int oy, int ox, epi_f32x4 v) {
-    const float bias = a.no_bias ? 0.f : a.bias[co];
+// ---- residual staged in LDS ---------------------------------------------------------------------------------------
+// The residual tensor is sampled 16 times per output fragment; gathered straight from memory that is 16 uncoalesced
+// loads per lane per fragment and costs more than the upsample pass it replaces.  Instead the workgroup copies the
+// source window of its output tile ([channels of the tile][rows][cols], a few KB) into LDS once, coalesced, and the
+// lanes sample from there.  Channel stride is odd so the 16 channels of a fragment column hit 16 different banks.
+
+// upper bound of source rows (cols) touched by n_out consecutive output rows (cols) at `scale` (host + device)
+__host__ __device__ inline int res_extent(int n_out, float scale) { return (int)(scale * (float)(n_out - 1)) + 3; }
+__host__ __device__ inline int res_chan_stride(int rows, int cols) { return (rows * cols) | 1; }
+
+struct ResWin {
+    int sy0, sx0, rows, cols, cs;   // window origin in the residual tensor, its size, channel stride (floats)
+};
+
+// window = every (y0, y0+1) x (x0, x0+1) tap pair of the tile; rows/cols past the tensor edge are staged as copies
+// of the edge (their interpolation weight is 0 up to rounding, exactly like the clamped index of lin_coord)
+__device__ __forceinline__ ResWin res_window(const ConvArgs &a, int oy0, int th, int ox0, int tw) {
+    ResWin w;
+    const int oy1 = min(oy0 + th, a.Hout) - 1, ox1 = min(ox0 + tw, a.Wout) - 1;
+    w.sy0 = min((int)(a.res_sh * (float)oy0), a.Hres - 1);
+    w.sx0 = min((int)(a.res_sw * (float)ox0), a.Wres - 1);
+    w.rows = min((int)(a.res_sh * (float)oy1), a.Hres - 1) + 2 - w.sy0;
+    w.cols = min((int)(a.res_sw * (float)ox1), a.Wres - 1) + 2 - w.sx0;
+    w.cs = res_chan_stride(w.rows, w.cols);
+    return w;
+}
+
+// all `nthr` threads of the workgroup: channels [co0, co0+nco) of the window -> lds[c*cs + r*cols + x]
+__device__ __forceinline__ void res_stage(const ConvArgs &a, const ResWin &w, int b, int co0, int nco, lds_float *lds,
+                                          int tid, int nthr) {
+    const int per = w.rows * w.cols;
+    const size_t plane = (size_t)a.Hres * a.Wres;
+    const float *base = a.res + ((size_t)b * a.res_ctotal + a.res_choff + co0) * plane;
+    for (int e0 = 0; e0 < per; e0 += 64) {            // a wave walks whole channels: lanes = window elements
+        const int e = e0 + (tid & 63);
+        const int r = e / w.cols, x = e - r * w.cols;
+        const size_t off = (size_t)min(w.sy0 + r, a.Hres - 1) * a.Wres + min(w.sx0 + x, a.Wres - 1);
+        for (int c = tid >> 6; c < nco; c += nthr >> 6)
+            if (e < per && co0 + c < a.Cout) lds[c * w.cs + e] = base[(size_t)c * plane + off];
+    }
+}
+
+// interpolation taps of the 4 pixels (oy, ox..ox+3) inside the staged window: shared by every channel of the tile
+struct ResTaps {
+    int o0[4], o1[4];     // float offsets (from the channel's base) of the (y0, x0) and (y1, x0) taps; x1 = x0 + 1
+    float lx1[4], hy1;
+};
+__device__ __forceinline__ ResTaps res_taps(const ConvArgs &a, const ResWin &w, int oy, int ox) {
+    ResTaps t;
+    int y0, y1;
+    float hy0;
+    lin_coord(oy, a.res_sh, a.Hres, y0, y1, hy0, t.hy1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int x0, x1;
+        float lx0;
+        lin_coord(min(ox + r, a.Wout - 1), a.res_sw, a.Wres, x0, x1, lx0, t.lx1[r]);
+        t.o0[r] = (y0 - w.sy0) * w.cols + (x0 - w.sx0);
+        t.o1[r] = (y1 - w.sy0) * w.cols + (x0 - w.sx0);
+    }
+    return t;
+}
+__device__ __forceinline__ epi_f32x4 res_apply(const lds_float *chan, const ResTaps &t, epi_f32x4 v) {
+    const float hy0 = 1.f - t.hy1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float lx0 = 1.f - t.lx1[r];
+        const float t0 = lx0 * chan[t.o0[r]] + t.lx1[r] * chan[t.o0[r] + 1];
+        const float t1 = lx0 * chan[t.o1[r]] + t.lx1[r] * chan[t.o1[r] + 1];
+        v[r] += hy0 * t0 + t.hy1 * t1;
+    }
+    return v;
+}
+
+// raw accumulator sums of (oy, ox..ox+3, co) -> finished activations.  chan/taps: this channel's staged residual
+// window and the pixel group's taps (or chan == nullptr: sample the residual from memory)
+// `bias` is loaded by the caller BEFORE its main loop (epi_bias): fetched here it is a cold, dependent global load
+// at the very end of every workgroup - measured at 8-9 us of a 25 us workgroup in conv_dma (tools/probe).
+__device__ __forceinline__ float epi_bias(const ConvArgs &a, int co) {
+    return (a.no_bias || co >= a.Cout) ? 0.f : a.bias[co];
+}
+__device__ __forceinline__ epi_f32x4 epi_finish(const ConvArgs &a, int b, int co, int oy, int ox, epi_f32x4 v, float bias,
+                                                const lds_float *chan = nullptr, const ResTaps *taps = nullptr) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] += bias;
     if (a.res) {
-        const float *s = a.res + ((size_t)b * a.res_ctotal + a.res_choff + co) * ((size_t)a.Hres * a.Wres);
-        int y0, y1;
-        float hy0, hy1;
-        lin_coord(oy, a.res_sh, a.Hres, y0, y1, hy0, hy1);
-        const float *r0 = s + (size_t)y0 * a.Wres, *r1 = s + (size_t)y1 * a.Wres;
+        if (chan) {
+            v = res_apply(chan, *taps, v);
+        } else {
+            int y0, y1;
+            float hy0, hy1;
+            lin_coord(oy, a.res_sh, a.Hres, y0, y1, hy0, hy1);
+            const float *s = a.res + ((size_t)b * a.res_ctotal + a.res_choff + co) * ((size_t)a.Hres * a.Wres);
+            const float *r0 = s + (size_t)y0 * a.Wres, *r1 = s + (size_t)y1 * a.Wres;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int x0, x1;
-            float lx0, lx1;
-            lin_coord(ox + r, a.res_sw, a.Wres, x0, x1, lx0, lx1);
-            const float t0 = lx0 * r0[x0] + lx1 * r0[x1];
-            const float t1 = lx0 * r1[x0] + lx1 * r1[x1];
-            v[r] += hy0 * t0 + hy1 * t1;
+            for (int r = 0; r < 4; ++r) {
+                int x0, x1;
+                float lx0, lx1;
+                lin_coord(ox + r, a.res_sw, a.Wres, x0, x1, lx0, lx1);
+                const float t0 = lx0 * r0[x0] + lx1 * r0[x1];
+                const float t1 = lx0 * r1[x0] + lx1 * r1[x1];
+                v[r] += hy0 * t0 + hy1 * t1;
+            }
         }
     }
     if (a.relu) {

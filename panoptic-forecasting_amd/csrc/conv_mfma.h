@@ -34,6 +34,7 @@ struct ConvArgs {
     const float *res;        // residual [B, res_ctotal, Hres, Wres], bilinearly upsampled (align_corners) and added
     int res_ctotal, res_choff, Hres, Wres;
     float res_sh, res_sw;    // (Hres-1)/(Hout-1), (Wres-1)/(Wout-1)
+    int res_lds_off;         // float offset of the staged residual window in the kernel's LDS, or -1: sample from memory
     int src_begin, src_end;      // input ranges to accumulate (whole conv: 0, n_src)
     int chunk_begin, chunk_end;  // = src_chunk0[src_begin], src_chunk0[src_end] (filled at launch)
     long long *probe;        // PF_PROBE builds only: in-kernel timestamps of workgroup 0 / wave 0 (else nullptr)

@@ -67,6 +67,7 @@ long long *probe_buffer() {
     if (!g_probe_dev) {
         if (hipMalloc((void **)&g_probe_dev, 64 * sizeof(long long)) != hipSuccess) return nullptr;
         (void)hipMemset(g_probe_dev, 0, 64 * sizeof(long long));
+        (void)hipMemset(g_probe_dev + 60, 0xFF, sizeof(long long));
     }
     return g_probe_dev;
 }
@@ -77,6 +78,7 @@ extern "C" int pf_debug_probe_read(long long *host64) {
     if (!g_probe_dev) return PF_EINVAL;
     if (hipMemcpy(host64, g_probe_dev, 64 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return PF_EHIP;
     (void)hipMemset(g_probe_dev, 0, 64 * sizeof(long long));
+    (void)hipMemset(g_probe_dev + 60, 0xFF, sizeof(long long));   // slot 60 is an atomicMin target
     return PF_OK;
 }
 

@@ -12,6 +12,8 @@
 //   * the weights of a chunk go L2 -> VGPR directly (fragment order, one dwordx4 per 4 MFMAs): no LDS space,
 //     no ds_read for the B operand, so 16-32 waves fit a CU;
 //   * small tiles (MH = 1 or 2) keep >= 1 wave per SIMD even for a 16x32 image.
+#include <cstring>
+
 #include "conv_epilogue.h"
 #include "pf_prof.h"
 
@@ -73,7 +75,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base) {
 }
 #endif
 
-template <int KS, int MH, int NT, int WK>
+// EPI: 0 = bias + ReLU, 1 = fused stages of conv_epilogue.h (separate instantiations: register budget)
+template <int KS, int MH, int NT, int WK, int EPI>
 __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only builtin types; the host pass only needs the stub
     using C = WaveCfg<KS, MH, NT, WK>;
@@ -144,6 +147,10 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
             if (C::NR) w[n].r = *reinterpret_cast<const f32x2 *>(wp + C::NQ * 256 + lane * 2);
         }
     };
+
+    float biasv[NT];   // fetched now, used in the epilogue: the latency hides behind the main loop
+#pragma unroll
+    for (int n = 0; n < NT; ++n) biasv[n] = epi_bias(a, (tile0 + n) * 16 + (lane & 15));
 
     f32x4 acc[MH][NT][C::NA];
 #pragma unroll
@@ -224,11 +231,18 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
             if (C::NA == 2) v += acc[m][n][C::NA - 1];
             red[((m * NT + n) * WK + wk) * 64 + lane] = v;
         }
+    ResWin rw = ResWin();
+    const lds_float *res_lds = nullptr;
+    if (EPI == 1 && a.res && a.res_lds_off >= 0) {   // residual window of this tile -> LDS behind the partial sums
+        rw = res_window(a, oy0, MH, ox0, 16);
+        res_stage(a, rw, b, tile0 * 16, NT * 16, (lds_float *)(smem + a.res_lds_off), threadIdx.x, 64 * WK);
+        res_lds = (const lds_float *)(smem + a.res_lds_off);
+    }
     __syncthreads();
     PROBE();
 
     // unit = one output fragment (or, when pooling, the fragments of rows m, m+1): summed and finished by one wave
-    const int rows = a.pool ? 2 : 1;
+    const int rows = (EPI == 1 && a.pool) ? 2 : 1;
 #pragma unroll
     for (int u = 0; u < MH * NT; ++u) {
         if (u % WK != wk || u >= (MH / rows) * NT) continue;
@@ -243,40 +257,77 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
             for (int k = 1; k < WK; ++k) v += red[(mn * WK + k) * 64 + lane];
             return v;
         };
-        const f32x4 top = epi_finish(a, b, co, oy, ox, total(m));
-        if (a.pool) {
-            if (MH > 1 && oy + 1 < a.Hout) epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, total(MH > 1 ? m + 1 : m)));
+        if (EPI == 0) {
+            f32x4 v = total(m);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] += biasv[n];
+                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            epi_store(a, b, co, oy, ox, v);
         } else {
-            epi_store(a, b, co, oy, ox, top);
+            const lds_float *chan = res_lds ? res_lds + (n * 16 + (lane & 15)) * rw.cs : nullptr;
+            ResTaps t0, t1;
+            if (res_lds) {
+                t0 = res_taps(a, rw, oy, ox);
+                if (a.pool && oy + 1 < a.Hout) t1 = res_taps(a, rw, oy + 1, ox);
+            }
+            const f32x4 top = epi_finish(a, b, co, oy, ox, total(m), biasv[n], chan, &t0);
+            if (a.pool) {
+                if (MH > 1 && oy + 1 < a.Hout)
+                    epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, total(MH > 1 ? m + 1 : m), biasv[n], chan, &t1));
+            } else {
+                epi_store(a, b, co, oy, ox, top);
+            }
         }
     }
 #endif
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int KS, int MH, int NT, int WK>
-static int launch_wave_cfg(const ConvArgs &a0, int B, hipStream_t s) {
+template <int KS, int MH, int NT, int WK, int EPI>
+static int launch_wave_epi(const ConvArgs &a0, int B, hipStream_t s) {
     using C = WaveCfg<KS, MH, NT, WK>;
     ConvArgs a = a0;
     a.tilesX = (a.Wout + 15) / 16;
     a.tilesY = (a.Hout + MH - 1) / MH;
-    const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
     if (lds > 64 * 1024) return fail(PF_EUNSUPPORTED, "conv_wave<%d,%d,%d,%d>: %zu B of LDS", KS, MH, NT, WK, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wave_kernel<KS, MH, NT, WK>),
+    a.res_lds_off = -1;
+    if (a.res) {   // staged residual window lives behind the K-split partial sums
+        const size_t need = (size_t)C::RED + (size_t)NT * 16 * res_chan_stride(res_extent(MH, a.res_sh), res_extent(16, a.res_sw));
+        if (need * sizeof(float) <= 64 * 1024) {
+            a.res_lds_off = C::RED;
+            if (need * sizeof(float) > lds) lds = need * sizeof(float);
+        }
+    }
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wave_kernel<KS, MH, NT, WK, EPI>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_lds = lds;
     }
     char label[96];
     snprintf(label, sizeof(label), "void pf::conv_wave_kernel<%d, %d, %d, %d>(pf::ConvArgs)", KS, MH, NT, WK);
+    if (a.res) strncat(label, " +res", sizeof(label) - strlen(label) - 1);
+    if (a.pool) strncat(label, " +pool", sizeof(label) - strlen(label) - 1);
+    if (a.no_bias) strncat(label, " lowres-half", sizeof(label) - strlen(label) - 1);
     const double px = (double)B * a.Hout * a.Wout;
     ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * KS * KS,
                  4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * KS * KS));
-    hipLaunchKernelGGL((conv_wave_kernel<KS, MH, NT, WK>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B),
+    hipLaunchKernelGGL((conv_wave_kernel<KS, MH, NT, WK, EPI>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B),
                        dim3(64 * WK), lds, s, a);
     PF_LAUNCH_CHECK("conv_wave_kernel");
     return PF_OK;
+}
+
+template <int KS, int MH, int NT, int WK>
+static int launch_wave_cfg(const ConvArgs &a, int B, hipStream_t s) {
+    if (a.pool || a.res || a.no_bias) {
+        if (KS == 1) return launch_wave_epi<KS, MH, NT, WK, KS == 1 ? 1 : 0>(a, B, s);
+        return fail(PF_EUNSUPPORTED, "conv_wave: fused epilogue stages are built for 1x1 convs only");
+    }
+    return launch_wave_epi<KS, MH, NT, WK, 0>(a, B, s);
 }
 
 int launch_conv_wave(const ConvArgs &a, int ks, int mh, int nt, int wk, int B, hipStream_t s) {

@@ -20,6 +20,7 @@ struct ConvPlan {
     size_t wpk_off = 0;   // floats into dev_weights
     size_t bias_off = 0;  // floats (padded to 16*n_tiles)
     size_t raw_off = 0;   // folded OIHW copy (stem only)
+    size_t dep_off = 0;   // stem only: depth-channel columns [tap][t][16]
     size_t tiled_off = 0; // per-cout-tile packing for the DMA fast path
     int tiled_chunks = 0;
     size_t wave_off = 0;  // fragment-order packing for the wave-autonomous path (stride 1 only)
@@ -203,7 +204,12 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                (in.w & 3) == 0 && (out.w & 3) == 0 && n.cout <= p->tensors[o.dst].channels;
     };
 
+    static const bool sync_ops = getenv("PF_SYNC_OPS") != nullptr;   // debugging: localise a faulting launch
     for (size_t i = 0; i < p->ops.size(); ++i) {
+        if (sync_ops) {
+            const hipError_t e = hipStreamSynchronize(s);
+            fprintf(stderr, "[pf] before op %zu (%s): %s\n", i, p->tensors[p->ops[i].dst].name, hipGetErrorString(e));
+        }
         const BlobOp &o = p->ops[i];
         const Dims in = d[o.src[0].tensor];
         const Dims out = o.kind == OP_HEAD ? in : d[o.dst];
@@ -215,6 +221,9 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         if (o.kind == OP_STEM && stem) {
             StemArgs a = *stem;
             a.w = p->dev_weights + p->conv[i].raw_off;
+            a.wdep = p->dev_weights + p->conv[i].dep_off;
+            a.probe = getenv("PF_PROBE") ? probe_buffer() : nullptr;
+            a.dbg_plane_pad = getenv("PF_DBG_PLANE_PAD") ? atoi(getenv("PF_DBG_PLANE_PAD")) : 0;
             a.bias = p->dev_weights + p->conv[i].bias_off;
             a.lut = p->dev_lut;
             a.dst = tptr(o.dst);
@@ -230,7 +239,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                 return fail(PF_EINVAL, "network input is consumed by a generic conv: use pf_hardnet_forward_dense");
             // conv + AvgPool2d(2,2): pool in the conv epilogue, the full-resolution tensor is never written
             const BlobOp *pool = nullptr;
-            if (fuse && i + 1 < p->ops.size() && p->ops[i + 1].kind == OP_POOL && o.stride == 1 && (in.w & 3) == 0 &&
+            if (fuse && i + 1 < p->ops.size() && p->ops[i + 1].kind == OP_POOL && o.stride == 1 && o.k == 1 && (in.w & 3) == 0 &&
                 p->ops[i + 1].src[0].tensor == o.dst && o.dst_choff == 0 && o.cout == p->tensors[o.dst].channels &&
                 p->readers[o.dst] == 1 && out.h >= 2 && out.w >= 2)
                 pool = &p->ops[i + 1];
@@ -263,6 +272,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             lo.src_begin = 0;
             lo.src_end = 1;
             if ((rc = launch_conv_op(n, i + 1, lo, 4))) return rc;
+            if (sync_ops) fprintf(stderr, "[pf]   low-resolution half: %s\n", hipGetErrorString(hipStreamSynchronize(s)));
             ConvArgs hi_a;
             fill_conv_args(n, i + 1, hi, hi, hi_a);
             hi_a.Cin = (int)n.src[1].ch;
@@ -373,6 +383,16 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
         if (o.kind == OP_STEM) {
             c.raw_off = host.size();
             host.insert(host.end(), wts + o.w_off, wts + o.w_off + (size_t)o.cout * o.cin * o.k * o.k);
+            // depth channels are the last T of the T*(n_cls+1) inputs (bg_model.py:68-69)
+            const int T = (int)o.cin / ((int)h.n_cls + 1), ks2 = (int)(o.k * o.k);
+            if (T >= 1 && (uint32_t)(T * ((int)h.n_cls + 1)) == o.cin && o.cout == 16) {
+                host.resize(align_up(host.size(), 16), 0.f);
+                c.dep_off = host.size();
+                for (int tap = 0; tap < ks2; ++tap)
+                    for (int t = 0; t < T; ++t)
+                        for (int co = 0; co < 16; ++co)
+                            host.push_back(wts[o.w_off + ((size_t)co * o.cin + T * h.n_cls + t) * ks2 + tap]);
+            }
         }
         host.resize(align_up(host.size(), 64), 0.f);
     }

@@ -11,11 +11,14 @@ struct StemArgs {
     const float *depth;    // [B,T,H,W]
     const uint8_t *mask;   // [B,T,H,W] (ignored with PF_HOP_DEPTH_U16)
     const float *w;        // folded OIHW [16][T*(n_cls+1)][3][3]
+    const float *wdep;     // depth-channel columns re-packed [tap][t][16] (uniform 64-B rows for scalar loads)
     const float *bias;     // [16]
     const uint8_t *lut;    // [256] id -> trainId (device)
     float *dst;            // [B,16,Hout,Wout]
     float depth_mean, depth_std, min_depth, max_depth;
     int seg_is_i64, hop, B, T, n_cls, H, W, Hout, Wout;
+    long long *probe;      // PF_PROBE builds only
+    int dbg_plane_pad;     // timing experiment only (PF_DBG_PLANE_PAD): extra floats between output planes
 };
 
 struct HeadArgs {

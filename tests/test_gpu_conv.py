@@ -141,10 +141,13 @@ def fuse_upsample():
     L.pf_set_option(b'fuse_upsample', 0)
 
 
+@pytest.mark.parametrize('force', [(0, 0, 0, 0), (1, 4, 2, 0), (1, 2, 1, 0), (1, 1, 2, 0), (2, 2, 2, 2), (2, 4, 1, 4)],
+                         ids=lambda f: 'k%d_%d_%d_%d' % f)
 @pytest.mark.parametrize('h,w,b', [(32, 64, 1), (20, 40, 2), (34, 52, 1)])
-def test_fused_pool_and_commuted_upsample(h, w, b, fuse_upsample):
+def test_fused_pool_and_commuted_upsample(h, w, b, force, fuse_upsample, force_conv):
     """The executor's fused stages (conv_epilogue.h): 1x1 conv + AvgPool2d in one launch, and
-    TransitionUp + 1x1 conv over cat([up(x), skip]) evaluated as W_skip*skip + up(W_x*x)."""
+    TransitionUp + 1x1 conv over cat([up(x), skip]) evaluated as W_skip*skip + up(W_x*x), with the residual window
+    staged in LDS - through both conv kernels (forced shapes)."""
     from helpers import MiniNet, MiniSpec
     from panoptic_forecasting_amd import hardnet_arch as arch
     g = torch.Generator().manual_seed(h * 7 + w)
@@ -153,12 +156,13 @@ def test_fused_pool_and_commuted_upsample(h, w, b, fuse_upsample):
     c1 = spec.conv('c1', [arch.Src(0, 0, 12)], 20, 3)
     c2 = spec.conv('c2', [arch.Src(c1, 0, 20)], 24, 1)
     p = spec.pool('p', c2)
-    c3 = spec.conv('c3', [arch.Src(p, 0, 24)], 16, 3)
+    c3 = spec.conv('c3', [arch.Src(p, 0, 24)], 40, 3)          # 40 >= 37: the commuted form is legal (cout <= cin_up)
     up = spec.upsample('up', c3, c1)
-    spec.conv('c4', [arch.Src(up, 0, 16), arch.Src(c1, 0, 20)], 18, 1)
+    spec.conv('c4', [arch.Src(up, 0, 40), arch.Src(c1, 0, 20)], 37, 1)
     P = {}
-    for name, cin, cout, k in [('c1', 12, 20, 3), ('c2', 20, 24, 1), ('c3', 24, 16, 3), ('c4', 36, 18, 1)]:
+    for name, cin, cout, k in [('c1', 12, 20, 3), ('c2', 20, 24, 1), ('c3', 24, 40, 3), ('c4', 60, 37, 1)]:
         P[name] = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.randn(cout, generator=g))
+    force_conv(*force)
     net = MiniNet(spec, P).run(x.cuda())
     r1 = F.relu(F.conv2d(x, *P['c1'], padding=1))
     r2 = F.relu(F.conv2d(r1, *P['c2']))

@@ -20,6 +20,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=1)
 ap.add_argument('--steps', type=int, default=5)
 args = ap.parse_args()
+for kv in filter(None, os.environ.get('PF_OPTS', '').split(',')):
+    k, v = kv.split('=')
+    pflib.check(pflib.load().pf_set_option(k.encode(), int(v)), 'pf_set_option')
 model = build_model(bench.model_params())
 model.load_state_dict(bench.calibrated_state_dict())
 batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
@@ -39,5 +42,5 @@ for r in recs:
     ms = r['ms'] / args.steps
     k, _, tag = r['label'].partition(' @')
     k = k.replace('void pf::', '').replace('(pf::ConvArgs)', '').replace('pf::', '')
-    print('%-44s %-34s %8.1f us %7.1f TF/s %8.0f GB/s' % (tag[:44], k[:34], ms * 1e3, r['flops'] / args.steps / max(ms, 1e-9) / 1e9,
+    print('%-44s %-52s %8.1f us %7.1f TF/s %8.0f GB/s' % (tag[:44], k[:52], ms * 1e3, r['flops'] / args.steps / max(ms, 1e-9) / 1e9,
                                                           r['bytes'] / args.steps / max(ms, 1e-9) / 1e6))
