@@ -113,7 +113,7 @@ int pf_hardnet_forward_dense(const pf_plan *plan, const float *x, int B, int H, 
 
 /* Process-wide execution options (not thread-safe; set before launching work):
  *   "fuse_pool"     (default 1) a 1x1 conv followed by AvgPool2d(2,2) (hardnet.py:296) pools in the conv epilogue;
- *   "fuse_upsample" (default 0) TransitionUp + 1x1 conv over cat([up(x), skip]) (hardnet.py:248-258,365-368) is
+ *   "fuse_upsample" (default 1) TransitionUp + 1x1 conv over cat([up(x), skip]) (hardnet.py:248-258,365-368) is
  *                   evaluated as W_skip*skip + up(W_x*x): same result up to fp32 rounding, no upsampled tensor;
  *   "use_tuned_table" (default 1) per-layer kernel shapes come from the measured table (csrc/conv_tuned.inc) where it
  *                   has the shape, else from the cost model; 0 = cost model only (tools/tune_convs.py). */

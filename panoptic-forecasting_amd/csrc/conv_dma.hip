@@ -198,7 +198,8 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
     // ---- residual window of this tile -> LDS (all waves, before the K-split partners leave)
     ResWin rw = ResWin();
     const lds_float *res_lds = nullptr;
-    if (EPI == 1 && a.res && a.res_lds_off >= 0) {
+    const bool has_res = EPI == 1 && a.res && a.res_lds_off >= 0;
+    if (has_res) {
         rw = res_window(a, tileY * C::TH, C::TH, tileX * C::TW, C::TW);
         res_stage(a, rw, b, tile0 * 16, NT * 16, (lds_float *)(smem + a.res_lds_off), tid, NTHR);
         res_lds = (const lds_float *)(smem + a.res_lds_off);
@@ -250,29 +251,34 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
             }
         }
     } else {
+        // The pixel coordinates are laundered through an empty asm so that hipcc cannot hoist the (loop-invariant)
+        // interpolation taps of all MP pixel groups above the main loop, where they cost ~100 live VGPRs (occupancy).
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
         // ---- fused epilogue (conv_epilogue.h): bias, residual, ReLU, optional 2x2 pool (rows ty, ty+1 = M-tiles
         //      m, m+TWT).  Pixel-group outer, channels inner: the residual taps are computed once for all NT tiles.
 #pragma unroll
         for (int m = 0; m < C::MP; ++m) {
             const int mt = wm * C::MP + m;
             const int oy = tileY * C::TH + mt / C::TWT;
-            const int ox = tileX * C::TW + (mt % C::TWT) * 16 + (lane >> 4) * 4;
+            const int ox = tileX * C::TW + (mt % C::TWT) * 16 + (lane_e >> 4) * 4;
             if (oy >= a.Hout || ox >= a.Wout) continue;
             const bool pool_top = a.pool && ((m / C::TWT) & 1) == 0 && m + C::TWT < C::MP && oy + 1 < a.Hout;
             if (a.pool && !pool_top) continue;
             ResTaps t0, t1;
-            if (res_lds) {
+            if (has_res) {
                 t0 = res_taps(a, rw, oy, ox);
                 if (pool_top) t1 = res_taps(a, rw, oy + 1, ox);
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const int co = (tile0 + n) * 16 + (lane & 15);
+                const int co = (tile0 + n) * 16 + (lane_e & 15);
                 if (co >= a.Cout) continue;
-                const lds_float *chan = res_lds ? res_lds + (n * 16 + (lane & 15)) * rw.cs : nullptr;
-                const f32x4 top = epi_finish(a, b, co, oy, ox, acc[m][n], biasv[n], chan, &t0);
+                const lds_float *chan = res_lds + (n * 16 + (lane_e & 15)) * rw.cs;
+                const f32x4 top = epi_finish(a, b, co, oy, ox, acc[m][n], biasv[n], has_res, chan, &t0);
                 if (!a.pool) epi_store(a, b, co, oy, ox, top);
-                else epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, acc[(m + C::TWT) % C::MP][n], biasv[n], chan, &t1));
+                else epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, acc[(m + C::TWT) % C::MP][n], biasv[n], has_res, chan, &t1));
+                __builtin_amdgcn_sched_barrier(0);   // one fragment at a time: interleaving them costs ~100 VGPRs (occupancy)
             }
             DPROBE(5 + m);
         }
@@ -292,11 +298,9 @@ static int launch_dma_epi(const ConvArgs &a0, int B, hipStream_t s) {
     a.res_lds_off = -1;
     if (a.res) {   // staged residual window lives behind the K-split partial sums
         const size_t need = (size_t)C::RED + (size_t)NT * 16 * res_chan_stride(res_extent(C::TH, a.res_sh), res_extent(C::TW, a.res_sw));
-        static const bool res_global = getenv("PF_RES_GLOBAL") != nullptr;   // debugging: sample the residual from memory
-        if (need * sizeof(float) <= 64 * 1024 && !res_global) {
-            a.res_lds_off = C::RED;
-            if (need * sizeof(float) > lds) lds = need * sizeof(float);
-        }
+        if (need * sizeof(float) > 64 * 1024) return fail(PF_EUNSUPPORTED, "residual window of %zu B does not fit LDS", need * sizeof(float));
+        a.res_lds_off = C::RED;
+        if (need * sizeof(float) > lds) lds = need * sizeof(float);
     }
     static size_t attr_lds = 0;
     if (lds > attr_lds) {

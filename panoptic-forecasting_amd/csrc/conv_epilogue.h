@@ -62,6 +62,7 @@ __device__ __forceinline__ void res_stage(const ConvArgs &a, const ResWin &w, in
         const int e = e0 + (tid & 63);
         const int r = e / w.cols, x = e - r * w.cols;
         const size_t off = (size_t)min(w.sy0 + r, a.Hres - 1) * a.Wres + min(w.sx0 + x, a.Wres - 1);
+#pragma unroll 4
         for (int c = tid >> 6; c < nco; c += nthr >> 6)
             if (e < per && co0 + c < a.Cout) lds[c * w.cs + e] = base[(size_t)c * plane + off];
     }
@@ -100,36 +101,20 @@ __device__ __forceinline__ epi_f32x4 res_apply(const lds_float *chan, const ResT
 }
 
 // raw accumulator sums of (oy, ox..ox+3, co) -> finished activations.  chan/taps: this channel's staged residual
-// window and the pixel group's taps (or chan == nullptr: sample the residual from memory)
+// window and the pixel group's taps (nullptr: no residual)
 // `bias` is loaded by the caller BEFORE its main loop (epi_bias): fetched here it is a cold, dependent global load
 // at the very end of every workgroup - measured at 8-9 us of a 25 us workgroup in conv_dma (tools/probe).
 __device__ __forceinline__ float epi_bias(const ConvArgs &a, int co) {
     return (a.no_bias || co >= a.Cout) ? 0.f : a.bias[co];
 }
 __device__ __forceinline__ epi_f32x4 epi_finish(const ConvArgs &a, int b, int co, int oy, int ox, epi_f32x4 v, float bias,
-                                                const lds_float *chan = nullptr, const ResTaps *taps = nullptr) {
+                                                bool has_res = false, const lds_float *chan = nullptr, const ResTaps *taps = nullptr) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] += bias;
-    if (a.res) {
-        if (chan) {
-            v = res_apply(chan, *taps, v);
-        } else {
-            int y0, y1;
-            float hy0, hy1;
-            lin_coord(oy, a.res_sh, a.Hres, y0, y1, hy0, hy1);
-            const float *s = a.res + ((size_t)b * a.res_ctotal + a.res_choff + co) * ((size_t)a.Hres * a.Wres);
-            const float *r0 = s + (size_t)y0 * a.Wres, *r1 = s + (size_t)y1 * a.Wres;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int x0, x1;
-                float lx0, lx1;
-                lin_coord(ox + r, a.res_sw, a.Wres, x0, x1, lx0, lx1);
-                const float t0 = lx0 * r0[x0] + lx1 * r0[x1];
-                const float t1 = lx0 * r1[x0] + lx1 * r1[x1];
-                v[r] += hy0 * t0 + hy1 * t1;
-            }
-        }
-    }
+    // (an explicit flag, not chan != nullptr: the window may sit at LDS address 0, which IS the null pointer there)
+    if (has_res) v = res_apply(chan, *taps, v);   // residual: always from the staged LDS window (the launchers refuse
+                                               // shapes whose window does not fit; a gather from memory here costs
+                                               // ~100 VGPRs of addresses and halves the occupancy of the whole kernel)
     if (a.relu) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);

@@ -233,7 +233,8 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
         }
     ResWin rw = ResWin();
     const lds_float *res_lds = nullptr;
-    if (EPI == 1 && a.res && a.res_lds_off >= 0) {   // residual window of this tile -> LDS behind the partial sums
+    const bool has_res = EPI == 1 && a.res && a.res_lds_off >= 0;
+    if (has_res) {   // residual window of this tile -> LDS behind the partial sums
         rw = res_window(a, oy0, MH, ox0, 16);
         res_stage(a, rw, b, tile0 * 16, NT * 16, (lds_float *)(smem + a.res_lds_off), threadIdx.x, 64 * WK);
         res_lds = (const lds_float *)(smem + a.res_lds_off);
@@ -241,20 +242,22 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
     __syncthreads();
     PROBE();
 
+    int lane_e = lane;   // laundered: keeps the epilogue's coordinate / tap arithmetic below the main loop (VGPR pressure)
+    asm volatile("" : "+v"(lane_e));
     // unit = one output fragment (or, when pooling, the fragments of rows m, m+1): summed and finished by one wave
     const int rows = (EPI == 1 && a.pool) ? 2 : 1;
 #pragma unroll
     for (int u = 0; u < MH * NT; ++u) {
         if (u % WK != wk || u >= (MH / rows) * NT) continue;
         const int m = (u / NT) * rows, n = u % NT;
-        const int co = (tile0 + n) * 16 + (lane & 15);
-        const int oy = oy0 + m, ox = ox0 + (lane >> 4) * 4;
+        const int co = (tile0 + n) * 16 + (lane_e & 15);
+        const int oy = oy0 + m, ox = ox0 + (lane_e >> 4) * 4;
         if (co >= a.Cout || oy >= a.Hout || ox >= a.Wout) continue;
         auto total = [&](int mm) {
             const int mn = mm * NT + n;
-            f32x4 v = red[(mn * WK) * 64 + lane];
+            f32x4 v = red[(mn * WK) * 64 + lane_e];
 #pragma unroll
-            for (int k = 1; k < WK; ++k) v += red[(mn * WK + k) * 64 + lane];
+            for (int k = 1; k < WK; ++k) v += red[(mn * WK + k) * 64 + lane_e];
             return v;
         };
         if (EPI == 0) {
@@ -266,19 +269,20 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
             }
             epi_store(a, b, co, oy, ox, v);
         } else {
-            const lds_float *chan = res_lds ? res_lds + (n * 16 + (lane & 15)) * rw.cs : nullptr;
+            const lds_float *chan = res_lds + (n * 16 + (lane_e & 15)) * rw.cs;
             ResTaps t0, t1;
-            if (res_lds) {
+            if (has_res) {
                 t0 = res_taps(a, rw, oy, ox);
                 if (a.pool && oy + 1 < a.Hout) t1 = res_taps(a, rw, oy + 1, ox);
             }
-            const f32x4 top = epi_finish(a, b, co, oy, ox, total(m), biasv[n], chan, &t0);
+            const f32x4 top = epi_finish(a, b, co, oy, ox, total(m), biasv[n], has_res, chan, &t0);
             if (a.pool) {
                 if (MH > 1 && oy + 1 < a.Hout)
-                    epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, total(MH > 1 ? m + 1 : m), biasv[n], chan, &t1));
+                    epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, total(MH > 1 ? m + 1 : m), biasv[n], has_res, chan, &t1));
             } else {
                 epi_store(a, b, co, oy, ox, top);
             }
+            __builtin_amdgcn_sched_barrier(0);   // one fragment at a time (register pressure)
         }
     }
 #endif
@@ -296,10 +300,9 @@ static int launch_wave_epi(const ConvArgs &a0, int B, hipStream_t s) {
     a.res_lds_off = -1;
     if (a.res) {   // staged residual window lives behind the K-split partial sums
         const size_t need = (size_t)C::RED + (size_t)NT * 16 * res_chan_stride(res_extent(MH, a.res_sh), res_extent(16, a.res_sw));
-        if (need * sizeof(float) <= 64 * 1024) {
-            a.res_lds_off = C::RED;
-            if (need * sizeof(float) > lds) lds = need * sizeof(float);
-        }
+        if (need * sizeof(float) > 64 * 1024) return fail(PF_EUNSUPPORTED, "residual window of %zu B does not fit LDS", need * sizeof(float));
+        a.res_lds_off = C::RED;
+        if (need * sizeof(float) > lds) lds = need * sizeof(float);
     }
     static size_t attr_lds = 0;
     if (lds > attr_lds) {

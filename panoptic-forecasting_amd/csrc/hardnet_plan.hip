@@ -39,7 +39,7 @@ struct pf_plan {
 };
 
 namespace pf {
-int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 0;
+int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1;
 extern int g_opt_use_tuned;
 }
 
@@ -192,16 +192,15 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         }
         return rc;
     };
-    // Opt-in (pf_set_option("fuse_upsample", 1)): correct and tested, but the per-lane bilinear gather of the residual in the epilogue
-    // (16 uncoalesced loads per fragment) currently costs more than the upsample pass it removes
-    // (gpurun_out/layers_b4f.txt: transUp.3 + conv1x1_up.3 281 us fused vs 233 us unfused at B=4).
+    // pf_set_option("fuse_upsample", 0/1); at B=4: transUp.3 + conv1x1_up.3 144 us fused vs 233 us as two passes
     const bool fuse_up = g_opt_fuse_upsample != 0;   // pf_set_option("fuse_upsample", 0/1)
     auto can_commute_upsample = [&](size_t i, const Dims &in, const Dims &out) -> bool {
         if (!fuse || !fuse_up || i + 1 >= p->ops.size()) return false;
         const BlobOp &o = p->ops[i], &n = p->ops[i + 1];
         return n.kind == OP_CONV && n.k == 1 && n.stride == 1 && n.n_src == 2 && n.src[0].tensor == o.dst &&
                n.src[0].choff == 0 && n.src[0].ch == p->tensors[o.dst].channels && p->readers[o.dst] == 1 &&
-               (in.w & 3) == 0 && (out.w & 3) == 0 && n.cout <= p->tensors[o.dst].channels;
+               (in.w & 3) == 0 && (out.w & 3) == 0 && n.cout <= p->tensors[o.dst].channels &&
+               2 * in.h <= out.h + 1 && 2 * in.w <= out.w + 1;   // >= ~2x upsampling: the residual window of a tile stays small
     };
 
     static const bool sync_ops = getenv("PF_SYNC_OPS") != nullptr;   // debugging: localise a faulting launch
@@ -271,6 +270,14 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             lo.Cin = (int)n.src[0].ch;
             lo.src_begin = 0;
             lo.src_end = 1;
+            auto tag_half = [&](const char *half, int cin, const Dims &dd) {
+                if (!(tag_ops && prof_enabled())) return;
+                char tag[96];
+                snprintf(tag, sizeof(tag), "%02zu%c %s.%s %d->%u %dx%d", i + 1, half[0] == 'l' ? 'a' : 'b', p->tensors[n.dst].name,
+                         half, cin, n.cout, dd.h, dd.w);
+                prof_set_tag(tag);
+            };
+            tag_half("lo", lo.Cin, in);
             if ((rc = launch_conv_op(n, i + 1, lo, 4))) return rc;
             if (sync_ops) fprintf(stderr, "[pf]   low-resolution half: %s\n", hipGetErrorString(hipStreamSynchronize(s)));
             ConvArgs hi_a;
@@ -278,6 +285,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             hi_a.Cin = (int)n.src[1].ch;
             hi_a.src_begin = 1;
             hi_a.src_end = 2;
+            tag_half("hi", hi_a.Cin, hi);
             hi_a.res = tptr(o.dst);
             hi_a.res_ctotal = (int)n.cout;
             hi_a.res_choff = 0;

@@ -15,188 +15,77 @@
 namespace pf {
 
 // ------------------------------------------------------------------------------------------------
-// Stem: one workgroup = 4 x 64 output pixels x 16 channels.
-//   stage 1  the 9 x 129 input window of each of the T frames is read ONCE, coalesced (16 B of depth, 4 B of labels
-//            per lane), turned into {class index or -1, normalised masked depth} (the hop emulation runs here, once
-//            per input pixel) and stored in LDS de-interleaved by column parity, so that stage 2's stride-2 window
-//            reads are consecutive across lanes (no bank conflicts);
-//   stage 2  one lane = one output pixel: per tap and frame one class byte + one depth float from LDS; the one-hot
-//            part is a 16-float weight row gathered from LDS (4 x ds_read_b128), the depth part is 16 FMAs whose
-//            weights come through the scalar cache (uniform address -> s_load, SGPR operands).
-// HBM traffic is the algorithmic minimum (inputs once, output once); profiles/r01_c had it at 5x that time.
-constexpr int kStemTH = 8, kStemTW = 64;   // 2 output rows per lane
-constexpr int kStemRows = 2 * kStemTH + 1;        // input rows per tile
-constexpr int kStemCols = kStemTW + 4;            // padded columns per parity (even: 64 used, odd: 65 used)
-constexpr int kStemRowF = 20;                     // floats between one-hot weight rows in LDS
-
-#ifndef PF_PROBE
-#define PF_PROBE 0
-#endif
-#if PF_PROBE
-#define SPROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == a.dbg_plane_pad % 100 && blockIdx.y == a.dbg_plane_pad / 100 && blockIdx.z == 0 && a.probe) { a.probe[i] = clock64(); a.probe[i + 8] = wall_clock64(); } } while (0)
-#else
-#define SPROBE(i) do { } while (0)
-#endif
-
-template <int T>
 __global__ __launch_bounds__(256) void stem_onehot_kernel(StemArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    SPROBE(0);
-#if PF_PROBE
-    const long long wg_t0 = wall_clock64();
-#endif
-    const int in_ch = T * (a.n_cls + 1);
-    // one-hot weight rows [tap][t][class 0..n_cls][kStemRowF]: row n_cls is zeros (labels >= n_cls / padding select
-    // it: no branch in the tap loop); rows are 20 floats apart so that 16 lanes reading 16 different classes with
-    // ds_read_b128 touch 16 different 4-bank slots (5 is coprime with 16)
-    const int nrow = a.n_cls + 1;
-    float *wl = smem;
-    float *dn_s = smem + 9 * T * nrow * kStemRowF;                      // [T][rows][parity][cols]
-    int8_t *cls_s = reinterpret_cast<int8_t *>(dn_s + T * kStemRows * 2 * kStemCols);
+    // weights in LDS as [tap][ch][16]: row = one input channel's 16 output weights for that tap
+    extern __shared__ __attribute__((aligned(16))) float wl[];
     __shared__ uint8_t lut[256];
-
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 9 * T * nrow * 16; e += 256) {
-        const int co = e & 15, row = e >> 4;                       // row = (tap*T + t)*nrow + cls
-        const int cls = row % nrow, t = (row / nrow) % T, tap = row / (nrow * T);
-        wl[row * kStemRowF + co] = cls < a.n_cls ? a.w[((size_t)co * in_ch + t * a.n_cls + cls) * 9 + tap] : 0.f;
+    const int in_ch = a.T * (a.n_cls + 1);
+    for (int e = threadIdx.x; e < 9 * in_ch * 16; e += 256) {
+        const int co = e & 15, ch = (e >> 4) % in_ch, tap = (e >> 4) / in_ch;
+        wl[e] = a.w[((size_t)co * in_ch + ch) * 9 + tap];
     }
-    lut[tid] = (a.hop & PF_HOP_TRAINID_LUT) ? a.lut[tid] : (uint8_t)tid;
+    lut[threadIdx.x] = (a.hop & PF_HOP_TRAINID_LUT) ? a.lut[threadIdx.x] : (uint8_t)threadIdx.x;
     __syncthreads();
-    SPROBE(1);
 
-    const int ox0 = blockIdx.x * kStemTW, oy0 = blockIdx.y * kStemTH, b = blockIdx.z;
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (ox >= a.Wout || oy >= a.Hout) return;
     const size_t N = (size_t)a.H * a.W;
-    const int ix0 = 2 * ox0 - 4, iy0 = 2 * oy0 - 1;      // window origin (ix0 is a multiple of 4)
-    constexpr int NV = (2 * kStemTW + 8) / 4;            // float4 pieces per window row (34)
-    const bool vec = (a.W & 3) == 0;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = a.bias[i];
+    const float mean_ = a.depth_mean, std_ = a.depth_std;
 
-    // ---- stage 1
-    for (int e = tid; e < T * kStemRows * NV; e += 256) {
-        const int t = e / (kStemRows * NV), rem = e - t * (kStemRows * NV);
-        const int r = rem / NV, i = rem - r * NV;
-        const int gy = iy0 + r, gx = ix0 + 4 * i;
-        float d[4] = {0.f, 0.f, 0.f, 0.f};
-        int lab[4] = {-1, -1, -1, -1};
-        bool m[4] = {false, false, false, false};
-        if (gy >= 0 && gy < a.H && gx + 3 >= 0 && gx < a.W) {
-            const size_t idx = ((size_t)b * T + t) * N + (size_t)gy * a.W + gx;
-            if (vec && gx >= 0 && gx + 3 < a.W) {
-                const float4 dv = *reinterpret_cast<const float4 *>(a.depth + idx);
-                d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
-                if (a.seg_is_i64) {
-                    const longlong2 s0 = reinterpret_cast<const longlong2 *>(reinterpret_cast<const long long *>(a.seg) + idx)[0];
-                    const longlong2 s1 = reinterpret_cast<const longlong2 *>(reinterpret_cast<const long long *>(a.seg) + idx)[1];
-                    lab[0] = (int)s0.x; lab[1] = (int)s0.y; lab[2] = (int)s1.x; lab[3] = (int)s1.y;
-                } else {
-                    const uchar4 sv = *reinterpret_cast<const uchar4 *>(reinterpret_cast<const uint8_t *>(a.seg) + idx);
-                    lab[0] = sv.x; lab[1] = sv.y; lab[2] = sv.z; lab[3] = sv.w;
-                }
-                if (!(a.hop & PF_HOP_DEPTH_U16)) {
-                    const uchar4 mv = *reinterpret_cast<const uchar4 *>(a.mask + idx);
-                    m[0] = mv.x != 0; m[1] = mv.y != 0; m[2] = mv.z != 0; m[3] = mv.w != 0;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (gx + k < 0 || gx + k >= a.W) continue;
-                    d[k] = a.depth[idx + k];
-                    lab[k] = a.seg_is_i64 ? (int)reinterpret_cast<const long long *>(a.seg)[idx + k]
-                                          : (int)reinterpret_cast<const uint8_t *>(a.seg)[idx + k];
-                    if (!(a.hop & PF_HOP_DEPTH_U16)) m[k] = a.mask[idx + k] != 0;
-                }
-            }
-        }
-        float *drow = dn_s + ((t * kStemRows + r) * 2) * kStemCols;
-        int8_t *crow = cls_s + ((t * kStemRows + r) * 2) * kStemCols;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool inside = gy >= 0 && gy < a.H && gx + k >= 0 && gx + k < a.W;
-            int cls = lab[k];
-            if (a.hop & PF_HOP_TRAINID_LUT) cls = lut[cls & 255];
-            if (!inside || cls < 0 || cls >= a.n_cls) cls = a.n_cls;  // labels >= n_cls: zero vector (bg_model.py:54-57)
-            float dd = d[k], mm;
-            if (a.hop & PF_HOP_DEPTH_U16) {
-                const float q = rintf(fminf(fmaxf(dd + 1.f, 0.f), 255.f) * 256.f);   // export :119-124
-                dd = q / 256.f - 1.f;                                                  // load bg_dataset.py:225
-                const bool mk = dd > 0.f;
-                dd = mk ? fminf(fmaxf(dd, a.min_depth), a.max_depth) : -1.f;            // :227-228,:166-170
-                mm = mk ? 1.f : 0.f;
-            } else {
-                mm = m[k] ? 1.f : 0.f;
-            }
-            const float dn = inside ? ((dd - a.depth_mean) / a.depth_std) * mm : 0.f;   // bg_model.py:50-51,66-67
-            // window column c = 4*i + k (absolute column ix0 + c): even columns -> j = (c-4)/2, odd -> j = (c-3)/2
-            const int c = 4 * i + k, par = c & 1, j = (c - 3 - (1 - par)) >> 1;        // valid j: even 0..63, odd 0..64
-            if (j >= 0 && j < kStemCols) {
-                drow[par * kStemCols + j] = dn;
-                crow[par * kStemCols + j] = (int8_t)cls;
-            }
-        }
-    }
-    __syncthreads();
-    SPROBE(2);
-
-    // ---- stage 2: lane = output column lx, rows 2*lyp and 2*lyp+1 of the tile
-    const int lx = tid & 63, lyp = tid >> 6;
-    float acc[2][16];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[p][i] = a.bias[i];
-    // (t, ky) loops stay rolled: fully unrolled and branch-free, hipcc hoists all 54 gathers and spills 200 VGPRs
-#pragma unroll 1
-    for (int t = 0; t < T; ++t) {
-#pragma unroll 1
-        for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int tap = ky * 3 + kx;
-                // depth column of this (tap, frame): 16 contiguous floats at a uniform address -> one s_load_dwordx16
-                const float *wd = a.wdep + (tap * T + t) * 16;
-                // input column 2*ox - 1 + kx: kx = 1 is even (j = lx), kx = 0 / 2 are odd (j = lx, lx + 1)
-                const int par = kx == 1 ? 0 : 1, j = lx + (kx == 2 ? 1 : 0);
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const int r = 2 * (2 * lyp + p) + ky;
-                    const int o = ((t * kStemRows + r) * 2 + par) * kStemCols + j;
-                    const int cls = cls_s[o];
-                    const float dn = dn_s[o];
-                    const f32x4v *row = reinterpret_cast<const f32x4v *>(wl + ((tap * T + t) * nrow + cls) * kStemRowF);
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        if (iy < 0 || iy >= a.H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            if (ix < 0 || ix >= a.W) continue;
+            const int tap = ky * 3 + kx;
+            const size_t pix = (size_t)iy * a.W + ix;
+            for (int t = 0; t < a.T; ++t) {
+                const size_t idx = ((size_t)b * a.T + t) * N + pix;
+                // label -> one-hot column (labels >= n_cls contribute nothing, bg_model.py:54-57)
+                int cls = a.seg_is_i64 ? (int)reinterpret_cast<const long long *>(a.seg)[idx]
+                                       : (int)reinterpret_cast<const uint8_t *>(a.seg)[idx];
+                if (a.hop & PF_HOP_TRAINID_LUT) cls = lut[cls & 255];
+                if (cls >= 0 && cls < a.n_cls) {
+                    const f32x4v *row = reinterpret_cast<const f32x4v *>(wl + (tap * in_ch + t * a.n_cls + cls) * 16);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4v w4 = row[q];
-                        acc[p][q * 4 + 0] += w4[0]; acc[p][q * 4 + 1] += w4[1];
-                        acc[p][q * 4 + 2] += w4[2]; acc[p][q * 4 + 3] += w4[3];
+                        const f32x4v r = row[q];
+                        acc[q * 4 + 0] += r[0]; acc[q * 4 + 1] += r[1]; acc[q * 4 + 2] += r[2]; acc[q * 4 + 3] += r[3];
                     }
+                }
+                // depth channel: ((d - mean)/std) * mask   (bg_model.py:50-51,66-67)
+                float d = a.depth[idx];
+                float m;
+                if (a.hop & PF_HOP_DEPTH_U16) {
+                    const float q = rintf(fminf(fmaxf(d + 1.f, 0.f), 255.f) * 256.f);  // export :119-124
+                    d = q / 256.f - 1.f;                                                // load bg_dataset.py:225
+                    const bool mk = d > 0.f;
+                    d = mk ? fminf(fmaxf(d, a.min_depth), a.max_depth) : -1.f;           // :227-228,:166-170
+                    m = mk ? 1.f : 0.f;
+                } else {
+                    m = a.mask[idx] ? 1.f : 0.f;
+                }
+                const float dn = ((d - mean_) / std_) * m;
+                const f32x4v *row = reinterpret_cast<const f32x4v *>(wl + (tap * in_ch + a.T * a.n_cls + t) * 16);
 #pragma unroll
-                    for (int co = 0; co < 16; ++co) acc[p][co] += wd[co] * dn;
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4v r = row[q];
+                    acc[q * 4 + 0] += r[0] * dn; acc[q * 4 + 1] += r[1] * dn;
+                    acc[q * 4 + 2] += r[2] * dn; acc[q * 4 + 3] += r[3] * dn;
                 }
             }
         }
     }
-    SPROBE(3);
-    const int ox = ox0 + lx;
     const size_t op = (size_t)a.Hout * a.Wout;
+    float *o = a.dst + (size_t)b * 16 * op + (size_t)oy * a.Wout + ox;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int oy = oy0 + 2 * lyp + p;
-        if (ox < a.Wout && oy < a.Hout) {
-            float *o = a.dst + (size_t)b * 16 * op + (size_t)oy * a.Wout + ox;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[i * op] = fmaxf(acc[p][i], 0.f);
-        }
-    }
-    SPROBE(4);
-#if PF_PROBE
-    if (threadIdx.x == 0 && a.probe) {   // whole-kernel view: first start, last end, summed workgroup time (100 MHz ticks)
-        const long long t1 = wall_clock64();
-        atomicMin((unsigned long long *)&a.probe[60], (unsigned long long)wg_t0);
-        atomicMax((unsigned long long *)&a.probe[61], (unsigned long long)t1);
-        atomicAdd((unsigned long long *)&a.probe[62], (unsigned long long)(t1 - wg_t0));
-        atomicAdd((unsigned long long *)&a.probe[63], 1ull);
-    }
-#endif
+    for (int i = 0; i < 16; ++i) o[i * op] = fmaxf(acc[i], 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -274,21 +163,13 @@ static unsigned grid_for(size_t total) {
 }
 
 int launch_stem(const StemArgs &a, hipStream_t s) {
-    if (a.T < 1 || a.T > 4 || a.n_cls > 126)
-        return fail(PF_EUNSUPPORTED, "stem: T=%d n_cls=%d (supported: 1..4 frames, <= 126 classes)", a.T, a.n_cls);
-    const size_t lds = (size_t)9 * a.T * (a.n_cls + 1) * kStemRowF * sizeof(float) +
-                       (size_t)a.T * kStemRows * 2 * kStemCols * (sizeof(float) + 1);
-    if (lds > 64 * 1024) return fail(PF_EUNSUPPORTED, "stem: T=%d n_cls=%d needs %zu B of LDS", a.T, a.n_cls, lds);
+    if (a.T * (a.n_cls + 1) * 9 * 16 * sizeof(float) > 60000)
+        return fail(PF_EUNSUPPORTED, "stem: T=%d n_cls=%d weights exceed LDS budget", a.T, a.n_cls);
+    const size_t lds = (size_t)a.T * (a.n_cls + 1) * 9 * 16 * sizeof(float);
     const double ipx = (double)a.B * a.T * a.H * a.W, opx = (double)a.B * a.Hout * a.Wout;
     ProfScope ps(s, "pf::stem_onehot_kernel(pf::StemArgs)", 2.0 * opx * 16 * a.T * (a.n_cls + 1) * 9,
                  ipx * ((a.seg_is_i64 ? 8 : 1) + 4 + ((a.hop & PF_HOP_DEPTH_U16) ? 0 : 1)) + opx * 16 * 4);
-    const dim3 grid((a.Wout + kStemTW - 1) / kStemTW, (a.Hout + kStemTH - 1) / kStemTH, a.B);
-    switch (a.T) {
-        case 1: hipLaunchKernelGGL(stem_onehot_kernel<1>, grid, dim3(256), lds, s, a); break;
-        case 2: hipLaunchKernelGGL(stem_onehot_kernel<2>, grid, dim3(256), lds, s, a); break;
-        case 3: hipLaunchKernelGGL(stem_onehot_kernel<3>, grid, dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL(stem_onehot_kernel<4>, grid, dim3(256), lds, s, a); break;
-    }
+    hipLaunchKernelGGL(stem_onehot_kernel, dim3((a.Wout + 63) / 64, (a.Hout + 3) / 4, a.B), dim3(256), lds, s, a);
     PF_LAUNCH_CHECK("stem_onehot_kernel");
     return PF_OK;
 }

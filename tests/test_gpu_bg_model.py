@@ -147,5 +147,5 @@ def test_execution_options_do_not_change_the_result(opts):
         assert (out['seg'].cpu() == ref['seg']).float().mean() >= AGREE
     finally:
         L.pf_set_option(b'fuse_pool', 1)
-        L.pf_set_option(b'fuse_upsample', 0)
+        L.pf_set_option(b'fuse_upsample', 1)
     assert L.pf_set_option(b'no_such_option', 1) == -1

@@ -138,7 +138,7 @@ def fuse_upsample():
     L = pflib.load()
     pflib.check(L.pf_set_option(b'fuse_upsample', 1), 'pf_set_option')
     yield
-    L.pf_set_option(b'fuse_upsample', 0)
+    L.pf_set_option(b'fuse_upsample', 1)   # library default
 
 
 @pytest.mark.parametrize('force', [(0, 0, 0, 0), (1, 4, 2, 0), (1, 2, 1, 0), (1, 1, 2, 0), (2, 2, 2, 2), (2, 4, 1, 4)],

@@ -98,7 +98,7 @@ if args.emit:
                 % (args.batch, args.height, args.width, tot_best, tot_auto))
         seen = set()
         for r in rows:
-            m = re.match(r'\d+ (\S+) (\d+)->(\d+) (\d+)x(\d+)', r['tag'])
+            m = re.match(r'\d+[ab]? (\S+) (\d+)->(\d+) (\d+)x(\d+)', r['tag'])
             cin, cout, h, w = int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5))
             ks = 1 if ('conv1x1' in r['tag'] or 'finalConv' in r['tag'] or re.match(r'\d+ base\.(5|8|11|14|17) ', r['tag'])) else 3
             key = (ks, cin, cout, h, w, args.batch)
