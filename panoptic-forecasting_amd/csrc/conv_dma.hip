@@ -122,6 +122,19 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
     const int cb = a.chunk_begin, nrounds = (a.chunk_end - cb + WK - 1) / WK;
     DPROBE(0);
 
+    // channels of `chunk` that exist (its range may end inside it): k-groups past them are all-zero and are skipped
+    auto chunk_valid = [&](int chunk) {
+        int ch0 = 0, cend = a.src_cstart[1], c0 = 0;
+#pragma unroll
+        for (int k = 1; k < kConvMaxSrc; ++k) {
+            const bool take = k < a.n_src && chunk >= a.src_chunk0[k];
+            ch0 = take ? a.src_chunk0[k] : ch0;
+            c0 = take ? a.src_cstart[k] : c0;
+            cend = take ? a.src_cstart[k + 1] : cend;
+        }
+        return (cend - c0) - (chunk - ch0) * C::KC;
+    };
+
     // issue the DMA of one round (WK chunks: inputs + weights) into buffer `buf`.  Which tensor a chunk reads, its
     // first channel and how many of its KC channels exist are workgroup-uniform: select chains on the scalar ALU.
     auto stage = [&](int round, float *buf) {
@@ -172,8 +185,10 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
         if (cb + round * WK + wk < a.chunk_end) {
             const float *in_s = cur + wk * C::SLOT;
             const float *w_s = in_s + C::KC * C::PLANE;
+            const int nv = chunk_valid(cb + round * WK + wk);
 #pragma unroll
             for (int kg = 0; kg < C::KC / 4; ++kg) {
+                if (kg > 0 && kg * 4 >= nv) break;   // wave-uniform: the tail of a range shorter than the chunk
 #pragma unroll
                 for (int tap = 0; tap < C::KS2; ++tap) {
                     const int ky = tap / KS, kx = tap - ky * KS;

@@ -162,9 +162,22 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
 
     const int abase = (lane >> 4) * C::PLANE + (lane & 15) + (C::APRON - KS / 2);
 
+    // channels of `chunk` that exist (its range may end inside it): k-groups past them are all-zero and are skipped
+    auto chunk_valid = [&](int chunk) {
+        int ch0 = 0, cend = a.src_cstart[1], c0 = 0;
+#pragma unroll
+        for (int k = 1; k < kConvMaxSrc; ++k) {
+            const bool take = k < a.n_src && chunk >= a.src_chunk0[k];
+            ch0 = take ? a.src_chunk0[k] : ch0;
+            c0 = take ? a.src_cstart[k] : c0;
+            cend = take ? a.src_cstart[k + 1] : cend;
+        }
+        return (cend - c0) - (chunk - ch0) * C::KC;
+    };
+
     // A operands are fetched one (k-group, tap) step ahead of the MFMAs that use them, so the LDS latency of step
     // s+1 is covered by the MP*NT MFMAs of step s instead of stalling the matrix pipe at every step.
-    auto compute = [&](const float *buf, const WFrag(&w)[NT]) {
+    auto compute = [&](const float *buf, const WFrag(&w)[NT], int nv) {
         auto aload = [&](int idx, float(&af)[MH]) {
             const int kg = idx / C::KS2, tap = idx - kg * C::KS2;
             const int ky = tap / KS, kx = tap - ky * KS;
@@ -175,6 +188,7 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
         aload(0, a0);
 #pragma unroll
         for (int idx = 0; idx < C::NV; ++idx) {
+            if (idx >= C::KS2 && (idx / C::KS2) * 4 >= nv) break;   // wave-uniform: k-groups past the end of the range
             float(&cur)[MH] = (idx & 1) ? a1 : a0;
             float(&nxt)[MH] = (idx & 1) ? a0 : a1;
             if (idx + 1 < C::NV) aload(idx + 1, nxt);
@@ -205,14 +219,14 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
             PROBE();
             wait_vm<C::NL>();
             PROBE();
-            compute(ring, w0);
+            compute(ring, w0, chunk_valid(first + i * WK));
             PROBE();
             if (i + 1 < nmine) {
                 issue(min(first + (i + 2) * WK, last), ring, w0);
                 PROBE();
                 wait_vm<C::NL>();
                 PROBE();
-                compute(ring + C::STAGE, w1);
+                compute(ring + C::STAGE, w1, chunk_valid(first + (i + 1) * WK));
                 PROBE();
             }
         }
