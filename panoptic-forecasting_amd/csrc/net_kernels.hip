@@ -156,6 +156,65 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
     }
 }
 
+// Fast path of the head for >= 3x upsampling (the bg net: logits at 1/4 resolution): one lane = 4 consecutive output
+// pixels of a row.  Their taps fall on at most 3 consecutive source columns, so each channel costs 6 loads for 4
+// outputs (the generic kernel: 16) and the labels leave as one 32-bit store.
+__global__ __launch_bounds__(256) void head4_kernel(HeadArgs a) {
+    const float sh = a.Hout > 1 ? (float)(a.Hin - 1) / (float)(a.Hout - 1) : 0.f;
+    const float sw = a.Wout > 1 ? (float)(a.Win - 1) / (float)(a.Wout - 1) : 0.f;
+    const size_t opl = (size_t)a.Hout * a.Wout, ipl = (size_t)a.Hin * a.Win;
+    const int W4 = a.Wout >> 2;
+    const size_t total = (size_t)a.B * a.Hout * W4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int xq = (int)(i % W4), x = xq * 4;
+        const size_t r = i / W4;
+        const int y = (int)(r % a.Hout), b = (int)(r / a.Hout);
+        int y0, y1;
+        float hy0, hy1;
+        lin_coord(y, sh, a.Hin, y0, y1, hy0, hy1);
+        int i0[4], i1[4];
+        float l0[4], l1[4];
+        int xa = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int x0, x1;
+            lin_coord(x + k, sw, a.Win, x0, x1, l0[k], l1[k]);
+            if (k == 0) xa = x0;
+            i0[k] = x0 - xa;   // 0 or 1
+            i1[k] = x1 - xa;   // 0, 1 or 2
+        }
+        const int xb = min(xa + 1, a.Win - 1), xc = min(xa + 2, a.Win - 1);
+        const float *s = a.logits + (size_t)b * a.C * ipl;
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int arg[4] = {0, 0, 0, 0};
+        for (int c = 0; c < a.C; ++c) {
+            const float *r0 = s + (size_t)c * ipl + (size_t)y0 * a.Win, *r1 = s + (size_t)c * ipl + (size_t)y1 * a.Win;
+            const float t0[3] = {r0[xa], r0[xb], r0[xc]}, t1[3] = {r1[xa], r1[xb], r1[xc]};
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a0 = i0[k] ? t0[1] : t0[0], a1 = i1[k] == 2 ? t0[2] : (i1[k] ? t0[1] : t0[0]);
+                const float b0 = i0[k] ? t1[1] : t1[0], b1 = i1[k] == 2 ? t1[2] : (i1[k] ? t1[1] : t1[0]);
+                const float u0 = l0[k] * a0 + l1[k] * a1;
+                const float u1 = l0[k] * b0 + l1[k] * b1;
+                v[k] = hy0 * u0 + hy1 * u1;
+                if (v[k] > best[k]) { best[k] = v[k]; arg[k] = c; }   // first maximum wins, like torch.argmax on CPU
+            }
+            if (a.out_logits)
+                *reinterpret_cast<f32x4v *>(a.out_logits + ((size_t)b * a.C + c) * opl + (size_t)y * a.Wout + x) = f32x4v{v[0], v[1], v[2], v[3]};
+        }
+        const size_t o = (size_t)b * opl + (size_t)y * a.Wout + x;
+        if (a.out_is_i64) {
+            long long *d = reinterpret_cast<long long *>(a.out_seg) + o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = arg[k];
+        } else {
+            *reinterpret_cast<unsigned *>(reinterpret_cast<uint8_t *>(a.out_seg) + o) =
+                (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 static unsigned grid_for(size_t total) {
     size_t g = (total + 255) / 256;
@@ -195,7 +254,11 @@ int launch_head(const HeadArgs &a, hipStream_t s) {
     const double opx = (double)a.B * a.Hout * a.Wout;
     ProfScope ps(s, "pf::head_kernel(pf::HeadArgs)", 0, 4.0 * a.B * a.C * a.Hin * a.Win + opx * (a.out_is_i64 ? 8 : 1) +
                                                           (a.out_logits ? opx * a.C * 4 : 0));
-    hipLaunchKernelGGL(head_kernel, dim3(grid_for((size_t)a.B * a.Hout * a.Wout)), dim3(256), 0, s, a);
+    const float sw = a.Wout > 1 ? (float)(a.Win - 1) / (float)(a.Wout - 1) : 0.f;
+    if ((a.Wout & 3) == 0 && 3.f * sw < 1.f && a.Win >= 3)   // 4 consecutive outputs span <= 2 source columns
+        hipLaunchKernelGGL(head4_kernel, dim3(grid_for((size_t)a.B * a.Hout * (a.Wout >> 2))), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(head_kernel, dim3(grid_for((size_t)a.B * a.Hout * a.Wout)), dim3(256), 0, s, a);
     PF_LAUNCH_CHECK("head_kernel");
     return PF_OK;
 }

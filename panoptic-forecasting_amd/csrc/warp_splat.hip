@@ -26,14 +26,27 @@
 // (seg 0, depth max+1) wherever no valid point lands; untouched bins give seg 0, depth -1 (:136-138).
 #include "pf_common.h"
 #include "pf_prof.h"
+#include <cstdlib>
+
+#ifndef PF_PROBE
+#define PF_PROBE 0
+#endif
+#if PF_PROBE   // 100 MHz wall-clock stamps of one raster workgroup + whole-kernel workgroup-time sum
+#define RPROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 100 && blockIdx.y == 1 && blockIdx.z == 0 && a.probe) a.probe[i] = wall_clock64(); } while (0)
+#else
+#define RPROBE(i) do { } while (0)
+#endif
 
 namespace pf {
+long long *probe_buffer();
 
 constexpr unsigned long long kEmpty = ~0ull;
 constexpr int kThreads = 256;
 constexpr int kSrcTH = 16, kSrcTW = 64;   // source tile (pixels); 256 threads x 4 consecutive pixels
 constexpr int kDstTH = 32, kDstTW = 128;  // destination tile owned by one raster workgroup (32 KB LDS)
-constexpr int kScan = 256;                // bounding boxes tested per scan batch
+constexpr int kScan = 256;                // bounding boxes tested per thread-pass
+constexpr int kScanBatches = 8;           // passes per list fill (list holds kScan * kScanBatches tile ids)
+constexpr int kZSlots = 64;               // atomicMax slots per z-buffer group (spreads the memory-side atomics)
 
 struct SplatArgs {
     const float *depth;
@@ -41,7 +54,7 @@ struct SplatArgs {
     const uint8_t *seg;
     const float *Kinv, *E, *Tt, *Einv, *K;
     int4 *bbox;           // [B][T][src tiles]  (x0min, y0min, x1max, y1max) of valid points' bins
-    unsigned *zmax_part;  // [T][B][src tiles]  order-preserving u32 of the block max(z)
+    unsigned *zmax_part;  // [G][kZSlots]       order-preserving u32 of max(z) per z-buffer group (atomicMax, zeroed per call)
     uint8_t *inv_mark;    // [B*G][N]           1 where an invalid point lands
     uint2 *proj;          // [B][T][N]          {bits(z), x0 | y0<<13 | (x1!=x0)<<26 | (y1!=y0)<<27 | valid<<28}
     uint8_t *out_seg;
@@ -50,6 +63,7 @@ struct SplatArgs {
     int B, T_total, t_first, T, H, W, C, per_frame;
     int stx, sty;         // source tiles per row / column
     int dtx, dty;         // destination tiles per row / column
+    long long *probe;     // PF_PROBE builds only
 };
 
 __device__ __forceinline__ unsigned float_to_ordered(float f) {
@@ -221,7 +235,9 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
             bx1 = max(bx1, bred[w][2]); by1 = max(by1, bred[w][3]);
         }
         const long long ntile = (long long)a.stx * a.sty;
-        a.zmax_part[((long long)tl * a.B + b) * ntile + tile] = float_to_ordered(zmax);
+        // :105 the sentinel is max(z)+1 over the whole predict call (one frame's points in per_frame mode): one
+        // order-independent atomicMax per source tile instead of every raster workgroup re-reducing all partials
+        atomicMax(&a.zmax_part[(a.per_frame ? tl : 0) * kZSlots + ((tile + b) & (kZSlots - 1))], float_to_ordered(zmax));
         a.bbox[((long long)b * a.T + tl) * ntile + tile] = make_int4(bx0, by0, bx1, by1);
     }
 }
@@ -229,9 +245,8 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
     __shared__ unsigned long long zb[kDstTH * kDstTW];   // 16 KB
-    __shared__ unsigned short list[kScan];
+    __shared__ unsigned short list[kScan * kScanBatches];
     __shared__ int list_n;
-    __shared__ unsigned red[kThreads / 64];
     __shared__ float sentinel_s;
 
     const int dtile = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
@@ -242,109 +257,154 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
     const long long P = (long long)Tg * N;
     const int ntile = a.stx * a.sty;
 
+    RPROBE(0);
+    int n_hits_total = 0;
     for (int i = threadIdx.x; i < kDstTH * kDstTW; i += kThreads) zb[i] = kEmpty;
 
     // sentinel = max(z over the whole predict call) + 1 (:105); one frame's points in per_frame mode
-    {
-        const unsigned *part = a.zmax_part + (a.per_frame ? (long long)g * a.B * ntile : 0);
-        const int cnt = Tg * a.B * ntile;
-        unsigned m = 0;
-        for (int i = threadIdx.x; i < cnt; i += kThreads) m = max(m, part[i]);
+    if (threadIdx.x < 64) {
+        unsigned m = a.zmax_part[(a.per_frame ? g : 0) * kZSlots + threadIdx.x];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned mm = red[0];
-#pragma unroll
-            for (int i = 1; i < kThreads / 64; ++i) mm = max(mm, red[i]);
-            sentinel_s = __fadd_rn(ordered_to_float(mm), 1.0f);
-        }
+        if (threadIdx.x == 0) sentinel_s = __fadd_rn(ordered_to_float(m), 1.0f);
     }
 
-    // ---- rasterise: every source tile whose valid-point bounding box touches this destination tile
+    // ---- rasterise: every source tile whose valid-point bounding box touches this destination tile.  Hits are
+    //      collected first (one barrier pair per 256 boxes) and then consumed four at a time: their 32-B projection
+    //      records are all in flight before the first goes through the LDS atomics - the loop was
+    //      a chain of ~2 us load latencies, one per hit (tools/probe_splat.py).
+    auto splat4 = [&](const unsigned (&pk)[8], int x, int y, unsigned long long ebase) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned f = pk[2 * k + 1];
+            if (!((f >> 28) & 1u)) continue;   // invalid points were handled by the byte marks
+            const int px0 = (int)(f & 8191u), py0 = (int)((f >> 13) & 8191u);
+            const int px1 = px0 + (int)((f >> 26) & 1u), py1 = py0 + (int)((f >> 27) & 1u);
+            // replicas r = 0:(x0,y0) 1:(x0,y1) 2:(x1,y0) 3:(x1,y1); e = r*P + t*N + n  (:112).  A replica
+            // on the bin of a lower replica of the same point can never win the tie-break: skip it.
+            const unsigned long long e0 = ebase + (unsigned long long)((long long)y * a.W + x + k);
+            const unsigned long long khi = (unsigned long long)pk[2 * k] << 32;
+            const bool in_x0 = px0 >= dx0 && px0 <= dx1, in_x1 = px1 >= dx0 && px1 <= dx1 && px1 != px0;
+            const bool in_y0 = py0 >= dy0 && py0 <= dy1, in_y1 = py1 >= dy0 && py1 <= dy1 && py1 != py0;
+            if (in_x0 && in_y0) atomicMin(&zb[(py0 - dy0) * kDstTW + (px0 - dx0)], khi | e0);
+            if (in_x0 && in_y1) atomicMin(&zb[(py1 - dy0) * kDstTW + (px0 - dx0)], khi | (e0 + (unsigned long long)P));
+            if (in_x1 && in_y0) atomicMin(&zb[(py0 - dy0) * kDstTW + (px1 - dx0)], khi | (e0 + 2ull * P));
+            if (in_x1 && in_y1) atomicMin(&zb[(py1 - dy0) * kDstTW + (px1 - dx0)], khi | (e0 + 3ull * P));
+        }
+    };
+    auto load4 = [&](const uint2 *pbase, int st, unsigned (&pk)[8], int &x, int &y) {
+        y = (st / a.stx) * kSrcTH + (threadIdx.x >> 4);
+        x = (st % a.stx) * kSrcTW + (threadIdx.x & 15) * 4;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pk[k] = 0u;      // valid bit clear: nothing to splat
+        if (st < 0 || y >= a.H || x >= a.W) return;
+        const uint2 *pj = pbase + (long long)y * a.W + x;
+        if ((a.W & 3) == 0) {
+            const uint4 q0 = reinterpret_cast<const uint4 *>(pj)[0], q1 = reinterpret_cast<const uint4 *>(pj)[1];
+            pk[0] = q0.x; pk[1] = q0.y; pk[2] = q0.z; pk[3] = q0.w;
+            pk[4] = q1.x; pk[5] = q1.y; pk[6] = q1.z; pk[7] = q1.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint2 q = x + k < a.W ? pj[k] : make_uint2(0u, 0u);
+                pk[2 * k] = q.x; pk[2 * k + 1] = q.y;
+            }
+        }
+    };
     for (int tt = 0; tt < Tg; ++tt) {
         const int tl = a.per_frame ? g : tt;     // local frame index
         const int4 *boxes = a.bbox + ((long long)b * a.T + tl) * ntile;
         const uint2 *pbase = a.proj + ((long long)b * a.T + tl) * N;
         const unsigned long long ebase = (unsigned long long)tt * N;
-        for (int s0 = 0; s0 < ntile; s0 += kScan) {
+        for (int s0 = 0; s0 < ntile; s0 += kScan * kScanBatches) {
             __syncthreads();
             if (threadIdx.x == 0) list_n = 0;
             __syncthreads();
-            const int s = s0 + threadIdx.x;
-            if (s < ntile) {
-                const int4 bb = boxes[s];
-                if (bb.x <= dx1 && bb.z >= dx0 && bb.y <= dy1 && bb.w >= dy0) list[atomicAdd(&list_n, 1)] = (unsigned short)threadIdx.x;
+#pragma unroll
+            for (int j = 0; j < kScanBatches; ++j) {
+                const int s = s0 + j * kScan + threadIdx.x;
+                if (s < ntile) {
+                    const int4 bb = boxes[s];
+                    if (bb.x <= dx1 && bb.z >= dx0 && bb.y <= dy1 && bb.w >= dy0) list[atomicAdd(&list_n, 1)] = (unsigned short)(s - s0);
+                }
             }
             __syncthreads();
             const int n_hit = list_n;
-            for (int li = 0; li < n_hit; ++li) {
-                const int st = s0 + list[li];
-                const int y = (st / a.stx) * kSrcTH + (threadIdx.x >> 4);
-                const int x = (st % a.stx) * kSrcTW + (threadIdx.x & 15) * 4;
-                if (y >= a.H || x >= a.W) continue;
-                const uint2 *pj = pbase + (long long)y * a.W + x;
-                unsigned pk[8];
-                if ((a.W & 3) == 0) {
-                    const uint4 q0 = reinterpret_cast<const uint4 *>(pj)[0], q1 = reinterpret_cast<const uint4 *>(pj)[1];
-                    pk[0] = q0.x; pk[1] = q0.y; pk[2] = q0.z; pk[3] = q0.w;
-                    pk[4] = q1.x; pk[5] = q1.y; pk[6] = q1.z; pk[7] = q1.w;
-                } else {
+            n_hits_total += n_hit;
+            RPROBE(4);
+            for (int li = 0; li < n_hit; li += 4) {
+                unsigned pk[4][8];
+                int xs[4], ys[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint2 q = x + k < a.W ? pj[k] : make_uint2(0u, 0u);
-                        pk[2 * k] = q.x; pk[2 * k + 1] = q.y;
-                    }
-                }
+                for (int j = 0; j < 4; ++j) load4(pbase, li + j < n_hit ? s0 + list[li + j] : -1, pk[j], xs[j], ys[j]);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned f = pk[2 * k + 1];
-                    if (!((f >> 28) & 1u)) continue;   // invalid points were handled by the byte marks
-                    const int px0 = (int)(f & 8191u), py0 = (int)((f >> 13) & 8191u);
-                    const int px1 = px0 + (int)((f >> 26) & 1u), py1 = py0 + (int)((f >> 27) & 1u);
-                    // replicas r = 0:(x0,y0) 1:(x0,y1) 2:(x1,y0) 3:(x1,y1); e = r*P + t*N + n  (:112).  A replica
-                    // on the bin of a lower replica of the same point can never win the tie-break: skip it.
-                    const unsigned long long e0 = ebase + (unsigned long long)((long long)y * a.W + x + k);
-                    const unsigned long long khi = (unsigned long long)pk[2 * k] << 32;
-                    const bool in_x0 = px0 >= dx0 && px0 <= dx1, in_x1 = px1 >= dx0 && px1 <= dx1 && px1 != px0;
-                    const bool in_y0 = py0 >= dy0 && py0 <= dy1, in_y1 = py1 >= dy0 && py1 <= dy1 && py1 != py0;
-                    if (in_x0 && in_y0) atomicMin(&zb[(py0 - dy0) * kDstTW + (px0 - dx0)], khi | e0);
-                    if (in_x0 && in_y1) atomicMin(&zb[(py1 - dy0) * kDstTW + (px0 - dx0)], khi | (e0 + (unsigned long long)P));
-                    if (in_x1 && in_y0) atomicMin(&zb[(py0 - dy0) * kDstTW + (px1 - dx0)], khi | (e0 + 2ull * P));
-                    if (in_x1 && in_y1) atomicMin(&zb[(py1 - dy0) * kDstTW + (px1 - dx0)], khi | (e0 + 3ull * P));
-                }
+                for (int j = 0; j < 4; ++j) splat4(pk[j], xs[j], ys[j], ebase);
             }
         }
     }
     __syncthreads();
+    RPROBE(1);
+#if PF_PROBE
+    if (threadIdx.x == 0 && blockIdx.x == 100 && blockIdx.y == 1 && blockIdx.z == 0 && a.probe) a.probe[3] = n_hits_total;
+#endif
 
-    // ---- resolve this tile's pixels (:120-139)
+    // ---- resolve this tile's pixels (:120-139): 4 consecutive pixels per lane, all loads issued before any is used
     const float sentinel = sentinel_s;
     const uint8_t *mark = a.inv_mark + ((long long)b * G + g) * N;
     const long long out_base = ((long long)b * G + g) * N;
     const long long seg_base = ((long long)b * a.T_total + a.t_first + (a.per_frame ? g : 0)) * N;
     const int C = a.C;
-    for (int i = threadIdx.x; i < kDstTH * kDstTW; i += kThreads) {
-        const int y = dy0 + i / kDstTW, x = dx0 + i % kDstTW;
+    const unsigned Pu = (unsigned)P;
+#pragma unroll
+    for (int it = 0; it < kDstTH * kDstTW / 4 / kThreads; ++it) {
+        const int i4 = it * kThreads + threadIdx.x;
+        const int y = dy0 + i4 / (kDstTW / 4), x = dx0 + (i4 % (kDstTW / 4)) * 4;
         if (y >= a.H || x >= a.W) continue;
-        const long long n = (long long)y * a.W + x;
-        const unsigned long long key = zb[i];
-        float dep;
-        long long src = -1;
-        if (key != kEmpty) {
-            dep = __uint_as_float((unsigned)(key >> 32));
-            src = seg_base + (long long)((key & 0xFFFFFFFFull) % (unsigned long long)P);   // e -> t*N + n
-        } else {
-            dep = mark[n] ? sentinel : -1.0f;   // won by an invalid point (:105,:133) / never touched (:136-138)
+        const long long n0 = (long long)y * a.W + x;
+        unsigned long long key[4];
+        long long src[4];
+        uint8_t mk[4], sg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            key[k] = zb[i4 * 4 + k];
+            unsigned e = (unsigned)key[k];               // e = r*P + t*N + n with r < 4: strip the corner replica
+            e -= e >= 2u * Pu ? 2u * Pu : 0u;
+            e -= e >= Pu ? Pu : 0u;
+            src[k] = key[k] != kEmpty ? seg_base + (long long)e : seg_base;     // always a readable address
         }
-        a.out_depth[out_base + n] = dep;
-        if (C == 1) {
-            a.out_seg[out_base + n] = src >= 0 ? a.seg[src] : (uint8_t)0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool in = x + k < a.W;
+            mk[k] = in ? mark[n0 + k] : (uint8_t)0;
+            sg[k] = C == 1 ? a.seg[src[k]] : (uint8_t)0;
+        }
+        float dep[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // empty bin: won by an invalid point (:105,:133) -> max+1, or never touched (:136-138) -> -1
+            dep[k] = key[k] != kEmpty ? __uint_as_float((unsigned)(key[k] >> 32)) : (mk[k] ? sentinel : -1.0f);
+            if (key[k] == kEmpty) sg[k] = 0;
+        }
+        if ((a.W & 3) == 0) {
+            *reinterpret_cast<float4 *>(a.out_depth + out_base + n0) = make_float4(dep[0], dep[1], dep[2], dep[3]);
+            if (C == 1) *reinterpret_cast<uchar4 *>(a.out_seg + out_base + n0) = make_uchar4(sg[0], sg[1], sg[2], sg[3]);
         } else {
-            for (int c = 0; c < C; ++c) a.out_seg[(out_base + n) * C + c] = src >= 0 ? a.seg[src * C + c] : (uint8_t)0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (x + k < a.W) {
+                    a.out_depth[out_base + n0 + k] = dep[k];
+                    if (C == 1) a.out_seg[out_base + n0 + k] = sg[k];
+                }
+        }
+        if (C != 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (x + k < a.W)
+                    for (int c = 0; c < C; ++c)
+                        a.out_seg[(out_base + n0 + k) * C + c] = key[k] != kEmpty ? a.seg[src[k] * C + c] : (uint8_t)0;
         }
     }
+    RPROBE(2);
 }
 
 struct SplatLayout {
@@ -359,7 +419,7 @@ static SplatLayout splat_layout(int B, int T, int H, int W, int per_frame) {
     const size_t ntile = (size_t)L.stx * L.sty, N = (size_t)H * W;
     L.bbox_off = 0;
     L.zmax_off = align_up(L.bbox_off + (size_t)B * T * ntile * sizeof(int4), 256);
-    L.mark_off = align_up(L.zmax_off + (size_t)B * T * ntile * sizeof(unsigned), 256);
+    L.mark_off = align_up(L.zmax_off + (size_t)T * kZSlots * sizeof(unsigned), 256);   // zmax slots sit right before the marks: one memset
     L.mark_bytes = (size_t)B * (per_frame ? T : 1) * N;
     L.proj_off = align_up(L.mark_off + L.mark_bytes, 256);
     L.total = align_up(L.proj_off + (size_t)B * T * N * sizeof(uint2), 256);
@@ -409,6 +469,10 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     a.B = B; a.T_total = T_total; a.t_first = t_first; a.T = T; a.H = H; a.W = W; a.C = seg_channels;
     a.per_frame = per_frame ? 1 : 0;
     a.stx = L.stx; a.sty = L.sty; a.dtx = L.dtx; a.dty = L.dty;
+    a.probe = nullptr;
+#if PF_PROBE
+    a.probe = getenv("PF_PROBE") ? pf::probe_buffer() : nullptr;
+#endif
     hipStream_t s = (hipStream_t)stream;
     const int G = per_frame ? T : 1;
 
@@ -416,7 +480,8 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     const double src_px = (double)B * T * H * W, dst_px = (double)B * G * H * W;
     {
         pf::ProfScope ps(s, "inv_mark_memset", 0, (double)L.mark_bytes);
-        PF_HIP_CHECK(hipMemsetAsync(a.inv_mark, 0, L.mark_bytes, s));
+        // zmax slots (ordered-u32 encoding: 0 is below every float) + invalid-point marks, contiguous
+        PF_HIP_CHECK(hipMemsetAsync(a.zmax_part, 0, (L.mark_off - L.zmax_off) + L.mark_bytes, s));
     }
     {
         pf::ProfScope ps(s, "pf::bin_kernel(pf::SplatArgs)", 0, src_px * (5.0 + (out_result2d ? 16.0 : 0.0)));
