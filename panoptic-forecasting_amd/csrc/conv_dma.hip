@@ -34,7 +34,7 @@ namespace pf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int STRIDE, int WM, int WK, int NT>
+template <int KS, int STRIDE, int WM, int WK, int NT, int RV = 0>
 struct DmaCfg {
     static constexpr int KC = dma_kc_ct(KS, STRIDE);  // input channels per stage
     static constexpr int MP = 4;                      // M-tiles (16 px) per wave
@@ -49,7 +49,8 @@ struct DmaCfg {
     static constexpr int PP = PLANE / 4, RP = RAW / 4, RW = IW / 4;  // 16-B pieces per plane / real / per row
     static constexpr int KS2 = KS * KS;
     static constexpr int WFRAG = (KC / 4) * KS2 * 64;  // floats per (cout tile, chunk)
-    static constexpr int SLOT = KC * PLANE + NT * WFRAG;  // floats per K-split slot
+    static constexpr int RFRAG = (KC / 4) * KS2 * RV * 4;  // remainder-cout weights per chunk: [kgroup][tap][RV][4 ch]
+    static constexpr int SLOT = KC * PLANE + NT * WFRAG + RFRAG;  // floats per K-split slot
     static constexpr int BUF = WK * SLOT;
     static constexpr int RED = (WK - 1) * WM * MP * NT * 256;
     static constexpr int LDS_FLOATS = 2 * BUF > RED ? 2 * BUF : RED;
@@ -61,10 +62,15 @@ typedef __attribute__((address_space(3))) void *dma_lds_ptr_t;
 
 // EPI: 0 = bias + ReLU (the common case keeps its register budget), 1 = fused stages of conv_epilogue.h (2x2 pool,
 // upsampled residual) - separate instantiations because the fused epilogue needs ~70 more VGPRs.
-template <int KS, int STRIDE, int WM, int WK, int NT, int EPI>
+// RV > 0: the last Cout % 16 <= RV output channels are NOT padded to a 16-wide MFMA tile (37-44 % of the matrix work
+// of a 18- or 10-channel HarDBlock layer would be zeros); they are accumulated on the vector ALU instead - one lane
+// per pixel, A operands from the same LDS tile, weights as broadcast reads - in the issue shadow of the MFMAs of the
+// full tiles (each v_mfma_f32_16x16x4_f32 occupies the matrix pipe for 32 cycles = 8 free issue slots).
+template <int KS, int STRIDE, int WM, int WK, int NT, int EPI, int RV>
 __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtin types in the body; the host pass only needs the stub
-    using C = DmaCfg<KS, STRIDE, WM, WK, NT>;
+    using C = DmaCfg<KS, STRIDE, WM, WK, NT, RV>;
+    static_assert(RV == 0 || (WK == 1 && EPI == 0), "the vector-ALU remainder path is built for WK = 1, plain epilogue");
     constexpr int NTHR = 64 * WM * WK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -88,6 +94,14 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
         const int ty = mt / C::TWT, tx0 = (mt % C::TWT) * 16;
         abase[m] = (lane >> 4) * C::PLANE + ty * STRIDE * C::IW + (tx0 + (lane & 15)) * STRIDE + (C::APRON - KS / 2);
     }
+
+    // vector-ALU remainder: this lane's pixel inside the tile and its accumulators
+    const bool do_rem = RV > 0 && (int)blockIdx.y == (int)gridDim.y - 1;
+    const int v_mt = wm * C::MP + (lane >> 4), v_ty = v_mt / C::TWT, v_tx = (v_mt % C::TWT) * 16 + (lane & 15);
+    const int vbase = v_ty * STRIDE * C::IW + v_tx * STRIDE + (C::APRON - KS / 2);
+    float accv[RV > 0 ? RV : 1];
+#pragma unroll
+    for (int r = 0; r < (RV > 0 ? RV : 1); ++r) accv[r] = 0.f;
 
     // ---- per-thread constants of the staging pattern (16-B piece p = it*NTHR + tid of a slot): byte offset of the
     //      piece from the chunk's first channel plane (inputs) / from the chunk's weight block (weights); pieces that
@@ -114,6 +128,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
         woff[it] = (p < NPW && tile0 + n < a.ntiles) ? ((unsigned)(tile0 + n) * a.nchunks * C::WFRAG + q * 4) * 4u : kDmaOob;
     }
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wpk, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(RV > 0 ? a.wrem : a.wpk), 0, 0x7FFFFFFF, 0x00020000);
 
     float biasv[NT];   // fetched now, used in the epilogue: the latency hides behind the main loop
 #pragma unroll
@@ -172,6 +187,12 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
                 if (it * NTHR + tid < NPW)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (dma_lds_ptr_t)(wslot + (it * NTHR + wave * 64) * 4), 16,
                                                              woff[it], wsoff, 0, 0);
+            if (RV > 0 && do_rem) {   // remainder weights of the chunk: RFRAG/4 <= NTHR pieces
+                static_assert(C::RFRAG / 4 <= NTHR, "one DMA instruction per thread");
+                if (tid < C::RFRAG / 4)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rrsrc, (dma_lds_ptr_t)(wslot + NT * C::WFRAG + wave * 64 * 4), 16,
+                                                             tid * 16u, (unsigned)chunk * C::RFRAG * 4u, 0, 0);
+            }
         }
     };
 
@@ -202,6 +223,20 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[n], acc[m][n], 0, 0, 0);
+                    if (RV > 0 && do_rem) {
+                        float av[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) av[c] = in_s[vbase + (kg * 4 + c) * C::PLANE + ky * C::IW + kx];
+                        const f32x4 *wr = reinterpret_cast<const f32x4 *>(w_s + NT * C::WFRAG + (kg * C::KS2 + tap) * RV * 4);
+#pragma unroll
+                        for (int r = 0; r < RV; ++r) {
+                            const f32x4 w4 = wr[r];   // uniform address: LDS broadcast
+                            accv[r] += av[0] * w4[0];
+                            accv[r] += av[1] * w4[1];
+                            accv[r] += av[2] * w4[2];
+                            accv[r] += av[3] * w4[3];
+                        }
+                    }
                 }
             }
         }
@@ -265,6 +300,19 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
                 epi_store(a, b, co, oy, ox, v);
             }
         }
+        if (RV > 0 && do_rem) {   // remainder channels: lane = pixel, stores coalesced along the row
+            const int oy = tileY * C::TH + v_ty, ox = tileX * C::TW + v_tx;
+            if (oy < a.Hout && ox < a.Wout) {
+#pragma unroll
+                for (int r = 0; r < RV; ++r) {
+                    const int co = a.ntiles * 16 + r;
+                    if (co >= a.Cout) break;
+                    float v = accv[r] + a.bias[co];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.dst[((size_t)b * a.dst_ctotal + a.dst_choff + co) * ((size_t)a.Hout * a.Wout) + (size_t)oy * a.Wout + ox] = v;
+                }
+            }
+        }
     } else {
         // The pixel coordinates are laundered through an empty asm so that hipcc cannot hoist the (loop-invariant)
         // interpolation taps of all MP pixel groups above the main loop, where they cost ~100 live VGPRs (occupancy).
@@ -303,9 +351,9 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int KS, int STRIDE, int WM, int WK, int NT, int EPI>
+template <int KS, int STRIDE, int WM, int WK, int NT, int EPI, int RV = 0>
 static int launch_dma_epi(const ConvArgs &a0, int B, hipStream_t s) {
-    using C = DmaCfg<KS, STRIDE, WM, WK, NT>;
+    using C = DmaCfg<KS, STRIDE, WM, WK, NT, RV>;
     ConvArgs a = a0;
     a.tilesX = (a.Wout + C::TW - 1) / C::TW;
     a.tilesY = (a.Hout + C::TH - 1) / C::TH;
@@ -319,19 +367,20 @@ static int launch_dma_epi(const ConvArgs &a0, int B, hipStream_t s) {
     }
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI>),
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI, RV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
     char label[96];
     snprintf(label, sizeof(label), "void pf::conv_dma_kernel<%d, %d, %d, %d, %d>(pf::ConvArgs)", KS, STRIDE, WM, WK, NT);
+    if (RV) strncat(label, " +valu-rem", sizeof(label) - strlen(label) - 1);
     if (a.res) strncat(label, " +res", sizeof(label) - strlen(label) - 1);
     if (a.pool) strncat(label, " +pool", sizeof(label) - strlen(label) - 1);
     if (a.no_bias) strncat(label, " lowres-half", sizeof(label) - strlen(label) - 1);
     const double px = (double)B * a.Hout * a.Wout;
     ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * KS * KS,
                  4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * KS * KS));
-    hipLaunchKernelGGL((conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI>),
+    hipLaunchKernelGGL((conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI, RV>),
                        dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(64 * WM * WK), lds, s, a);
     PF_LAUNCH_CHECK("conv_dma_kernel");
     return PF_OK;
@@ -342,6 +391,15 @@ static int launch_dma_cfg(const ConvArgs &a, int B, hipStream_t s) {
     if (a.pool || a.res || a.no_bias) {
         if (KS == 1 && STRIDE == 1) return launch_dma_epi<KS, STRIDE, WM, WK, NT, (KS == 1 && STRIDE == 1) ? 1 : 0>(a, B, s);
         return fail(PF_EUNSUPPORTED, "conv_dma: fused epilogue stages are built for 1x1 convs only");
+    }
+    if (a.rem > 0) {   // remainder couts on the vector ALU (a.ntiles = FULL tiles)
+        if (KS == 3 && STRIDE == 1 && WM == 4 && WK == 1) {
+            constexpr bool ok = KS == 3 && STRIDE == 1 && WM == 4 && WK == 1;
+            if (a.rem <= 2) return launch_dma_epi<KS, STRIDE, WM, WK, NT, 0, ok ? 2 : 0>(a, B, s);
+            if (a.rem <= 4) return launch_dma_epi<KS, STRIDE, WM, WK, NT, 0, ok ? 4 : 0>(a, B, s);
+            return launch_dma_epi<KS, STRIDE, WM, WK, NT, 0, ok ? 8 : 0>(a, B, s);
+        }
+        return fail(PF_EUNSUPPORTED, "conv_dma: the vector-ALU remainder path is built for 3x3/s1, WM=4 only");
     }
     return launch_dma_epi<KS, STRIDE, WM, WK, NT, 0>(a, B, s);
 }
@@ -394,9 +452,12 @@ int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t s,
     int wm = 4, wk = 1, nt = 1;
     pick_shape(a, ks, stride, B, wm, wk, nt);
     if (force_wm > 0) {
+        const int model_nt = wm == force_wm ? nt : 2;
         wm = force_wm;
         wk = 4 / wm;
-        nt = force_nt < a.ntiles ? force_nt : a.ntiles;
+        nt = force_nt > 0 ? force_nt : model_nt;
+        nt = nt < a.ntiles ? nt : a.ntiles;
+        if (wm == 1 && nt > 2) nt = 2;
     }
 #define PF_CASE(KS_, ST_, WM_, WK_, NT_) \
     if (ks == KS_ && stride == ST_ && wm == WM_ && nt == NT_) return launch_dma_cfg<KS_, ST_, WM_, WK_, NT_>(a, B, s);
@@ -411,6 +472,24 @@ int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t s,
     PF_CASE(1, 1, 1, 4, 1) PF_CASE(1, 1, 1, 4, 2)
 #undef PF_CASE
     return fail(PF_EUNSUPPORTED, "conv_dma: no kernel for ks=%d stride=%d wm=%d nt=%d", ks, stride, wm, nt);
+}
+
+// [chunk][kgroup][tap][rv][4 channels]: the last cout % 16 output channels, zero padded to rv
+void pack_conv_weights_rem(const float *w, int cin, int cout, int ks, int kc, const int *src_ch, int n_src, float *out) {
+    const int ks2 = ks * ks, rem = cout % 16, rv = dma_rem_rv(rem), co0 = cout - rem;
+    size_t o = 0;
+    int c0 = 0;
+    for (int j = 0; j < n_src; ++j) {
+        for (int lc = 0; lc * kc < src_ch[j]; ++lc)
+            for (int kg = 0; kg < kc / 4; ++kg)
+                for (int tap = 0; tap < ks2; ++tap)
+                    for (int r = 0; r < rv; ++r)
+                        for (int c = 0; c < 4; ++c) {
+                            const int cl = lc * kc + kg * 4 + c;
+                            out[o++] = (r < rem && cl < src_ch[j]) ? w[((size_t)(co0 + r) * cin + c0 + cl) * ks2 + tap] : 0.f;
+                        }
+        c0 += src_ch[j];
+    }
 }
 
 int dma_chunks(const int *src_ch, int n_src, int ks, int stride) {

@@ -35,6 +35,8 @@ struct ConvArgs {
     int res_ctotal, res_choff, Hres, Wres;
     float res_sh, res_sw;    // (Hres-1)/(Hout-1), (Wres-1)/(Wout-1)
     int res_lds_off;         // float offset of the staged residual window in the kernel's LDS, or -1: sample from memory
+    const float *wrem;       // conv_dma remainder path: weights of the last `rem` couts, [chunk][kgroup][tap][RV][4 ch]
+    int rem;                 // > 0: couts handled on the vector ALU; ntiles then counts FULL 16-cout tiles only
     int src_begin, src_end;      // input ranges to accumulate (whole conv: 0, n_src)
     int chunk_begin, chunk_end;  // = src_chunk0[src_begin], src_chunk0[src_end] (filled at launch)
     long long *probe;        // PF_PROBE builds only: in-kernel timestamps of workgroup 0 / wave 0 (else nullptr)
@@ -62,6 +64,9 @@ int launch_conv(const ConvArgs &a, const ConvTiling &t, int B, hipStream_t strea
 constexpr int dma_kc_ct(int ks, int stride) { return ks == 1 ? 16 : (stride == 2 ? 4 : 8); }
 inline int dma_kc(int ks, int stride) { return dma_kc_ct(ks, stride); }
 int dma_chunks(const int *src_ch, int n_src, int ks, int stride);
+// remainder-cout weights for conv_dma's vector-ALU path: rv in {2,4,8} >= cout % 16
+inline int dma_rem_rv(int rem) { return rem <= 2 ? 2 : (rem <= 4 ? 4 : 8); }
+void pack_conv_weights_rem(const float *w_oihw, int cin, int cout, int ks, int kc, const int *src_ch, int n_src, float *out);
 void pack_conv_weights_tiled(const float *w_oihw, int cin, int cout, int ks, int kc, const int *src_ch, int n_src, float *out);
 // force_wm/force_nt > 0 override the cost model (tuning runs)
 int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t stream, int force_wm = 0, int force_nt = 0);

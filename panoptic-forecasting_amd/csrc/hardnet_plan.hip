@@ -23,6 +23,7 @@ struct ConvPlan {
     size_t dep_off = 0;   // stem only: depth-channel columns [tap][t][16]
     size_t tiled_off = 0; // per-cout-tile packing for the DMA fast path
     int tiled_chunks = 0;
+    size_t rem_off = 0;   // conv_dma vector-ALU remainder weights (3x3/s1 convs with 2 <= cout % 16 <= 8), else 0
     size_t wave_off = 0;  // fragment-order packing for the wave-autonomous path (stride 1 only)
     int wave_chunks = 0;
 };
@@ -39,7 +40,7 @@ struct pf_plan {
 };
 
 namespace pf {
-int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1;
+int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1;
 extern int g_opt_use_tuned;
 }
 
@@ -48,6 +49,7 @@ extern "C" int pf_set_option(const char *name, int value) {
     if (!strcmp(name, "fuse_pool")) g_opt_fuse_pool = value;
     else if (!strcmp(name, "fuse_upsample")) g_opt_fuse_upsample = value;
     else if (!strcmp(name, "use_tuned_table")) g_opt_use_tuned = value;
+    else if (!strcmp(name, "valu_remainder")) g_opt_valu_rem = value;
     else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);
     return PF_OK;
 }
@@ -188,7 +190,21 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.wpk = p->dev_weights + p->conv[i].tiled_off;
             a.nchunks = p->conv[i].tiled_chunks;
             set_chunks(dma_kc((int)o.k, (int)o.stride));
-            rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s, ch.p0, ch.p1);
+            // 2..8 leftover output channels of a big image go to the vector ALU instead of a padded MFMA tile
+            // (conv_dma WM=4 shapes only: forced or cost-model-chosen WM is checked inside, which falls back)
+            a.rem = 0;
+            if (g_opt_valu_rem && p->conv[i].rem_off && !need && a.src_begin == 0 && a.src_end == a.n_src &&
+                (ch.p0 == 0 || ch.p0 == 4)) {
+                a.rem = (int)o.cout % 16;
+                a.wrem = p->dev_weights + p->conv[i].rem_off;
+                a.ntiles = (int)o.cout / 16;
+                rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s, 4, ch.p0 == 4 && ch.p1 > 0 ? ch.p1 : 0);
+                if (rc == PF_EUNSUPPORTED) {
+                    a.rem = 0;
+                    a.ntiles = ((int)o.cout + 15) / 16;
+                }
+            }
+            if (a.rem == 0) rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s, ch.p0, ch.p1);
         }
         return rc;
     };
@@ -380,6 +396,13 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
             host.resize(host.size() + (size_t)((o.cout + 15) / 16) * c.tiled_chunks * (kc / 4) * o.k * o.k * 64);
             pack_conv_weights_tiled(wts + o.w_off, (int)o.cin, (int)o.cout, (int)o.k, kc, src_ch, (int)o.n_src,
                                     host.data() + c.tiled_off);
+        }
+        if (o.k == 3 && o.stride == 1 && o.cout >= 16 && o.cout % 16 >= 2 && o.cout % 16 <= 8) {
+            const int kc = dma_kc(3, 1), rv = dma_rem_rv((int)o.cout % 16);
+            host.resize(align_up(host.size(), 4), 0.f);
+            c.rem_off = host.size();
+            host.resize(host.size() + (size_t)c.tiled_chunks * (kc / 4) * 9 * rv * 4);
+            pack_conv_weights_rem(wts + o.w_off, (int)o.cin, (int)o.cout, 3, kc, src_ch, (int)o.n_src, host.data() + c.rem_off);
         }
         if (o.stride == 1) {
             c.wave_chunks = wave_chunks(src_ch, (int)o.n_src, (int)o.k);

@@ -174,3 +174,24 @@ def test_fused_pool_and_commuted_upsample(h, w, b, force, fuse_upsample, force_c
     assert (net.tensor('c3').cpu() - r3).abs().max() <= _tol(r3)
     assert (net.tensor('c4').cpu() - r4).abs().max() <= 2 * _tol(r4)
     net.close()
+
+
+@pytest.mark.parametrize('cin,cout,h,w', [(58, 18, 32, 64), (20, 36, 24, 40), (33, 24, 40, 96), (12, 20, 17, 32)])
+def test_valu_remainder_path(cin, cout, h, w, force_conv):
+    """cout % 16 in 2..8: conv_dma runs the full 16-cout tiles on the matrix cores and the leftover channels on
+    the vector ALU (forced to conv_dma WM=4 here; big images take this path by themselves)."""
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(2, cin, h, w, generator=g)
+    spec = MiniSpec(cin)
+    a, bch = cin // 3, cin - cin // 3
+    spec.conv('c', [arch.Src(0, bch, a), arch.Src(0, 0, bch)], cout, 3)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    force_conv(1, 4, 2, 0)
+    net = MiniNet(spec, {'c': (wt, bias)}).run(x.cuda())
+    ref = F.relu(F.conv2d(torch.cat([x[:, bch:], x[:, :bch]], 1), wt, bias, padding=1))
+    err = (net.tensor('c').cpu() - ref).abs().max().item()
+    assert err <= _tol(ref), (err, _tol(ref))
+    net.close()
