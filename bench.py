@@ -66,7 +66,8 @@ def pmc_traffic(kernel_label):
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        k = json.load(f).get('kernels', {}).get(kernel_label)
+        # labels are the rocprofv3 symbol + optional " +res"/" +pool"/" lowres-half" annotations of the launch
+        k = json.load(f).get('kernels', {}).get(kernel_label.split(')')[0] + ')')
     return k.get('hbm_bytes_per_launch') if k else None
 
 

@@ -111,6 +111,57 @@ int pf_hardnet_forward_dense(const pf_plan *plan, const float *x, int B, int H, 
                              int out_w, void *out_seg, int out_seg_is_i64, float *out_logits,
                              float *out_orig_logits, void *ws, size_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The on-disk hop between the reference's tasks, device side.  Elementwise, HBM-bound.
+ *
+ * pf_hop_export — what export_results applies to a prediction before the PNG encoder
+ * (experiments/export_cityscapes_segmentation_results.py):
+ *   seg [n] u8 or i64 (nullable) -> out_seg [n] u8; seg_mode 0 = as is (--no_convert), 1 = trainId -> label id
+ *   (convert_labels :27-32, values outside 0..18 -> 0), 2 = label id -> trainId (convert_labels_to_trainid :34-38,
+ *   ids outside the table -> 0);  depth [n] f32 (nullable) -> out_depth_u16 [n] = round(clamp(d+1,0,255)*256) (:119-121).
+ * pf_hop_load — what BGDataset.__getitem__ applies to the u16 depth it reads (data/datasets/bg_dataset.py:224-228,
+ *   166-170): d = q/256 - 1, mask = d > 0, d[~mask] = -1, masked values clamped to [min_depth, max_depth].
+ * All buffers 16-byte aligned device pointers.
+ */
+int pf_hop_export(const void *seg, int seg_is_i64, int seg_mode, const float *depth, size_t n, uint8_t *out_seg,
+                  uint16_t *out_depth_u16, void *stream);
+int pf_hop_load(const uint16_t *depth_u16, size_t n, float min_depth, float max_depth, float *out_depth,
+                uint8_t *out_mask, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fg -> panoptic merge — replaces the pasting loops of FGModel.predict_panoptic
+ * (models/fg/fg_model.py:548-588; panoptic_ids=1, clear_things=1) and FGModel.predict_semantics (:455-480; panoptic_ids=0,
+ * clear_things=0) together with model_utils.paste_mask (models/fg/model_utils.py:30-57).
+ *
+ *   background    [B,H,W] u8 / i32 / i64 (bg_kind 0/1/2) trainId canvas, or NULL (canvas of 255, :517-518)
+ *   bg_depth      [B,H,W] f32 or NULL;  bg_depth_mask [B,H,W] u8 or NULL (0 -> depth 1e9, :563-564)
+ *   masks         [N,MH,MW] f32 mask PROBABILITIES (after the sigmoid of :532), all images concatenated
+ *   boxes         [N,4] f32 (cx,cy,w,h), or (x0,y0,x1,y1) when box_is_ulbr
+ *   inst_depth    [N] f32 forecast depth per instance (required with use_depth_sorting)
+ *   classes       [N] i64 thing class (0..7);  inst_offsets [B+1] i32: image b owns instances [off[b], off[b+1])
+ *   out           [B,H,W] i32 or i64
+ * Paste order: descending depth, stable (ATen's CPU sort) when use_depth_sorting, else index order.  A pixel takes
+ * an instance's value where its bilinearly pasted mask is >= 0.5 and - when bg_depth is given - its depth is strictly
+ * nearer than the current one (:580-585); value = (class+11)*1000 + running per-class id (:568-572) or class+11.
+ * The mask sampling reproduces F.grid_sample(bilinear, zeros, align_corners=False) of ATen's vectorised CPU kernel
+ * bit for bit.  Unlike the reference, the caller's bg_depth tensor is not modified.  W % 4 == 0.
+ * Workspace: pf_panoptic_merge_workspace(n_instances) bytes.
+ *
+ * pf_panoptic_encode — export_cityscapes_panoptic_results.py:27-68: ids converted to Cityscapes ids when
+ * convert_to_ids (255 -> 0; v > 100: id(cat)*1000 + inst; else id(v)), out_rgb [B,H,W,3] = (id%256, id/256%256,
+ * id/65536), out_ids (nullable) [B,H,W] i32, out_present [B, pf_panoptic_max_ids()] u8 = 1 for every id that occurs
+ * (get_segments_info's np.unique).  H*W % 4 == 0.
+ */
+int pf_panoptic_merge_workspace(int n_instances, size_t *bytes);
+int pf_panoptic_merge(const void *background, int bg_kind, const float *bg_depth, const uint8_t *bg_depth_mask,
+                      const float *masks, int MH, int MW, const float *boxes, int box_is_ulbr,
+                      const float *inst_depth, const int64_t *classes, const int32_t *inst_offsets,
+                      int n_instances, int B, int H, int W, int use_depth_sorting, int panoptic_ids,
+                      int clear_things, void *out, int out_is_i64, void *ws, size_t ws_bytes, void *stream);
+int pf_panoptic_encode(const void *seg, int seg_is_i64, int convert_to_ids, int B, int H, int W, uint8_t *out_rgb,
+                       int32_t *out_ids, uint8_t *out_present, void *stream);
+int pf_panoptic_max_ids(void);
+
 /* Process-wide execution options (not thread-safe; set before launching work):
  *   "fuse_pool"     (default 1) a 1x1 conv followed by AvgPool2d(2,2) (hardnet.py:296) pools in the conv epilogue;
  *   "fuse_upsample" (default 1) TransitionUp + 1x1 conv over cat([up(x), skip]) (hardnet.py:248-258,365-368) is

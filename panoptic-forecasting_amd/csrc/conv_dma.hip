@@ -372,8 +372,7 @@ static int launch_dma_epi(const ConvArgs &a0, int B, hipStream_t s) {
         attr_lds = lds;
     }
     char label[96];
-    snprintf(label, sizeof(label), "void pf::conv_dma_kernel<%d, %d, %d, %d, %d>(pf::ConvArgs)", KS, STRIDE, WM, WK, NT);
-    if (RV) strncat(label, " +valu-rem", sizeof(label) - strlen(label) - 1);
+    snprintf(label, sizeof(label), "void pf::conv_dma_kernel<%d, %d, %d, %d, %d, %d, %d>(pf::ConvArgs)", KS, STRIDE, WM, WK, NT, EPI, RV);
     if (a.res) strncat(label, " +res", sizeof(label) - strlen(label) - 1);
     if (a.pool) strncat(label, " +pool", sizeof(label) - strlen(label) - 1);
     if (a.no_bias) strncat(label, " lowres-half", sizeof(label) - strlen(label) - 1);

@@ -325,7 +325,7 @@ static int launch_wave_epi(const ConvArgs &a0, int B, hipStream_t s) {
         attr_lds = lds;
     }
     char label[96];
-    snprintf(label, sizeof(label), "void pf::conv_wave_kernel<%d, %d, %d, %d>(pf::ConvArgs)", KS, MH, NT, WK);
+    snprintf(label, sizeof(label), "void pf::conv_wave_kernel<%d, %d, %d, %d, %d>(pf::ConvArgs)", KS, MH, NT, WK, EPI);
     if (a.res) strncat(label, " +res", sizeof(label) - strlen(label) - 1);
     if (a.pool) strncat(label, " +pool", sizeof(label) - strlen(label) - 1);
     if (a.no_bias) strncat(label, " lowres-half", sizeof(label) - strlen(label) - 1);

@@ -27,6 +27,13 @@ SIGNATURES = {
     'pf_hardnet_tensor_view': (_i, [_vp, _c.c_char_p, _i, _i, _i, _c.POINTER(_sz), _c.POINTER(_i),
                                     _c.POINTER(_i), _c.POINTER(_i)]),
     'pf_hardnet_flops': (_i, [_vp, _i, _i, _c.POINTER(_c.c_double)]),
+    'pf_hop_export': (_i, [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    'pf_hop_load': (_i, [_vp, _sz, _f, _f, _vp, _vp, _vp]),
+    'pf_panoptic_merge_workspace': (_i, [_i, _c.POINTER(_sz)]),
+    'pf_panoptic_merge': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
+                               _vp, _i, _vp, _sz, _vp]),
+    'pf_panoptic_encode': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'pf_panoptic_max_ids': (_i, []),
     'pf_set_option': (_i, [_c.c_char_p, _i]),
     'pf_debug_force_conv': (_i, [_i, _i, _i, _i]),
     'pf_debug_probe_read': (_i, [_c.POINTER(_c.c_longlong)]),
