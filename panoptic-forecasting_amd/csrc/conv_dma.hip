@@ -49,7 +49,7 @@ struct DmaCfg {
     static constexpr int PP = PLANE / 4, RP = RAW / 4, RW = IW / 4;  // 16-B pieces per plane / real / per row
     static constexpr int KS2 = KS * KS;
     static constexpr int WFRAG = (KC / 4) * KS2 * 64;  // floats per (cout tile, chunk)
-    static constexpr int RFRAG = (KC / 4) * KS2 * RV * 4;  // remainder-cout weights per chunk: [kgroup][tap][RV][4 ch]
+    static constexpr int RFRAG = (KC / 4) * KS2 * RV * 4;  // vector-ALU cout weights per chunk: [kgroup][tap][RV/4][4 ch][4 couts]
     static constexpr int SLOT = KC * PLANE + NT * WFRAG + RFRAG;  // floats per K-split slot
     static constexpr int BUF = WK * SLOT;
     static constexpr int RED = (WK - 1) * WM * MP * NT * 256;
@@ -62,15 +62,25 @@ typedef __attribute__((address_space(3))) void *dma_lds_ptr_t;
 
 // EPI: 0 = bias + ReLU (the common case keeps its register budget), 1 = fused stages of conv_epilogue.h (2x2 pool,
 // upsampled residual) - separate instantiations because the fused epilogue needs ~70 more VGPRs.
-// RV > 0: the last Cout % 16 <= RV output channels are NOT padded to a 16-wide MFMA tile (37-44 % of the matrix work
-// of a 18- or 10-channel HarDBlock layer would be zeros); they are accumulated on the vector ALU instead - one lane
-// per pixel, A operands from the same LDS tile, weights as broadcast reads - in the issue shadow of the MFMAs of the
-// full tiles (each v_mfma_f32_16x16x4_f32 occupies the matrix pipe for 32 cycles = 8 free issue slots).
+// RV > 0 (a multiple of 4): the last `a.rem` <= RV output channels do not go through the matrix pipe at all.  On gfx950 the
+// fp32 vector ALU has the same peak as the fp32 MFMA (157 TF/s) and the two pipes run concurrently, so these channels
+// are accumulated on the vector ALU in the issue shadow of the MFMAs of the full tiles: a 28-channel HarDBlock layer
+// runs as one 16-wide MFMA tile + 12 VALU channels instead of two MFMA tiles (12.5 % of them zeros).  Per k-group/tap:
+//   * the A operands the MFMAs just used (lane = pixel l&15 of M-tile m, channel l>>4) are turned into the VALU layout
+//     (lane = pixel l&15 of M-tile l>>4, registers = the 4 channels) by a 4x4 block transpose in registers:
+//     2 x v_permlane32_swap + 2 x v_permlane16_swap (gfx950) - no second LDS read of the input tile;
+//   * the weights of 4 output channels x 4 input channels arrive with ONE ds_read_b128 per wave: lane l reads the 16-B
+//     piece of input channel l&3 (4 distinct addresses: a broadcast read), and each FMA picks "its" channel's weight
+//     out of the quad with a DPP quad_perm on the multiplier (v_fmac_f32_dpp): no broadcast instruction, no SGPRs.
+// (hipcc's __builtin_amdgcn_permlane*_swap returns the same register for both results on ROCm 7.2, hence inline asm;
+// the s_nop's are the VALU-write -> permlane-swap-read wait states the compiler would insert.)
+#define PF_FMAC_QUAD(acc, w, x, C) \
+    asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #C "," #C "," #C "," #C "] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(x))
 template <int KS, int STRIDE, int WM, int WK, int NT, int EPI, int RV>
 __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtin types in the body; the host pass only needs the stub
     using C = DmaCfg<KS, STRIDE, WM, WK, NT, RV>;
-    static_assert(RV == 0 || (WK == 1 && EPI == 0), "the vector-ALU remainder path is built for WK = 1, plain epilogue");
+    static_assert(RV == 0 || (WK == 1 && EPI == 0 && C::MP == 4 && (RV == 2 || RV % 4 == 0)), "the vector-ALU path is built for WK = 1, plain epilogue");
     constexpr int NTHR = 64 * WM * WK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -98,7 +108,6 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
     // vector-ALU remainder: this lane's pixel inside the tile and its accumulators
     const bool do_rem = RV > 0 && (int)blockIdx.y == (int)gridDim.y - 1;
     const int v_mt = wm * C::MP + (lane >> 4), v_ty = v_mt / C::TWT, v_tx = (v_mt % C::TWT) * 16 + (lane & 15);
-    const int vbase = v_ty * STRIDE * C::IW + v_tx * STRIDE + (C::APRON - KS / 2);
     float accv[RV > 0 ? RV : 1];
 #pragma unroll
     for (int r = 0; r < (RV > 0 ? RV : 1); ++r) accv[r] = 0.f;
@@ -187,11 +196,13 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
                 if (it * NTHR + tid < NPW)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (dma_lds_ptr_t)(wslot + (it * NTHR + wave * 64) * 4), 16,
                                                              woff[it], wsoff, 0, 0);
-            if (RV > 0 && do_rem) {   // remainder weights of the chunk: RFRAG/4 <= NTHR pieces
-                static_assert(C::RFRAG / 4 <= NTHR, "one DMA instruction per thread");
-                if (tid < C::RFRAG / 4)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rrsrc, (dma_lds_ptr_t)(wslot + NT * C::WFRAG + wave * 64 * 4), 16,
-                                                             tid * 16u, (unsigned)chunk * C::RFRAG * 4u, 0, 0);
+            if (RV > 0 && do_rem) {   // vector-ALU weights of the chunk
+                constexpr int NPR = C::RFRAG / 4, NITR = (NPR + NTHR - 1) / NTHR;
+#pragma unroll
+                for (int it = 0; it < NITR; ++it)
+                    if (it * NTHR + tid < NPR)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rrsrc, (dma_lds_ptr_t)(wslot + NT * C::WFRAG + (it * NTHR + wave * 64) * 4), 16,
+                                                                 (it * NTHR + tid) * 16u, (unsigned)chunk * C::RFRAG * 4u, 0, 0);
             }
         }
     };
@@ -224,17 +235,33 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
                         for (int n = 0; n < NT; ++n)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[n], acc[m][n], 0, 0, 0);
                     if (RV > 0 && do_rem) {
-                        float av[4];
+                        float x0 = af[0], x1 = af[1], x2 = af[2], x3 = af[3];   // [M-tile][channel row] -> [channel][M-tile row]
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1\n\t"
+                                     "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+                        if (RV == 2) {   // two channels: two uniform (broadcast) 16-B weight reads and plain FMAs beat the DPP form
+                            const f32x4 *wu = reinterpret_cast<const f32x4 *>(w_s + NT * C::WFRAG + (kg * C::KS2 + tap) * RV * 4);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) av[c] = in_s[vbase + (kg * 4 + c) * C::PLANE + ky * C::IW + kx];
-                        const f32x4 *wr = reinterpret_cast<const f32x4 *>(w_s + NT * C::WFRAG + (kg * C::KS2 + tap) * RV * 4);
+                            for (int r = 0; r < 2; ++r) {
+                                const f32x4 w4 = wu[r];
+                                accv[r] = fmaf(x0, w4[0], accv[r]);
+                                accv[r] = fmaf(x1, w4[1], accv[r]);
+                                accv[r] = fmaf(x2, w4[2], accv[r]);
+                                accv[r] = fmaf(x3, w4[3], accv[r]);
+                            }
+                        }
+                        const f32x4 *wr = reinterpret_cast<const f32x4 *>(w_s + NT * C::WFRAG + (kg * C::KS2 + tap) * RV * 4) + (lane & 3);
 #pragma unroll
-                        for (int r = 0; r < RV; ++r) {
-                            const f32x4 w4 = wr[r];   // uniform address: LDS broadcast
-                            accv[r] += av[0] * w4[0];
-                            accv[r] += av[1] * w4[1];
-                            accv[r] += av[2] * w4[2];
-                            accv[r] += av[3] * w4[3];
+                        for (int g = 0; g < RV / 4; ++g) {
+                            const f32x4 w4 = wr[g * 4];   // lane l: weights of couts 4g..4g+3 for input channel l&3
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float w = w4[j];
+                                PF_FMAC_QUAD(accv[g * 4 + j], w, x0, 0);
+                                PF_FMAC_QUAD(accv[g * 4 + j], w, x1, 1);
+                                PF_FMAC_QUAD(accv[g * 4 + j], w, x2, 2);
+                                PF_FMAC_QUAD(accv[g * 4 + j], w, x3, 3);
+                            }
                         }
                     }
                 }
@@ -391,14 +418,16 @@ static int launch_dma_cfg(const ConvArgs &a, int B, hipStream_t s) {
         if (KS == 1 && STRIDE == 1) return launch_dma_epi<KS, STRIDE, WM, WK, NT, (KS == 1 && STRIDE == 1) ? 1 : 0>(a, B, s);
         return fail(PF_EUNSUPPORTED, "conv_dma: fused epilogue stages are built for 1x1 convs only");
     }
-    if (a.rem > 0) {   // remainder couts on the vector ALU (a.ntiles = FULL tiles)
-        if (KS == 3 && STRIDE == 1 && WM == 4 && WK == 1) {
-            constexpr bool ok = KS == 3 && STRIDE == 1 && WM == 4 && WK == 1;
+    if (a.rem > 0) {   // the last a.rem couts on the vector ALU (a.ntiles = tiles that go through the matrix pipe)
+        if (KS == 3 && STRIDE == 1 && WM == 4 && WK == 1 && NT <= 3) {
+            constexpr bool ok = KS == 3 && STRIDE == 1 && WM == 4 && WK == 1 && NT <= 3;
             if (a.rem <= 2) return launch_dma_epi<KS, STRIDE, WM, WK, NT, 0, ok ? 2 : 0>(a, B, s);
             if (a.rem <= 4) return launch_dma_epi<KS, STRIDE, WM, WK, NT, 0, ok ? 4 : 0>(a, B, s);
-            return launch_dma_epi<KS, STRIDE, WM, WK, NT, 0, ok ? 8 : 0>(a, B, s);
+            if (a.rem <= 8) return launch_dma_epi<KS, STRIDE, WM, WK, NT, 0, ok ? 8 : 0>(a, B, s);
+            if (a.rem <= 12) return launch_dma_epi<KS, STRIDE, WM, WK, NT, 0, ok ? 12 : 0>(a, B, s);
+            if (a.rem <= 16) return launch_dma_epi<KS, STRIDE, WM, WK, NT, 0, ok ? 16 : 0>(a, B, s);
         }
-        return fail(PF_EUNSUPPORTED, "conv_dma: the vector-ALU remainder path is built for 3x3/s1, WM=4 only");
+        return fail(PF_EUNSUPPORTED, "conv_dma: the vector-ALU cout path is built for 3x3/s1, WM=4, NT<=3, <=16 channels");
     }
     return launch_dma_epi<KS, STRIDE, WM, WK, NT, 0>(a, B, s);
 }
@@ -473,20 +502,31 @@ int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t s,
     return fail(PF_EUNSUPPORTED, "conv_dma: no kernel for ks=%d stride=%d wm=%d nt=%d", ks, stride, wm, nt);
 }
 
-// [chunk][kgroup][tap][rv][4 channels]: the last cout % 16 output channels, zero padded to rv
-void pack_conv_weights_rem(const float *w, int cin, int cout, int ks, int kc, const int *src_ch, int n_src, float *out) {
-    const int ks2 = ks * ks, rem = cout % 16, rv = dma_rem_rv(rem), co0 = cout - rem;
+// [chunk][kgroup][tap][rv/4][4 input channels][4 couts] (rv = 2: [chunk][kgroup][tap][2 couts][4 input channels]):
+// the last `rem` output channels, zero padded to rv = dma_rem_rv(rem)
+void pack_conv_weights_rem(const float *w, int cin, int cout, int rem, int ks, int kc, const int *src_ch, int n_src, float *out) {
+    const int ks2 = ks * ks, rv = dma_rem_rv(rem), co0 = cout - rem;
     size_t o = 0;
     int c0 = 0;
     for (int j = 0; j < n_src; ++j) {
         for (int lc = 0; lc * kc < src_ch[j]; ++lc)
             for (int kg = 0; kg < kc / 4; ++kg)
-                for (int tap = 0; tap < ks2; ++tap)
-                    for (int r = 0; r < rv; ++r)
-                        for (int c = 0; c < 4; ++c) {
-                            const int cl = lc * kc + kg * 4 + c;
-                            out[o++] = (r < rem && cl < src_ch[j]) ? w[((size_t)(co0 + r) * cin + c0 + cl) * ks2 + tap] : 0.f;
-                        }
+                for (int tap = 0; tap < ks2; ++tap) {
+                    if (rv == 2) {   // [cout][4 input channels]: read as two uniform 16-B rows
+                        for (int r = 0; r < 2; ++r)
+                            for (int c = 0; c < 4; ++c) {
+                                const int cl = lc * kc + kg * 4 + c;
+                                out[o++] = (r < rem && cl < src_ch[j]) ? w[((size_t)(co0 + r) * cin + c0 + cl) * ks2 + tap] : 0.f;
+                            }
+                        continue;
+                    }
+                    for (int g = 0; g < rv / 4; ++g)
+                        for (int c = 0; c < 4; ++c)
+                            for (int q = 0; q < 4; ++q) {
+                                const int cl = lc * kc + kg * 4 + c, r = g * 4 + q;
+                                out[o++] = (r < rem && cl < src_ch[j]) ? w[((size_t)(co0 + r) * cin + c0 + cl) * ks2 + tap] : 0.f;
+                            }
+                }
         c0 += src_ch[j];
     }
 }

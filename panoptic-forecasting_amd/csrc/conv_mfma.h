@@ -64,9 +64,17 @@ int launch_conv(const ConvArgs &a, const ConvTiling &t, int B, hipStream_t strea
 constexpr int dma_kc_ct(int ks, int stride) { return ks == 1 ? 16 : (stride == 2 ? 4 : 8); }
 inline int dma_kc(int ks, int stride) { return dma_kc_ct(ks, stride); }
 int dma_chunks(const int *src_ch, int n_src, int ks, int stride);
-// remainder-cout weights for conv_dma's vector-ALU path: rv in {2,4,8} >= cout % 16
-inline int dma_rem_rv(int rem) { return rem <= 2 ? 2 : (rem <= 4 ? 4 : 8); }
-void pack_conv_weights_rem(const float *w_oihw, int cin, int cout, int ks, int kc, const int *src_ch, int n_src, float *out);
+// conv_dma's vector-ALU cout path: the last `rem` (1..16) output channels; accumulators rv in {2,4,8,12,16} >= rem
+inline int dma_rem_rv(int rem) { return rem <= 2 ? 2 : (rem + 3) / 4 * 4; }
+// how many trailing output channels of a 3x3/s1 conv go to the vector ALU (0 = none): the partial tile, or with
+// peel_full a whole 16-wide tile of a conv whose cout is a multiple of 16
+inline int dma_valu_split(int cout, bool peel_full) {
+    if (cout < 16) return 0;
+    const int r = cout % 16;
+    if (r == 0) return (peel_full && cout >= 32) ? 16 : 0;
+    return r;
+}
+void pack_conv_weights_rem(const float *w_oihw, int cin, int cout, int rem, int ks, int kc, const int *src_ch, int n_src, float *out);
 void pack_conv_weights_tiled(const float *w_oihw, int cin, int cout, int ks, int kc, const int *src_ch, int n_src, float *out);
 // force_wm/force_nt > 0 override the cost model (tuning runs)
 int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t stream, int force_wm = 0, int force_nt = 0);
@@ -81,8 +89,17 @@ void pack_conv_weights_wave(const float *w_oihw, int cin, int cout, int ks, cons
 size_t wave_packed_floats(const int *src_ch, int n_src, int cout, int ks);
 int launch_conv_wave(const ConvArgs &a, int ks, int mh, int nt, int wk, int B, hipStream_t stream);
 
+// Vector-ALU path (conv_valu.hip; 3x3/s1, Win % 4 == 0, no fused epilogue): a.wpk must point at
+// pack_conv_weights_valu() output, chunks of kValuKc channels.  rows = output rows per wave (1 or 2).
+constexpr int kValuKc = 4;
+bool conv_valu_supports(int cout);
+int valu_chunks(const int *src_ch, int n_src);
+size_t valu_packed_floats(const int *src_ch, int n_src, int cout);
+void pack_conv_weights_valu(const float *w_oihw, int cin, int cout, const int *src_ch, int n_src, float *out);
+int launch_conv_valu(const ConvArgs &a, int rows, int B, hipStream_t stream);
+
 // Kernel/shape choice for one stride-1 conv (conv_select.cpp): kind 1 = conv_dma (p0 = WM, p1 = NT),
-// kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK).
+// kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK), kind 3 = conv_valu (p0 = rows per wave).
 struct ConvChoice {
     int kind, p0, p1, p2;
 };

@@ -23,9 +23,12 @@ struct ConvPlan {
     size_t dep_off = 0;   // stem only: depth-channel columns [tap][t][16]
     size_t tiled_off = 0; // per-cout-tile packing for the DMA fast path
     int tiled_chunks = 0;
-    size_t rem_off = 0;   // conv_dma vector-ALU remainder weights (3x3/s1 convs with 2 <= cout % 16 <= 8), else 0
+    size_t rem_off = 0;   // conv_dma vector-ALU cout weights (3x3/s1 convs, rem_count trailing couts), else 0
+    int rem_count = 0;
     size_t wave_off = 0;  // fragment-order packing for the wave-autonomous path (stride 1 only)
     int wave_chunks = 0;
+    size_t valu_off = 0;  // [chunk][ch][tap][cout] rows for the vector-ALU path (3x3/s1 with a supported cout), else 0
+    bool has_valu = false;
 };
 
 struct pf_plan {
@@ -171,6 +174,8 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             if ((need & 2) && ch.p0 == 1) ch.p0 = 2;
         }
         if (g_conv_force.kind == 1) ch = g_conv_force;
+        if (g_conv_force.kind == 3 && p->conv[i].has_valu && !need) ch = g_conv_force;
+        if (ch.kind == 3 && (!p->conv[i].has_valu || need)) ch = ConvChoice{1, 0, 0, 0};
         int rc = PF_EUNSUPPORTED;
         auto set_chunks = [&](int kc) {
             a.src_chunk0[0] = 0;
@@ -179,6 +184,13 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.chunk_begin = a.src_chunk0[a.src_begin];
             a.chunk_end = a.src_chunk0[a.src_end];
         };
+        if (ch.kind == 3) {
+            a.wpk = p->dev_weights + p->conv[i].valu_off;
+            set_chunks(kValuKc);
+            rc = launch_conv_valu(a, ch.p0 == 1 ? 1 : 2, B, s);
+            if (rc != PF_EUNSUPPORTED) return rc;
+            ch = ConvChoice{1, 0, 0, 0};
+        }
         if (ch.kind == 2) {
             a.wpk = p->dev_weights + p->conv[i].wave_off;
             a.nchunks = p->conv[i].wave_chunks;
@@ -190,14 +202,14 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.wpk = p->dev_weights + p->conv[i].tiled_off;
             a.nchunks = p->conv[i].tiled_chunks;
             set_chunks(dma_kc((int)o.k, (int)o.stride));
-            // 2..8 leftover output channels of a big image go to the vector ALU instead of a padded MFMA tile
+            // the trailing rem_count output channels of a big image go to the vector ALU instead of an MFMA tile
             // (conv_dma WM=4 shapes only: forced or cost-model-chosen WM is checked inside, which falls back)
             a.rem = 0;
             if (g_opt_valu_rem && p->conv[i].rem_off && !need && a.src_begin == 0 && a.src_end == a.n_src &&
                 (ch.p0 == 0 || ch.p0 == 4)) {
-                a.rem = (int)o.cout % 16;
+                a.rem = p->conv[i].rem_count;
                 a.wrem = p->dev_weights + p->conv[i].rem_off;
-                a.ntiles = (int)o.cout / 16;
+                a.ntiles = ((int)o.cout - a.rem) / 16;
                 rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s, 4, ch.p0 == 4 && ch.p1 > 0 ? ch.p1 : 0);
                 if (rc == PF_EUNSUPPORTED) {
                     a.rem = 0;
@@ -397,12 +409,25 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
             pack_conv_weights_tiled(wts + o.w_off, (int)o.cin, (int)o.cout, (int)o.k, kc, src_ch, (int)o.n_src,
                                     host.data() + c.tiled_off);
         }
-        if (o.k == 3 && o.stride == 1 && o.cout >= 16 && o.cout % 16 >= 2 && o.cout % 16 <= 8) {
-            const int kc = dma_kc(3, 1), rv = dma_rem_rv((int)o.cout % 16);
+        // trailing couts that may run on the vector ALU beside the MFMA tiles (conv_dma.hip); env knobs for A/B runs:
+        // PF_VALU_MAX = largest such group (default 8: beyond that the padded MFMA tile measured faster; 0 disables), PF_VALU_PEEL = 1 also peels a full tile of cout % 16 == 0
+        static const int valu_max = getenv("PF_VALU_MAX") ? atoi(getenv("PF_VALU_MAX")) : 8;
+        static const bool valu_peel = getenv("PF_VALU_PEEL") ? atoi(getenv("PF_VALU_PEEL")) != 0 : false;
+        const int split = (o.k == 3 && o.stride == 1) ? dma_valu_split((int)o.cout, valu_peel) : 0;
+        if (split > 0 && split <= valu_max) {
+            const int kc = dma_kc(3, 1), rv = dma_rem_rv(split);
             host.resize(align_up(host.size(), 4), 0.f);
             c.rem_off = host.size();
+            c.rem_count = split;
             host.resize(host.size() + (size_t)c.tiled_chunks * (kc / 4) * 9 * rv * 4);
-            pack_conv_weights_rem(wts + o.w_off, (int)o.cin, (int)o.cout, 3, kc, src_ch, (int)o.n_src, host.data() + c.rem_off);
+            pack_conv_weights_rem(wts + o.w_off, (int)o.cin, (int)o.cout, split, 3, kc, src_ch, (int)o.n_src, host.data() + c.rem_off);
+        }
+        if (o.k == 3 && o.stride == 1 && conv_valu_supports((int)o.cout)) {
+            host.resize(align_up(host.size(), 16), 0.f);
+            c.valu_off = host.size();
+            c.has_valu = true;
+            host.resize(host.size() + valu_packed_floats(src_ch, (int)o.n_src, (int)o.cout));
+            pack_conv_weights_valu(wts + o.w_off, (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, host.data() + c.valu_off);
         }
         if (o.stride == 1) {
             c.wave_chunks = wave_chunks(src_ch, (int)o.n_src, (int)o.k);

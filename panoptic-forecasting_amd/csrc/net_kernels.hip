@@ -8,6 +8,8 @@
 //   avgpool2_kernel    : nn.AvgPool2d(2,2)                     hardnet.py:296
 //   upsample_kernel    : F.interpolate(bilinear, align_corners) hardnet.py:248-253
 //   head_kernel        : final bilinear upsample + argmax      hardnet.py:372-384, bg_model.py:98
+#include <cstdlib>
+
 #include "net_kernels.h"
 #include "conv_epilogue.h"
 #include "pf_prof.h"
@@ -80,6 +82,94 @@ __global__ __launch_bounds__(256) void stem_onehot_kernel(StemArgs a) {
                     acc[q * 4 + 2] += r[2] * dn; acc[q * 4 + 3] += r[3] * dn;
                 }
             }
+        }
+    }
+    const size_t op = (size_t)a.Hout * a.Wout;
+    float *o = a.dst + (size_t)b * 16 * op + (size_t)oy * a.Wout + ox;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i * op] = fmaxf(acc[i], 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem, latency-organised (T compile-time): the generic kernel above walks its 9*T taps one dependent
+// load -> LUT -> weight-row chain at a time (54 serial HBM round trips per wave; profiles/r01_e: 193 us at B=4 for
+// 65 us of traffic).  Here every lane first issues ALL its 9*T label and depth loads (clamped addresses, no branches
+// in between, so they are in flight together), and only then consumes them; the depth-channel weights are uniform
+// per (tap, t) and come through the scalar cache (a.wdep, [tap][t][16]) instead of LDS, which halves the LDS reads.
+template <int T, bool SEG64>
+__global__ __launch_bounds__(256) void stem_onehot_batched_kernel(StemArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [tap][ch][16]
+    __shared__ uint8_t lut[256];
+    const int in_ch = T * (a.n_cls + 1);
+    for (int e = threadIdx.x; e < 9 * in_ch * 16; e += 256) {
+        const int co = e & 15, ch = (e >> 4) % in_ch, tap = (e >> 4) / in_ch;
+        wl[e] = a.w[((size_t)co * in_ch + ch) * 9 + tap];
+    }
+    lut[threadIdx.x] = (a.hop & PF_HOP_TRAINID_LUT) ? a.lut[threadIdx.x] : (uint8_t)threadIdx.x;
+    __syncthreads();
+
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (ox >= a.Wout || oy >= a.Hout) return;
+    const size_t N = (size_t)a.H * a.W;
+    const bool hop_d = (a.hop & PF_HOP_DEPTH_U16) != 0;
+
+    // ---- phase 1: all loads
+    int lab[9 * T];
+    float dep[9 * T];
+    uint8_t msk[9 * T];
+    unsigned okbits = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
+        const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        okbits |= ok ? (1u << tap) : 0u;
+        const size_t pix = (size_t)(ok ? iy : 0) * a.W + (ok ? ix : 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const size_t idx = ((size_t)b * T + t) * N + pix;
+            lab[tap * T + t] = SEG64 ? (int)reinterpret_cast<const long long *>(a.seg)[idx]
+                                     : (int)reinterpret_cast<const uint8_t *>(a.seg)[idx];
+            dep[tap * T + t] = a.depth[idx];
+            msk[tap * T + t] = hop_d ? (uint8_t)0 : a.mask[idx];
+        }
+    }
+
+    // ---- phase 2
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = a.bias[i];
+    const float mean_ = a.depth_mean, std_ = a.depth_std;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const bool ok = (okbits >> tap) & 1u;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            int cls = lab[tap * T + t];
+            if (a.hop & PF_HOP_TRAINID_LUT) cls = lut[cls & 255];
+            if (ok && cls >= 0 && cls < a.n_cls) {     // labels >= n_cls contribute nothing (bg_model.py:54-57)
+                const f32x4v *row = reinterpret_cast<const f32x4v *>(wl + (tap * in_ch + t * a.n_cls + cls) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4v r = row[q];
+                    acc[q * 4 + 0] += r[0]; acc[q * 4 + 1] += r[1]; acc[q * 4 + 2] += r[2]; acc[q * 4 + 3] += r[3];
+                }
+            }
+            float d = dep[tap * T + t], m;
+            if (hop_d) {
+                const float q = rintf(fminf(fmaxf(d + 1.f, 0.f), 255.f) * 256.f);  // export :119-124
+                d = q / 256.f - 1.f;                                                // load bg_dataset.py:225
+                const bool mk = d > 0.f;
+                d = mk ? fminf(fmaxf(d, a.min_depth), a.max_depth) : -1.f;           // :227-228,:166-170
+                m = mk ? 1.f : 0.f;
+            } else {
+                m = msk[tap * T + t] ? 1.f : 0.f;
+            }
+            const float dn = ok ? ((d - mean_) / std_) * m : 0.f;                    // (bg_model.py:50-51,66-67)
+            const float *wd = a.wdep + (tap * T + t) * 16;                           // uniform: scalar loads
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += wd[i] * dn;
         }
     }
     const size_t op = (size_t)a.Hout * a.Wout;
@@ -228,7 +318,14 @@ int launch_stem(const StemArgs &a, hipStream_t s) {
     const double ipx = (double)a.B * a.T * a.H * a.W, opx = (double)a.B * a.Hout * a.Wout;
     ProfScope ps(s, "pf::stem_onehot_kernel(pf::StemArgs)", 2.0 * opx * 16 * a.T * (a.n_cls + 1) * 9,
                  ipx * ((a.seg_is_i64 ? 8 : 1) + 4 + ((a.hop & PF_HOP_DEPTH_U16) ? 0 : 1)) + opx * 16 * 4);
-    hipLaunchKernelGGL(stem_onehot_kernel, dim3((a.Wout + 63) / 64, (a.Hout + 3) / 4, a.B), dim3(256), lds, s, a);
+    const dim3 grid((a.Wout + 63) / 64, (a.Hout + 3) / 4, a.B);
+    static const bool generic = getenv("PF_STEM_GENERIC") != nullptr;   // A/B switch for profiling
+    if (a.T == 3 && a.wdep && !generic) {
+        if (a.seg_is_i64) hipLaunchKernelGGL((stem_onehot_batched_kernel<3, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((stem_onehot_batched_kernel<3, false>), grid, dim3(256), lds, s, a);
+    } else {
+        hipLaunchKernelGGL(stem_onehot_kernel, grid, dim3(256), lds, s, a);
+    }
     PF_LAUNCH_CHECK("stem_onehot_kernel");
     return PF_OK;
 }

@@ -32,7 +32,7 @@ model.load_state_dict(bench.calibrated_state_dict())
 batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
 
 CONFIGS = [(0, 0, 0, 0)] + [(1, wm, nt, 0) for wm in (4, 2, 1) for nt in (1, 2, 3, 4) if not (wm == 1 and nt > 2)] + \
-          [(2, mh, nt, wk) for mh in (1, 2, 4) for nt in (1, 2) for wk in (2, 4, 8, 16)]
+          [(2, mh, nt, wk) for mh in (1, 2, 4) for nt in (1, 2) for wk in (2, 4, 8, 16)] + [(3, 1, 0, 0), (3, 2, 0, 0)]
 
 
 def run(cfg):
@@ -73,9 +73,12 @@ for tag in sorted(table):
         nums = [int(x) for x in _re.findall(r'-?\d+', kern.split('<', 1)[1])] if '<' in kern else []
         if c[0] == 0:
             return True
-        if c[0] == 1:
-            return 'conv_dma' in kern and len(nums) == 5 and nums[2] == c[1] and nums[4] <= c[2]
-        return 'conv_wave' in kern and len(nums) == 4 and nums[1] == c[1] and nums[2] <= c[2] and nums[3] == c[3]
+        if c[0] == 1:     # conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI, RV>
+            return 'conv_dma' in kern and len(nums) == 7 and nums[2] == c[1] and nums[4] <= c[2]
+        if c[0] == 3:     # conv_valu_kernel<CP, ROWS, KC>
+            return 'conv_valu' in kern and len(nums) == 3 and nums[1] == c[1]
+        # conv_wave_kernel<KS, MH, NT, WK, EPI>
+        return 'conv_wave' in kern and len(nums) == 5 and nums[1] == c[1] and nums[2] <= c[2] and nums[3] == c[3]
     cands = {c: v for c, v in d.items() if ran_as_asked(c, v[1])}
     best = min(cands, key=lambda c: cands[c][0])
     tot_auto += auto[0]
