@@ -49,8 +49,11 @@ def model_params():
                       'final_h': H, 'final_w': W, 'emulate_disk_hop': True, 'seg_is_label_id': True}}
 
 
-def make_batch(b, seed0, device):
-    parts = [synth.make_inputs(b=1, t=T, h=H, w=W, seed=seed0 + i, gap_len=3) for i in range(b)]
+TERM = {'short': dict(gap_len=3, predicted=False), 'mid': dict(gap_len=9, predicted=True)}   # configs[1] / configs[2]
+
+
+def make_batch(b, seed0, device, term='short'):
+    parts = [synth.make_inputs(b=1, t=T, h=H, w=W, seed=seed0 + i, **TERM[term]) for i in range(b)]
     inp = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
     # camera inverses are per-sequence constants prepared with the inputs (host LAPACK)
     inp['intrinsics_inv'] = host_inverse(inp['intrinsics'])
@@ -71,7 +74,7 @@ def pmc_traffic(kernel_label):
     return k.get('hbm_bytes_per_launch') if k else None
 
 
-def cpu_baseline(sd, n_frames):
+def cpu_baseline(sd, n_frames, term='short'):
     """The oracle (CPU port of the reference path) timed on this box's host cores."""
     import numpy as np
     from oracle import hardnet_ref
@@ -84,7 +87,7 @@ def cpu_baseline(sd, n_frames):
         if f > 0 and time.perf_counter() - t0 > CPU_BUDGET_S:
             n_frames = f
             break
-        inp = synth.make_inputs(b=1, t=T, h=H, w=W, seed=f, gap_len=3)
+        inp = synth.make_inputs(b=1, t=T, h=H, w=W, seed=f, **TERM[term])
         segs, deps = [], []
         for t in range(T):
             o = ow.predict(inp, only_this_ind=t)
@@ -115,6 +118,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=12)
     ap.add_argument('--profile-steps', type=int, default=3)
+    ap.add_argument('--term', choices=['short', 'mid'], default='short',
+                    help="short = BASELINE configs[1] (dt=3, the headline); mid = configs[2] (dt=9, predicted odometry)")
     args = ap.parse_args()
 
     rank, world, local = pfdist.init_distributed_mode()
@@ -132,7 +137,7 @@ def main():
     model.load_state_dict(sd)
     model.eval()
     B = args.batch
-    batch = make_batch(B, seed0=rank * B, device=dev)
+    batch = make_batch(B, seed0=rank * B, device=dev, term=args.term)
 
     def step():
         return model.predict(batch, None)
@@ -212,23 +217,24 @@ def main():
     cpu = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        fps, secs, ref, n_done = cpu_baseline(sd, args.cpu_frames)
+        fps, secs, ref, n_done = cpu_baseline(sd, args.cpu_frames, args.term)
         cpu = {'value': fps, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
                'sample': '%d forecast frames @%dx%d (3 C-oracle splats on 1 thread + torch-CPU HarDNet on %d threads each), %.1f s'
                          % (n_done, H, W, torch.get_num_threads(), secs)}
         # full-size parity of the LAST cpu frame (seed cpu_frames-1) against the HIP path
-        chk = make_batch(1, seed0=n_done - 1, device=dev)
+        chk = make_batch(1, seed0=n_done - 1, device=dev, term=args.term)
         got = model.predict(chk, None)['seg'].long().cpu()
         agree = float((got == ref['seg']).float().mean())
         pq_ref = pfpq.pq_from_acc(pfpq.pq_accumulate(got, ref['seg'], 11))['pq']
         parity = {'argmax_agreement_vs_oracle': agree, 'pq_vs_oracle_as_gt': pq_ref}
 
     if rank == 0:
-        line = {'metric': 'forecast frames/sec @1024x2048, 3-in->dt=3 bg', 'value': value, 'unit': 'frames/s',
+        line = {'metric': 'forecast frames/sec @1024x2048, 3-in->dt=%d bg' % (3 if args.term == 'short' else 9), 'value': value, 'unit': 'frames/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': 'configs[1]: bg short-term forecast, 3 frames in, dt=3, 1024x2048, random-init '
-                                       'calibrated weights; step = 3 warp/splats + HarDNet + upsample/argmax',
+                'config': {'workload': ('configs[1]: bg short-term forecast, 3 frames in, dt=3' if args.term == 'short' else
+                                        'configs[2]: bg mid-term forecast, 3 frames in, dt=9, predicted-odometry ego chain') +
+                                       ', 1024x2048, random-init calibrated weights; step = 3 warp/splats + HarDNet + upsample/argmax',
                            'frames_per_gpu_per_step': B, 'launch': 'hipGraph replay' if use_graph else 'eager',
                            'sharding': 'batch over %d rank(s), no data-path collective' % world},
                 'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity,

@@ -316,11 +316,15 @@ int launch_stem(const StemArgs &a, hipStream_t s) {
         return fail(PF_EUNSUPPORTED, "stem: T=%d n_cls=%d weights exceed LDS budget", a.T, a.n_cls);
     const size_t lds = (size_t)a.T * (a.n_cls + 1) * 9 * 16 * sizeof(float);
     const double ipx = (double)a.B * a.T * a.H * a.W, opx = (double)a.B * a.Hout * a.Wout;
-    ProfScope ps(s, "pf::stem_onehot_kernel(pf::StemArgs)", 2.0 * opx * 16 * a.T * (a.n_cls + 1) * 9,
+    static const bool generic = getenv("PF_STEM_GENERIC") != nullptr;   // A/B switch for profiling
+    const bool batched = a.T == 3 && a.wdep && !generic;
+    const char *label = !batched ? "pf::stem_onehot_kernel(pf::StemArgs)"
+                        : a.seg_is_i64 ? "void pf::stem_onehot_batched_kernel<3, true>(pf::StemArgs)"
+                                       : "void pf::stem_onehot_batched_kernel<3, false>(pf::StemArgs)";
+    ProfScope ps(s, label, 2.0 * opx * 16 * a.T * (a.n_cls + 1) * 9,
                  ipx * ((a.seg_is_i64 ? 8 : 1) + 4 + ((a.hop & PF_HOP_DEPTH_U16) ? 0 : 1)) + opx * 16 * 4);
     const dim3 grid((a.Wout + 63) / 64, (a.Hout + 3) / 4, a.B);
-    static const bool generic = getenv("PF_STEM_GENERIC") != nullptr;   // A/B switch for profiling
-    if (a.T == 3 && a.wdep && !generic) {
+    if (batched) {
         if (a.seg_is_i64) hipLaunchKernelGGL((stem_onehot_batched_kernel<3, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((stem_onehot_batched_kernel<3, false>), grid, dim3(256), lds, s, a);
     } else {
