@@ -98,8 +98,16 @@ size_t valu_packed_floats(const int *src_ch, int n_src, int cout);
 void pack_conv_weights_valu(const float *w_oihw, int cin, int cout, const int *src_ch, int n_src, float *out);
 int launch_conv_valu(const ConvArgs &a, int rows, int B, hipStream_t stream);
 
+// bf16-split path (conv_split.hip; 3x3/s1, Wout % 4 == 0, no fused epilogue; opt-in: results differ from the fp32
+// kernels by ~1e-5 relative): a.wpk must point at pack_conv_weights_split() output, chunks of 8 channels.
+int split_chunks(const int *src_ch, int n_src);
+size_t split_packed_floats(const int *src_ch, int n_src, int cout);
+void pack_conv_weights_split(const float *w_oihw, int cin, int cout, const int *src_ch, int n_src, float *out);
+int launch_conv_split(const ConvArgs &a, int nt, int B, hipStream_t stream);
+
 // Kernel/shape choice for one stride-1 conv (conv_select.cpp): kind 1 = conv_dma (p0 = WM, p1 = NT),
-// kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK), kind 3 = conv_valu (p0 = rows per wave).
+// kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK), kind 3 = conv_valu (p0 = rows per wave),
+// kind 4 = conv_split (p0 = NT).
 struct ConvChoice {
     int kind, p0, p1, p2;
 };

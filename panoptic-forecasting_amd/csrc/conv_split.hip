@@ -1,0 +1,288 @@
+// 3x3/s1 convolution with fp32 operands SPLIT into bf16 terms on the bf16 matrix pipe of gfx950 (opt-in).
+//
+// fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at the fp32 vector rate and shares its budget with the VALU: ~135 TF/s is
+// the ceiling of conv_dma.hip.  v_mfma_f32_16x16x32_bf16 is 16x faster.  Every fp32 value x is split exactly into
+//     x = hi + mid + lo,   hi = bf16(x),  mid = bf16(x - hi)            (both round-to-nearest; x - hi is exact in fp32)
+// and a product a*b is evaluated as  a_hi*b_hi + a_hi*b_mid + a_mid*b_hi  in fp32 accumulators: three matrix
+// instructions instead of one at 3/16 of the time.  The dropped terms (a_mid*b_mid, a*b_lo, a_lo*b) are <= 2^-16 of
+// the product each, so a K-term dot product carries a relative error of ~2^-16/sqrt(K)..2^-16: logits agree with the
+// fp32 path to ~1e-4 (tests/test_gpu_conv.py::test_split_bf16_conv states 2e-4*(1+max|ref|); the fp32 kernels 2e-5).
+// Inputs and outputs stay fp32 NCHW: the split happens inside the kernel, so the path is a drop-in for single layers.
+//
+// GEMM view: M = 16 pixels of a row, N = 16 output channels, K = 32 per instruction = 8 input channels x 4 TAPS: lane l
+// supplies 8 consecutive-K values = the 8 channels of one pixel for tap 4*step + (l >> 4).  9 taps = 3 steps (the last
+// with 3 zero-weight slots).  Per round of 8 input channels:
+//   * every thread loads "its" halo pixels (8 channels, coalesced along x) into registers one round ahead, splits them
+//     and writes two 16-B vectors [pixel][8 ch] (hi, mid) to LDS: an A fragment is then ONE ds_read_b128 per term;
+//   * weights are pre-split and pre-tiled on the host in fragment order ([tile][chunk][step][term][lane][8]) and arrive by
+//     LDS-DMA; a B fragment is one conflict-free ds_read_b128;
+//   * 4 waves x 4 M-tiles x NT cout tiles x 3 steps x 3 products MFMAs per round.
+#include <cstring>
+
+#include "conv_epilogue.h"
+#include "pf_prof.h"
+
+namespace pf {
+
+typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void *sp_lds_ptr_t;
+[[maybe_unused]] constexpr unsigned kSplitOob = 0x80000000u;
+
+template <int NT>
+struct SplitCfg {
+    static constexpr int KC = 8, TW = 32, TH = 8, MP = 4;
+    static constexpr int IW = TW + 8, IH = TH + 2, NPIX = IH * IW;       // halo tile with a 4-pixel apron left/right
+    static constexpr int PIT = (NPIX + 255) / 256;                       // halo pixels per thread
+    static constexpr int ABUF = 2 * NPIX * 16;                           // bytes: [term][pixel][8 bf16]
+    static constexpr int WBUF = NT * 3 * 2 * 64 * 16;                    // bytes: [nt][step][term][lane][8 bf16]
+    static constexpr size_t LDS_BYTES = 2 * (size_t)(ABUF + WBUF);
+    static constexpr int WPIECES = WBUF / 16;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using C = SplitCfg<NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tileY = blockIdx.x / a.tilesX, tileX = blockIdx.x - tileY * a.tilesX;
+    const int tile0 = blockIdx.y * NT, b = blockIdx.z;
+    const int iy0 = tileY * C::TH - 1, ix0 = tileX * C::TW - 4;
+    auto abuf = [&](int i) { return smem_raw + i * C::ABUF; };
+    auto wbuf = [&](int i) { return smem_raw + 2 * C::ABUF + i * C::WBUF; };
+
+    sp_f32x4 acc[C::MP][NT];
+#pragma unroll
+    for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this thread's halo pixels: offset inside one channel plane, or -1 (outside the image / past the tile)
+    const unsigned in_plane = (unsigned)a.Hin * a.Win;
+    int poff[C::PIT];
+#pragma unroll
+    for (int it = 0; it < C::PIT; ++it) {
+        const int p = it * 256 + tid, row = p / C::IW, col = p - row * C::IW;
+        const int gy = iy0 + row, gx = ix0 + col;
+        poff[it] = (p < C::NPIX && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? gy * a.Win + gx : -1;
+    }
+    // A-fragment byte offsets (inside one term's plane) for step s, M-tile m: tap = min(4s + (lane>>4), 8)
+    int aoff[3][C::MP];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int tap = min(4 * s + (lane >> 4), 8), ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m) {
+            const int mt = wave * C::MP + m, ty = mt >> 1, tx0 = (mt & 1) * 16;
+            aoff[s][m] = ((ty + ky) * C::IW + tx0 + (lane & 15) + kx + 3) * 16;
+        }
+    }
+    unsigned woff[(C::WPIECES + 255) / 256];
+#pragma unroll
+    for (int it = 0; it < (C::WPIECES + 255) / 256; ++it) {
+        const int p = it * 256 + tid, n = p / (3 * 2 * 64);   // pieces of cout tile n are contiguous
+        woff[it] = (p < C::WPIECES && tile0 + n < a.ntiles) ? (unsigned)((tile0 + n) * a.nchunks * (3 * 2 * 64) + (p - n * (3 * 2 * 64))) * 16u : kSplitOob;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wpk, 0, 0x7FFFFFFF, 0x00020000);
+
+    float biasv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) biasv[n] = epi_bias(a, (tile0 + n) * 16 + (lane & 15));
+
+    // source tensor / first channel / valid channels of a chunk (workgroup-uniform select chains)
+    auto chunk_src = [&](int chunk, const float *&base, int &nvalid) {
+        const float *sp = a.src[0];
+        int ctot = a.src_ctotal[0], coff = a.src_choff[0], ch0 = 0, cend = a.src_cstart[1], c0 = 0;
+#pragma unroll
+        for (int k = 1; k < kConvMaxSrc; ++k) {
+            const bool take = k < a.n_src && chunk >= a.src_chunk0[k];
+            sp = take ? a.src[k] : sp;
+            ctot = take ? a.src_ctotal[k] : ctot;
+            coff = take ? a.src_choff[k] : coff;
+            ch0 = take ? a.src_chunk0[k] : ch0;
+            c0 = take ? a.src_cstart[k] : c0;
+            cend = take ? a.src_cstart[k + 1] : cend;
+        }
+        const int lc = chunk - ch0;
+        nvalid = (cend - c0) - lc * C::KC;
+        base = sp + ((size_t)b * ctot + coff + lc * C::KC) * in_plane;
+    };
+
+    float xr[C::PIT][C::KC];   // the round in flight: 8 channels of this thread's halo pixels
+    auto load_round = [&](int chunk, unsigned char *wdst) {
+        const float *base;
+        int nv;
+        chunk_src(chunk, base, nv);
+#pragma unroll
+        for (int it = 0; it < C::PIT; ++it)
+#pragma unroll
+            for (int c = 0; c < C::KC; ++c)
+                xr[it][c] = (poff[it] >= 0 && c < nv) ? base[(size_t)c * in_plane + poff[it]] : 0.f;
+#pragma unroll
+        for (int it = 0; it < (C::WPIECES + 255) / 256; ++it)
+            if (it * 256 + tid < C::WPIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (sp_lds_ptr_t)(wdst + (it * 256 + wave * 64) * 16), 16, woff[it],
+                                                         (unsigned)chunk * (3 * 2 * 64 * 16), 0, 0);
+    };
+    auto split_store = [&](unsigned char *adst) {
+#pragma unroll
+        for (int it = 0; it < C::PIT; ++it) {
+            const int p = it * 256 + tid;
+            if (p >= C::NPIX) continue;
+            sp_bf16x8 hi, mid;
+#pragma unroll
+            for (int c = 0; c < C::KC; ++c) {
+                const __bf16 h = (__bf16)xr[it][c];
+                hi[c] = h;
+                mid[c] = (__bf16)(xr[it][c] - (float)h);
+            }
+            *reinterpret_cast<sp_bf16x8 *>(adst + p * 16) = hi;
+            *reinterpret_cast<sp_bf16x8 *>(adst + C::NPIX * 16 + p * 16) = mid;
+        }
+    };
+
+    const int cb = a.chunk_begin, nrounds = a.chunk_end - cb;
+    if (nrounds > 0) {
+        load_round(cb, wbuf(0));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        split_store(abuf(0));
+    }
+    __syncthreads();
+
+    for (int round = 0; round < nrounds; ++round) {
+        const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
+        if (round + 1 < nrounds) load_round(cb + round + 1, wbuf((round + 1) & 1));   // in flight during the MFMAs
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            sp_bf16x8 bh[NT], bm[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bh[n] = *reinterpret_cast<const sp_bf16x8 *>(wb + (((n * 3 + s) * 2 + 0) * 64 + lane) * 16);
+                bm[n] = *reinterpret_cast<const sp_bf16x8 *>(wb + (((n * 3 + s) * 2 + 1) * 64 + lane) * 16);
+            }
+#pragma unroll
+            for (int m = 0; m < C::MP; ++m) {
+                const sp_bf16x8 ah = *reinterpret_cast<const sp_bf16x8 *>(ab + aoff[s][m]);
+                const sp_bf16x8 am = *reinterpret_cast<const sp_bf16x8 *>(ab + C::NPIX * 16 + aoff[s][m]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    // smallest terms first
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+        if (round + 1 < nrounds) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            split_store(abuf((round + 1) & 1));
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + ReLU, NCHW float4 stores (same D fragment as the fp32 kernels)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = (tile0 + n) * 16 + (lane & 15);
+        if (co >= a.Cout) continue;
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m) {
+            const int mt = wave * C::MP + m;
+            const int oy = tileY * C::TH + (mt >> 1);
+            const int ox = tileX * C::TW + (mt & 1) * 16 + (lane >> 4) * 4;
+            if (oy >= a.Hout || ox >= a.Wout) continue;
+            sp_f32x4 v = acc[m][n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] += biasv[n];
+                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            epi_store(a, b, co, oy, ox, v);
+        }
+    }
+#endif
+}
+
+template <int NT>
+static int launch_split_cfg(const ConvArgs &a0, int B, hipStream_t s) {
+    using C = SplitCfg<NT>;
+    ConvArgs a = a0;
+    a.tilesX = (a.Wout + C::TW - 1) / C::TW;
+    a.tilesY = (a.Hout + C::TH - 1) / C::TH;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_split_kernel<NT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_set = true;
+    }
+    char label[96];
+    snprintf(label, sizeof(label), "void pf::conv_split_kernel<%d>(pf::ConvArgs)", NT);
+    const double px = (double)B * a.Hout * a.Wout;
+    ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * 9,
+                 4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * 9));
+    hipLaunchKernelGGL((conv_split_kernel<NT>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(256), C::LDS_BYTES, s, a);
+    PF_LAUNCH_CHECK("conv_split_kernel");
+    return PF_OK;
+}
+
+// a.wpk = pack_conv_weights_split() output; chunks of 8 channels (a.src_chunk0 / chunk_begin / chunk_end set for 8)
+int launch_conv_split(const ConvArgs &a, int nt, int B, hipStream_t s) {
+    if (a.pool || a.res || a.no_bias) return fail(PF_EUNSUPPORTED, "conv_split: no fused epilogue stages");
+    if ((a.Wout & 3) != 0 || a.Hin != a.Hout || a.Win != a.Wout) return fail(PF_EUNSUPPORTED, "conv_split: 3x3/s1, width % 4 == 0 only");
+    nt = nt < 1 ? 1 : (nt > a.ntiles ? a.ntiles : nt);
+    if (nt == 1) return launch_split_cfg<1>(a, B, s);
+    if (nt == 2) return launch_split_cfg<2>(a, B, s);
+    return launch_split_cfg<3>(a, B, s);
+}
+
+static unsigned short bf16_rne(float x) {
+    unsigned u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);   // inf / nan: truncate
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static float bf16_to_f32(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int split_chunks(const int *src_ch, int n_src) {
+    int n = 0;
+    for (int j = 0; j < n_src; ++j) n += (src_ch[j] + 7) / 8;
+    return n;
+}
+
+// bytes as floats (the weight arena is a float array): [tile][chunk][step 3][term 2][lane 64][8 bf16] = 16 B per lane
+size_t split_packed_floats(const int *src_ch, int n_src, int cout) {
+    return (size_t)((cout + 15) / 16) * split_chunks(src_ch, n_src) * 3 * 2 * 64 * 4;
+}
+
+void pack_conv_weights_split(const float *w, int cin, int cout, const int *src_ch, int n_src, float *out_f) {
+    unsigned short *out = reinterpret_cast<unsigned short *>(out_f);
+    const int ntiles = (cout + 15) / 16;
+    size_t o = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        int c0 = 0;
+        for (int j = 0; j < n_src; ++j) {
+            for (int lc = 0; lc * 8 < src_ch[j]; ++lc)
+                for (int s = 0; s < 3; ++s)
+                    for (int term = 0; term < 2; ++term)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int co = t * 16 + (lane & 15), tap = 4 * s + (lane >> 4), cl = lc * 8 + e;
+                                float v = 0.f;
+                                if (co < cout && tap < 9 && cl < src_ch[j]) v = w[((size_t)co * cin + c0 + cl) * 9 + tap];
+                                const unsigned short hi = bf16_rne(v);
+                                out[o++] = term == 0 ? hi : bf16_rne(v - bf16_to_f32(hi));
+                            }
+            c0 += src_ch[j];
+        }
+    }
+}
+
+}  // namespace pf

@@ -29,6 +29,9 @@ struct ConvPlan {
     int wave_chunks = 0;
     size_t valu_off = 0;  // [chunk][ch][tap][cout] rows for the vector-ALU path (3x3/s1 with a supported cout), else 0
     bool has_valu = false;
+    size_t split_off = 0; // bf16 hi/mid fragments for the bf16-split path (3x3/s1), else 0
+    int split_chunks = 0;
+    bool has_split = false;
 };
 
 struct pf_plan {
@@ -43,7 +46,7 @@ struct pf_plan {
 };
 
 namespace pf {
-int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1;
+int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_split_bf16 = 1;
 extern int g_opt_use_tuned;
 }
 
@@ -53,6 +56,7 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "fuse_upsample")) g_opt_fuse_upsample = value;
     else if (!strcmp(name, "use_tuned_table")) g_opt_use_tuned = value;
     else if (!strcmp(name, "valu_remainder")) g_opt_valu_rem = value;
+    else if (!strcmp(name, "split_bf16")) g_opt_split_bf16 = value;
     else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);
     return PF_OK;
 }
@@ -175,6 +179,8 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         }
         if (g_conv_force.kind == 1) ch = g_conv_force;
         if (g_conv_force.kind == 3 && p->conv[i].has_valu && !need) ch = g_conv_force;
+        if (g_conv_force.kind == 4 && p->conv[i].has_split && !need) ch = g_conv_force;
+        if (ch.kind == 4 && (!p->conv[i].has_split || need || !g_opt_split_bf16)) ch = ConvChoice{1, 0, 0, 0};
         if (ch.kind == 3 && (!p->conv[i].has_valu || need)) ch = ConvChoice{1, 0, 0, 0};
         int rc = PF_EUNSUPPORTED;
         auto set_chunks = [&](int kc) {
@@ -184,6 +190,14 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.chunk_begin = a.src_chunk0[a.src_begin];
             a.chunk_end = a.src_chunk0[a.src_end];
         };
+        if (ch.kind == 4) {
+            a.wpk = p->dev_weights + p->conv[i].split_off;
+            a.nchunks = p->conv[i].split_chunks;
+            set_chunks(8);
+            rc = launch_conv_split(a, ch.p0, B, s);
+            if (rc != PF_EUNSUPPORTED) return rc;
+            ch = ConvChoice{1, 0, 0, 0};
+        }
         if (ch.kind == 3) {
             a.wpk = p->dev_weights + p->conv[i].valu_off;
             set_chunks(kValuKc);
@@ -421,6 +435,14 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
             c.rem_count = split;
             host.resize(host.size() + (size_t)c.tiled_chunks * (kc / 4) * 9 * rv * 4);
             pack_conv_weights_rem(wts + o.w_off, (int)o.cin, (int)o.cout, split, 3, kc, src_ch, (int)o.n_src, host.data() + c.rem_off);
+        }
+        if (o.k == 3 && o.stride == 1) {
+            host.resize(align_up(host.size(), 16), 0.f);
+            c.split_off = host.size();
+            c.split_chunks = split_chunks(src_ch, (int)o.n_src);
+            c.has_split = true;
+            host.resize(host.size() + split_packed_floats(src_ch, (int)o.n_src, (int)o.cout));
+            pack_conv_weights_split(wts + o.w_off, (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, host.data() + c.split_off);
         }
         if (o.k == 3 && o.stride == 1 && conv_valu_supports((int)o.cout)) {
             host.resize(align_up(host.size(), 16), 0.f);

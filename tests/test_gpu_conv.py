@@ -226,3 +226,32 @@ def test_vector_alu_conv(cin, cout, h, w, rows, force_conv):
     err = (net.tensor('c').cpu() - ref).abs().max().item()
     assert err <= _tol(ref), (err, _tol(ref))
     net.close()
+
+
+@pytest.mark.parametrize('nt', [1, 2, 3])
+@pytest.mark.parametrize('cin,cout,h,w', [(48, 10, 24, 64), (58, 18, 17, 128), (91, 28, 20, 72), (7, 16, 5, 60),
+                                          (33, 46, 9, 36), (163, 46, 16, 32), (16, 24, 40, 96)])
+def test_split_bf16_conv(cin, cout, h, w, nt, force_conv):
+    """conv_split: fp32 operands split into bf16 hi + mid, three products on v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+    Stated tolerance 2e-4 * (1 + max|ref|) (the dropped cross terms are <= 2^-16 of each product); inputs with a wide
+    dynamic range so that the mid terms matter: with hi-only operands this test fails by two orders of magnitude."""
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    from panoptic_forecasting_amd import lib as pflib
+    g = torch.Generator().manual_seed(cin * 5 + cout)
+    x = torch.randn(2, cin, h, w, generator=g) * torch.exp(torch.randn(2, cin, 1, 1, generator=g))
+    spec = MiniSpec(cin)
+    a, bch = cin // 3, cin - cin // 3
+    spec.conv('c', [arch.Src(0, bch, a), arch.Src(0, 0, bch)], cout, 3)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    force_conv(4, nt, 0, 0)
+    pflib.profile(True)
+    net = MiniNet(spec, {'c': (wt, bias)}).run(x.cuda())
+    labels = [r['label'] for r in pflib.profile_results()]
+    pflib.profile(False)
+    assert any('conv_split_kernel' in l for l in labels), labels
+    ref = F.relu(F.conv2d(torch.cat([x[:, bch:], x[:, :bch]], 1).double(), wt.double(), bias.double(), padding=1)).float()
+    err = (net.tensor('c').cpu() - ref).abs().max().item()
+    assert err <= 2e-4 * (1.0 + ref.abs().max().item()), (err, ref.abs().max().item())
+    net.close()
