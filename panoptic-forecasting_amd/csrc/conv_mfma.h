@@ -103,11 +103,11 @@ int launch_conv_valu(const ConvArgs &a, int rows, int B, hipStream_t stream);
 int split_chunks(const int *src_ch, int n_src);
 size_t split_packed_floats(const int *src_ch, int n_src, int cout);
 void pack_conv_weights_split(const float *w_oihw, int cin, int cout, const int *src_ch, int n_src, float *out);
-int launch_conv_split(const ConvArgs &a, int nt, int B, hipStream_t stream);
+int launch_conv_split(const ConvArgs &a, int nt, int wide, int B, hipStream_t stream);
 
 // Kernel/shape choice for one stride-1 conv (conv_select.cpp): kind 1 = conv_dma (p0 = WM, p1 = NT),
 // kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK), kind 3 = conv_valu (p0 = rows per wave),
-// kind 4 = conv_split (p0 = NT).
+// kind 4 = conv_split (p0 = NT, p1 = 1: 8x64-pixel tiles).
 struct ConvChoice {
     int kind, p0, p1, p2;
 };

@@ -12,8 +12,9 @@
 // GEMM view: M = 16 pixels of a row, N = 16 output channels, K = 32 per instruction = 8 input channels x 4 TAPS: lane l
 // supplies 8 consecutive-K values = the 8 channels of one pixel for tap 4*step + (l >> 4).  9 taps = 3 steps (the last
 // with 3 zero-weight slots).  Per round of 8 input channels:
-//   * every thread loads "its" halo pixels (8 channels, coalesced along x) into registers one round ahead, splits them
-//     and writes two 16-B vectors [pixel][8 ch] (hi, mid) to LDS: an A fragment is then ONE ds_read_b128 per term;
+//   * every thread loads "its" group of 4 consecutive halo pixels (8 channels, one 16-B load each) into registers one
+//     round ahead, splits them and writes 16-B vectors [pixel][8 ch] (hi, mid) to LDS: an A fragment is then ONE
+//     ds_read_b128 per term; workgroup tiles are 8x32 or 8x64 pixels (halo over-read 1.56x / 1.41x);
 //   * weights are pre-split and pre-tiled on the host in fragment order ([tile][chunk][step][term][lane][8]) and arrive by
 //     LDS-DMA; a B fragment is one conflict-free ds_read_b128;
 //   * 4 waves x 4 M-tiles x NT cout tiles x 3 steps x 3 products MFMAs per round.
@@ -29,21 +30,22 @@ typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void *sp_lds_ptr_t;
 [[maybe_unused]] constexpr unsigned kSplitOob = 0x80000000u;
 
-template <int NT>
+template <int NT, int TW_>
 struct SplitCfg {
-    static constexpr int KC = 8, TW = 32, TH = 8, MP = 4;
+    static constexpr int KC = 8, TW = TW_, TH = 8, MTR = TW / 16, MP = 2 * MTR;   // 4 waves x MP M-tiles = 8 rows x TW pixels
     static constexpr int IW = TW + 8, IH = TH + 2, NPIX = IH * IW;       // halo tile with a 4-pixel apron left/right
-    static constexpr int PIT = (NPIX + 255) / 256;                       // halo pixels per thread
+    static constexpr int GW = IW / 4, NGRP = IH * GW;                    // 4-pixel groups: one per thread (<= 256)
     static constexpr int ABUF = 2 * NPIX * 16;                           // bytes: [term][pixel][8 bf16]
     static constexpr int WBUF = NT * 3 * 2 * 64 * 16;                    // bytes: [nt][step][term][lane][8 bf16]
     static constexpr size_t LDS_BYTES = 2 * (size_t)(ABUF + WBUF);
     static constexpr int WPIECES = WBUF / 16;
+    static_assert(NGRP <= 256, "one halo pixel group per thread");
 };
 
-template <int NT>
+template <int NT, int TW_>
 __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using C = SplitCfg<NT>;
+    using C = SplitCfg<NT, TW_>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,14 +61,14 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // this thread's halo pixels: offset inside one channel plane, or -1 (outside the image / past the tile)
+    // this thread's halo pixel GROUP (4 consecutive pixels of a row: one 16-B load per channel; W % 4 == 0 and the 4-pixel
+    // apron keep a group entirely inside or entirely outside the image): offset inside a channel plane, or -1
     const unsigned in_plane = (unsigned)a.Hin * a.Win;
-    int poff[C::PIT];
-#pragma unroll
-    for (int it = 0; it < C::PIT; ++it) {
-        const int p = it * 256 + tid, row = p / C::IW, col = p - row * C::IW;
+    int poff;
+    {
+        const int row = tid / C::GW, col = (tid - row * C::GW) * 4;
         const int gy = iy0 + row, gx = ix0 + col;
-        poff[it] = (p < C::NPIX && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? gy * a.Win + gx : -1;
+        poff = (tid < C::NGRP && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? gy * a.Win + gx : -1;
     }
     // A-fragment byte offsets (inside one term's plane) for step s, M-tile m: tap = min(4s + (lane>>4), 8)
     int aoff[3][C::MP];
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
         const int tap = min(4 * s + (lane >> 4), 8), ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
         for (int m = 0; m < C::MP; ++m) {
-            const int mt = wave * C::MP + m, ty = mt >> 1, tx0 = (mt & 1) * 16;
+            const int mt = wave * C::MP + m, ty = mt / C::MTR, tx0 = (mt % C::MTR) * 16;
             aoff[s][m] = ((ty + ky) * C::IW + tx0 + (lane & 15) + kx + 3) * 16;
         }
     }
@@ -110,16 +112,15 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
         base = sp + ((size_t)b * ctot + coff + lc * C::KC) * in_plane;
     };
 
-    float xr[C::PIT][C::KC];   // the round in flight: 8 channels of this thread's halo pixels
+    sp_f32x4 xr[C::KC];   // the round in flight: 8 channels x this thread's 4 halo pixels
     auto load_round = [&](int chunk, unsigned char *wdst) {
         const float *base;
         int nv;
         chunk_src(chunk, base, nv);
 #pragma unroll
-        for (int it = 0; it < C::PIT; ++it)
-#pragma unroll
-            for (int c = 0; c < C::KC; ++c)
-                xr[it][c] = (poff[it] >= 0 && c < nv) ? base[(size_t)c * in_plane + poff[it]] : 0.f;
+        for (int c = 0; c < C::KC; ++c)
+            xr[c] = (poff >= 0 && c < nv) ? *reinterpret_cast<const sp_f32x4 *>(base + (size_t)c * in_plane + poff)
+                                          : sp_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < (C::WPIECES + 255) / 256; ++it)
             if (it * 256 + tid < C::WPIECES)
@@ -127,19 +128,18 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
                                                          (unsigned)chunk * (3 * 2 * 64 * 16), 0, 0);
     };
     auto split_store = [&](unsigned char *adst) {
+        if (tid >= C::NGRP) return;
 #pragma unroll
-        for (int it = 0; it < C::PIT; ++it) {
-            const int p = it * 256 + tid;
-            if (p >= C::NPIX) continue;
+        for (int k = 0; k < 4; ++k) {
             sp_bf16x8 hi, mid;
 #pragma unroll
             for (int c = 0; c < C::KC; ++c) {
-                const __bf16 h = (__bf16)xr[it][c];
+                const __bf16 h = (__bf16)xr[c][k];
                 hi[c] = h;
-                mid[c] = (__bf16)(xr[it][c] - (float)h);
+                mid[c] = (__bf16)(xr[c][k] - (float)h);
             }
-            *reinterpret_cast<sp_bf16x8 *>(adst + p * 16) = hi;
-            *reinterpret_cast<sp_bf16x8 *>(adst + C::NPIX * 16 + p * 16) = mid;
+            *reinterpret_cast<sp_bf16x8 *>(adst + (tid * 4 + k) * 16) = hi;
+            *reinterpret_cast<sp_bf16x8 *>(adst + C::NPIX * 16 + (tid * 4 + k) * 16) = mid;
         }
     };
 
@@ -154,26 +154,46 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
     for (int round = 0; round < nrounds; ++round) {
         const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
         if (round + 1 < nrounds) load_round(cb + round + 1, wbuf((round + 1) & 1));   // in flight during the MFMAs
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            sp_bf16x8 bh[NT], bm[NT];
+        // Units of work: (tap step s, group of 4 M-tiles), written as fetch(u+1) before the MFMAs of unit u.  hipcc re-sinks
+        // most of the reads towards their uses (fewer live registers, one more wave per SIMD); pinning the prefetch with
+        // sched_barriers was measured 5-20 % SLOWER (188 registers -> 2 waves per SIMD).
+        // Within a unit the order is product-major: consecutive MFMAs hit different accumulators (a 16x16x32 MFMA has 8
+        // passes; back-to-back updates of ONE accumulator would serialise on its result); smallest terms first.
+        constexpr int HALVES = C::MP / 4, UNITS = 3 * HALVES;
+        sp_bf16x8 fa_h[2][4], fa_m[2][4], fb_h[2][NT], fb_m[2][NT];
+        auto fetch = [&](int u, int set) {
+            const int s = u / HALVES, m0 = (u % HALVES) * 4;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                bh[n] = *reinterpret_cast<const sp_bf16x8 *>(wb + (((n * 3 + s) * 2 + 0) * 64 + lane) * 16);
-                bm[n] = *reinterpret_cast<const sp_bf16x8 *>(wb + (((n * 3 + s) * 2 + 1) * 64 + lane) * 16);
+                fb_h[set][n] = *reinterpret_cast<const sp_bf16x8 *>(wb + (((n * 3 + s) * 2 + 0) * 64 + lane) * 16);
+                fb_m[set][n] = *reinterpret_cast<const sp_bf16x8 *>(wb + (((n * 3 + s) * 2 + 1) * 64 + lane) * 16);
             }
 #pragma unroll
-            for (int m = 0; m < C::MP; ++m) {
-                const sp_bf16x8 ah = *reinterpret_cast<const sp_bf16x8 *>(ab + aoff[s][m]);
-                const sp_bf16x8 am = *reinterpret_cast<const sp_bf16x8 *>(ab + C::NPIX * 16 + aoff[s][m]);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    // smallest terms first
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
-                }
+            for (int m = 0; m < 4; ++m) {
+                fa_h[set][m] = *reinterpret_cast<const sp_bf16x8 *>(ab + aoff[s][m0 + m]);
+                fa_m[set][m] = *reinterpret_cast<const sp_bf16x8 *>(ab + C::NPIX * 16 + aoff[s][m0 + m]);
             }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int set = u & 1, m0 = (u % HALVES) * 4;
+            if (u + 1 < UNITS) fetch(u + 1, set ^ 1);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_m[set][m], fb_h[set][n], acc[m0 + m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[set][m], fb_m[set][n], acc[m0 + m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[set][m], fb_h[set][n], acc[m0 + m][n], 0, 0, 0);
         }
         if (round + 1 < nrounds) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -190,8 +210,8 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int m = 0; m < C::MP; ++m) {
             const int mt = wave * C::MP + m;
-            const int oy = tileY * C::TH + (mt >> 1);
-            const int ox = tileX * C::TW + (mt & 1) * 16 + (lane >> 4) * 4;
+            const int oy = tileY * C::TH + mt / C::MTR;
+            const int ox = tileX * C::TW + (mt % C::MTR) * 16 + (lane >> 4) * 4;
             if (oy >= a.Hout || ox >= a.Wout) continue;
             sp_f32x4 v = acc[m][n];
 #pragma unroll
@@ -205,36 +225,42 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
 #endif
 }
 
-template <int NT>
+template <int NT, int TW_>
 static int launch_split_cfg(const ConvArgs &a0, int B, hipStream_t s) {
-    using C = SplitCfg<NT>;
+    using C = SplitCfg<NT, TW_>;
     ConvArgs a = a0;
     a.tilesX = (a.Wout + C::TW - 1) / C::TW;
     a.tilesY = (a.Hout + C::TH - 1) / C::TH;
     static bool attr_set = false;
     if (!attr_set) {
-        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_split_kernel<NT>),
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_split_kernel<NT, TW_>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_set = true;
     }
     char label[96];
-    snprintf(label, sizeof(label), "void pf::conv_split_kernel<%d>(pf::ConvArgs)", NT);
+    snprintf(label, sizeof(label), "void pf::conv_split_kernel<%d, %d>(pf::ConvArgs)", NT, TW_);
     const double px = (double)B * a.Hout * a.Wout;
     ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * 9,
                  4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * 9));
-    hipLaunchKernelGGL((conv_split_kernel<NT>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(256), C::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_split_kernel<NT, TW_>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(256), C::LDS_BYTES, s, a);
     PF_LAUNCH_CHECK("conv_split_kernel");
     return PF_OK;
 }
 
-// a.wpk = pack_conv_weights_split() output; chunks of 8 channels (a.src_chunk0 / chunk_begin / chunk_end set for 8)
-int launch_conv_split(const ConvArgs &a, int nt, int B, hipStream_t s) {
+// a.wpk = pack_conv_weights_split() output; chunks of 8 channels (a.src_chunk0 / chunk_begin / chunk_end set for 8).
+// nt = cout tiles per workgroup (1..3), wide = 8x64-pixel workgroup tiles instead of 8x32.
+int launch_conv_split(const ConvArgs &a, int nt, int wide, int B, hipStream_t s) {
     if (a.pool || a.res || a.no_bias) return fail(PF_EUNSUPPORTED, "conv_split: no fused epilogue stages");
     if ((a.Wout & 3) != 0 || a.Hin != a.Hout || a.Win != a.Wout) return fail(PF_EUNSUPPORTED, "conv_split: 3x3/s1, width % 4 == 0 only");
     nt = nt < 1 ? 1 : (nt > a.ntiles ? a.ntiles : nt);
-    if (nt == 1) return launch_split_cfg<1>(a, B, s);
-    if (nt == 2) return launch_split_cfg<2>(a, B, s);
-    return launch_split_cfg<3>(a, B, s);
+    if (wide) {
+        if (nt == 1) return launch_split_cfg<1, 64>(a, B, s);
+        if (nt == 2) return launch_split_cfg<2, 64>(a, B, s);
+        return launch_split_cfg<3, 64>(a, B, s);
+    }
+    if (nt == 1) return launch_split_cfg<1, 32>(a, B, s);
+    if (nt == 2) return launch_split_cfg<2, 32>(a, B, s);
+    return launch_split_cfg<3, 32>(a, B, s);
 }
 
 static unsigned short bf16_rne(float x) {

@@ -194,7 +194,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.wpk = p->dev_weights + p->conv[i].split_off;
             a.nchunks = p->conv[i].split_chunks;
             set_chunks(8);
-            rc = launch_conv_split(a, ch.p0, B, s);
+            rc = launch_conv_split(a, ch.p0, ch.p1, B, s);
             if (rc != PF_EUNSUPPORTED) return rc;
             ch = ConvChoice{1, 0, 0, 0};
         }

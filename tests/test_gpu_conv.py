@@ -228,10 +228,10 @@ def test_vector_alu_conv(cin, cout, h, w, rows, force_conv):
     net.close()
 
 
-@pytest.mark.parametrize('nt', [1, 2, 3])
+@pytest.mark.parametrize('nt,wide', [(1, 0), (2, 0), (3, 0), (1, 1), (2, 1), (3, 1)])
 @pytest.mark.parametrize('cin,cout,h,w', [(48, 10, 24, 64), (58, 18, 17, 128), (91, 28, 20, 72), (7, 16, 5, 60),
                                           (33, 46, 9, 36), (163, 46, 16, 32), (16, 24, 40, 96)])
-def test_split_bf16_conv(cin, cout, h, w, nt, force_conv):
+def test_split_bf16_conv(cin, cout, h, w, nt, wide, force_conv):
     """conv_split: fp32 operands split into bf16 hi + mid, three products on v_mfma_f32_16x16x32_bf16, fp32 accumulate.
     Stated tolerance 2e-4 * (1 + max|ref|) (the dropped cross terms are <= 2^-16 of each product); inputs with a wide
     dynamic range so that the mid terms matter: with hi-only operands this test fails by two orders of magnitude."""
@@ -245,7 +245,7 @@ def test_split_bf16_conv(cin, cout, h, w, nt, force_conv):
     spec.conv('c', [arch.Src(0, bch, a), arch.Src(0, 0, bch)], cout, 3)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
     bias = torch.randn(cout, generator=g)
-    force_conv(4, nt, 0, 0)
+    force_conv(4, nt, wide, 0)
     pflib.profile(True)
     net = MiniNet(spec, {'c': (wt, bias)}).run(x.cuda())
     labels = [r['label'] for r in pflib.profile_results()]

@@ -33,7 +33,7 @@ batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
 
 CONFIGS = [(0, 0, 0, 0)] + [(1, wm, nt, 0) for wm in (4, 2, 1) for nt in (1, 2, 3, 4) if not (wm == 1 and nt > 2)] + \
           [(2, mh, nt, wk) for mh in (1, 2, 4) for nt in (1, 2) for wk in (2, 4, 8, 16)] + [(3, 1, 0, 0), (3, 2, 0, 0)] + \
-          ([(4, nt, 0, 0) for nt in (1, 2, 3)] if os.environ.get('PF_TUNE_SPLIT', '1') != '0' else [])
+          ([(4, nt, wd, 0) for nt in (1, 2, 3) for wd in (0, 1)] if os.environ.get('PF_TUNE_SPLIT', '1') != '0' else [])
 
 
 def run(cfg):
@@ -77,7 +77,7 @@ for tag in sorted(table):
         if c[0] == 1:     # conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI, RV>
             return 'conv_dma' in kern and len(nums) == 7 and nums[2] == c[1] and nums[4] <= c[2]
         if c[0] == 4:     # conv_split_kernel<NT>
-            return 'conv_split' in kern and len(nums) == 1 and nums[0] <= c[1]
+            return 'conv_split' in kern and len(nums) == 2 and nums[0] <= c[1] and nums[1] == (64 if c[2] else 32)
         if c[0] == 3:     # conv_valu_kernel<CP, ROWS, KC>
             return 'conv_valu' in kern and len(nums) == 3 and nums[1] == c[1]
         # conv_wave_kernel<KS, MH, NT, WK, EPI>
