@@ -167,7 +167,11 @@ int pf_panoptic_max_ids(void);
  *   "fuse_upsample" (default 1) TransitionUp + 1x1 conv over cat([up(x), skip]) (hardnet.py:248-258,365-368) is
  *                   evaluated as W_skip*skip + up(W_x*x): same result up to fp32 rounding, no upsampled tensor;
  *   "use_tuned_table" (default 1) per-layer kernel shapes come from the measured table (csrc/conv_tuned.inc) where it
- *                   has the shape, else from the cost model; 0 = cost model only (tools/tune_convs.py). */
+ *                   has the shape, else from the cost model; 0 = cost model only (tools/tune_convs.py);
+ *   "split_bf16"    (default 1) the table may select conv_split for stride-1 3x3 layers: fp32 operands split into bf16
+ *                   hi+mid terms, three products on v_mfma_f32_16x16x32_bf16, fp32 accumulation (single layers within
+ *                   2e-4*(1+max|ref|) of fp64; the fp32 kernels 2e-5); 0 = every convolution on fp32 MFMA / fp32 VALU;
+ *   "valu_remainder" (default 1) trailing cout % 16 <= 8 channels of a conv_dma layer on the vector ALU. */
 int pf_set_option(const char *name, int value);
 
 /* Introspection for per-stage parity tests: where tensor `name` (packing.py tensor names, e.g.
@@ -193,7 +197,9 @@ int pf_profile_get(int i, char *label, size_t label_cap, int *launches, double *
 /* Tuning/diagnostic hook (tools/tune_convs.py, tests): force the convolution kernel and tile shape of every
  * stride-1 conv the library launches from now on.  kind 0 = automatic (default); 1 = conv_dma (p0 = WM in
  * {1,2,4}, p1 = NT); 2 = conv_wave (p0 = rows per tile in {1,2,4}, p1 = NT in {1,2}, p2 = K-split waves in
- * {2,4,8,16}).  Shapes that are not built fall back to the automatic choice.  Process-wide, not thread-safe. */
+ * {2,4,8,16}); 3 = conv_valu (3x3 only, p0 = rows per wave in {1,2}); 4 = conv_split (3x3 only, p0 = NT in {1,2,3},
+ * p1 = 1 for 8x64-pixel tiles).  Shapes that are not built fall back to the automatic choice.  Process-wide, not
+ * thread-safe. */
 int pf_debug_force_conv(int kind, int p0, int p1, int p2);
 /* Instrumented builds only (make libpfhip_probe.so, env PF_PROBE=1): the 64 in-kernel timestamps (shader clock)
  * written by workgroup 0 / wave 0 of the last conv_wave launch; PF_EINVAL when nothing was recorded. */
