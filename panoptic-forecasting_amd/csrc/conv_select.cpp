@@ -32,7 +32,16 @@ ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout
         if (g_opt_use_tuned && t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == B &&
             (!(need & 2) || t.c.kind != 2 || t.c.p0 != 1))
             return t.c;
-    // Untuned shape.  Images of >= 256x512 pixels keep the barrier-synchronised kernel (its big shared tiles move the
+    // Untuned shape.  Large stride-1 3x3 layers go to the bf16-split kernel: on every measured shape with >= 64x128
+    // pixels x 4 images it beat the fp32-MFMA kernels by 1.3-2.2x (profiles/README.md); cout tiles per workgroup by
+    // channel count, 8x64 tiles where the image is wide enough to still fill the chip.  (The executor falls back to
+    // conv_dma when the layer needs a fused epilogue or split_bf16 is off.)
+    if (ks == 3 && (need == 0) && (wout & 3) == 0 && (long)B * hout * wout >= 32768) {
+        const int nt = cout <= 16 ? 1 : (cout <= 32 ? 2 : 3);
+        const long tiles_wide = (long)B * ((hout + 7) / 8) * ((wout + 63) / 64) * (((cout + 15) / 16 + nt - 1) / nt);
+        return ConvChoice{4, nt, (nt <= 2 && tiles_wide >= 512) ? 1 : 0, 0};
+    }
+    // Images of >= 256x512 pixels keep the barrier-synchronised kernel (its big shared tiles move the
     // fewest bytes); below that the wave-autonomous kernel wins everywhere it was measured.  Pick the tile with the
     // most operand reuse (rows x cout tiles) that still puts >= 2 waves on every SIMD of the chip.
     const long px = (long)B * hout * wout;
