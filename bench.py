@@ -113,8 +113,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=16, help='forecast frames per GPU per step (the reference export loop '
-                    'batches 2; one stream saturates at 4-8, four concurrent sub-batches of 4 are the throughput optimum)')
+    ap.add_argument('--batch', type=int, default=32, help='forecast frames per GPU per step (the reference export loop '
+                    'batches 2; throughput saturates around 32-48 frames in flight as two or three concurrent sub-batches of 16)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=12)
@@ -122,7 +122,7 @@ def main():
     ap.add_argument('--fp32-mfma-only', action='store_true', help='disable the bf16-split 3x3 kernels (pf_set_option split_bf16=0): '
                     'every convolution on v_mfma_f32_16x16x4_f32 / the fp32 VALU')
     ap.add_argument('--streams', type=int, default=0, help='sub-batches run concurrently on this many HIP streams '
-                    '(0 = one per 4 frames of the batch)')
+                    '(0 = one per 16 frames of the batch)')
     ap.add_argument('--term', choices=['short', 'mid'], default='short',
                     help="short = BASELINE configs[1] (dt=3, the headline); mid = configs[2] (dt=9, predicted odometry)")
     args = ap.parse_args()
@@ -147,9 +147,10 @@ def main():
     batch = make_batch(B, seed0=rank * B, device=dev, term=args.term)
 
     # --streams S > 1: the per-rank batch is cut into S sub-batches, each with its own model object (own workspaces,
-    # shared weights are re-packed per plan: 16.5 MB) on its own HIP stream inside the captured step; the low-resolution
-    # layers of one sub-batch (small grids, latency-bound) then overlap the high-resolution layers of another.
-    S = max(1, min(args.streams, B)) if args.streams > 0 else max(1, B // 4)
+    # weights re-packed per plan) on its own HIP stream inside the captured step; the low-resolution layers of one
+    # sub-batch (small grids, latency-bound) and its memory-bound splat/stem kernels then overlap the matrix-bound
+    # high-resolution layers of another.
+    S = max(1, min(args.streams, B)) if args.streams > 0 else max(1, B // 16)
     if S > 1:
         if B % S:
             raise SystemExit('--batch must be a multiple of --streams')

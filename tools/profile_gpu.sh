@@ -8,9 +8,9 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-# one sub-batch (4 frames) on one stream: the launches bench.py times for its roofline line; the headline runs 4 of
-# these concurrently on 4 streams inside one hipGraph
-BENCH="python $REPO/bench.py --batch 4 --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --no-graph --profile-steps 1 $*"
+# one sub-batch (16 frames) on one stream: the launches bench.py times for its roofline line; the headline runs 2 of
+# these concurrently on 2 streams inside one hipGraph
+BENCH="python $REPO/bench.py --batch 16 --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --no-graph --profile-steps 1 $*"
 cd /tmp
 # 1. kernel trace + stats (timing)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BENCH > "$OUT/bench_trace.log" 2>"$OUT/trace.err"
