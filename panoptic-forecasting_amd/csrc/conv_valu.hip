@@ -1,8 +1,9 @@
 // fp32 3x3/s1 convolution on the VECTOR ALU of gfx950, for layers whose output-channel count fits the 16-wide MFMA tile
 // badly (FC-HarDNet's 10/18/24/28-channel HarDBlock layers carry a third of the network's time at 256x512).
 // STATUS (round 1, profiles/README.md): correct everywhere, but it sustains ~80 TF/s against the MFMA kernels' 100-135
-// executed TF/s, so the per-layer table only selects it where the MFMA padding loss is larger than that gap
-// (18->10 and 16->24 at >= 256x512); kept as the measured alternative for the layers the matrix tile fits worst.
+// executed TF/s; it beat them only on 18->10 and 16->24 at >= 256x512, and conv_split.hip now beats it there too: the
+// shipped table selects it nowhere.  Kept (tested, forceable) as the measured fp32-only alternative for the layers the
+// matrix tile fits worst.
 //
 // Why not the matrix cores: on gfx950 the fp32 MFMA runs at exactly the fp32 vector rate, and the two pipes share one
 // power/clock budget - tools/ubench/valu_rate.hip measures 135 TF/s for MFMA alone, 128 TF/s for v_pk_fma_f32 alone and
