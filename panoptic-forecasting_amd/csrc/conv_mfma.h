@@ -104,6 +104,11 @@ int split_chunks(const int *src_ch, int n_src);
 size_t split_packed_floats(const int *src_ch, int n_src, int cout);
 void pack_conv_weights_split(const float *w_oihw, int cin, int cout, const int *src_ch, int n_src, float *out);
 int launch_conv_split(const ConvArgs &a, int nt, int wide, int B, hipStream_t stream);
+// 1x1/s1 on the same scheme (chunks of 32 channels; pack_conv_weights_split1()); supports the fused epilogue stages
+int split1_chunks(const int *src_ch, int n_src);
+size_t split1_packed_floats(const int *src_ch, int n_src, int cout);
+void pack_conv_weights_split1(const float *w_oihw, int cin, int cout, const int *src_ch, int n_src, float *out);
+int launch_conv_split1(const ConvArgs &a, int nt, int B, hipStream_t stream);
 
 // Kernel/shape choice for one stride-1 conv (conv_select.cpp): kind 1 = conv_dma (p0 = WM, p1 = NT),
 // kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK), kind 3 = conv_valu (p0 = rows per wave),

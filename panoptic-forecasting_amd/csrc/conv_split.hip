@@ -263,6 +263,299 @@ int launch_conv_split(const ConvArgs &a, int nt, int wide, int B, hipStream_t s)
     return launch_split_cfg<3, 32>(a, B, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 convolutions on the same scheme: K = 32 per instruction = 4 groups of 8 input channels (no taps, nothing padded but
+// the channel ranges, to 32); one round = 32 channels of an 8x32-pixel tile; thread (g, q) loads the 4 pixels of group g
+// for the 8 channels of k-group q, splits them and writes [term][k-group][pixel][8 ch].  The fused epilogue stages of
+// conv_epilogue.h (2x2 average pool, bilinearly upsampled residual, bias-free low-resolution half) are supported: the
+// D fragment is the one the fp32 kernels produce.  These layers were fp32-MFMA-bound at ~50 TF/s (K = Cin only) while
+// moving < 2.5 TB/s; here they are bound by their bytes.
+template <int NT>
+struct Split1Cfg {
+    static constexpr int KC = 32, TW = 32, TH = 8, MTR = 2, MP = 4, NPIX = TH * TW;
+    static constexpr int ABUF = 2 * 4 * NPIX * 16;                  // bytes: [term][k-group][pixel][8 bf16]
+    static constexpr int WBUF = NT * 2 * 64 * 16;                   // bytes: [nt][term][lane][8 bf16]
+    static constexpr int MAIN = 2 * (ABUF + WBUF);
+    static constexpr int WPIECES = WBUF / 16;
+};
+
+template <int NT, int EPI>
+__global__ __launch_bounds__(256) void conv_split1_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using C = Split1Cfg<NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tileY = blockIdx.x / a.tilesX, tileX = blockIdx.x - tileY * a.tilesX;
+    const int tile0 = blockIdx.y * NT, b = blockIdx.z;
+    auto abuf = [&](int i) { return smem_raw + i * C::ABUF; };
+    auto wbuf = [&](int i) { return smem_raw + 2 * C::ABUF + i * C::WBUF; };
+
+    sp_f32x4 acc[C::MP][NT];
+#pragma unroll
+    for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // thread = (pixel group g of 4 consecutive pixels, k-group q of 8 channels)
+    const int g = tid & 63, q = tid >> 6;
+    const unsigned in_plane = (unsigned)a.Hin * a.Win;
+    int poff;
+    {
+        const int row = g >> 3, col = (g & 7) * 4;
+        const int gy = tileY * C::TH + row, gx = tileX * C::TW + col;
+        poff = (gy < a.Hin && gx < a.Win) ? gy * a.Win + gx : -1;
+    }
+    int aoff[C::MP];
+#pragma unroll
+    for (int m = 0; m < C::MP; ++m) {
+        const int mt = wave * C::MP + m, ty = mt / C::MTR, tx0 = (mt % C::MTR) * 16;
+        aoff[m] = ((lane >> 4) * C::NPIX + ty * C::TW + tx0 + (lane & 15)) * 16;
+    }
+    constexpr int NITW = (C::WPIECES + 255) / 256;
+    unsigned woff[NITW];
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+        const int p = it * 256 + tid, n = p / (2 * 64);
+        woff[it] = (p < C::WPIECES && tile0 + n < a.ntiles) ? (unsigned)((tile0 + n) * a.nchunks * (2 * 64) + (p - n * (2 * 64))) * 16u : kSplitOob;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wpk, 0, 0x7FFFFFFF, 0x00020000);
+
+    float biasv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) biasv[n] = epi_bias(a, (tile0 + n) * 16 + (lane & 15));
+
+    auto chunk_src = [&](int chunk, const float *&base, int &nvalid) {
+        const float *sp = a.src[0];
+        int ctot = a.src_ctotal[0], coff = a.src_choff[0], ch0 = 0, cend = a.src_cstart[1], c0 = 0;
+#pragma unroll
+        for (int k = 1; k < kConvMaxSrc; ++k) {
+            const bool take = k < a.n_src && chunk >= a.src_chunk0[k];
+            sp = take ? a.src[k] : sp;
+            ctot = take ? a.src_ctotal[k] : ctot;
+            coff = take ? a.src_choff[k] : coff;
+            ch0 = take ? a.src_chunk0[k] : ch0;
+            c0 = take ? a.src_cstart[k] : c0;
+            cend = take ? a.src_cstart[k + 1] : cend;
+        }
+        const int lc = chunk - ch0;
+        nvalid = (cend - c0) - lc * C::KC;
+        base = sp + ((size_t)b * ctot + coff + lc * C::KC) * in_plane;
+    };
+
+    sp_f32x4 xr[8];
+    auto load_round = [&](int chunk, unsigned char *wdst) {
+        const float *base;
+        int nv;
+        chunk_src(chunk, base, nv);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            xr[c] = (poff >= 0 && q * 8 + c < nv) ? *reinterpret_cast<const sp_f32x4 *>(base + (size_t)(q * 8 + c) * in_plane + poff)
+                                                  : sp_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < NITW; ++it)
+            if (it * 256 + tid < C::WPIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (sp_lds_ptr_t)(wdst + (it * 256 + wave * 64) * 16), 16, woff[it],
+                                                         (unsigned)chunk * (2 * 64 * 16), 0, 0);
+    };
+    auto split_store = [&](unsigned char *adst) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sp_bf16x8 hi, mid;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const __bf16 h = (__bf16)xr[c][k];
+                hi[c] = h;
+                mid[c] = (__bf16)(xr[c][k] - (float)h);
+            }
+            *reinterpret_cast<sp_bf16x8 *>(adst + (q * C::NPIX + g * 4 + k) * 16) = hi;
+            *reinterpret_cast<sp_bf16x8 *>(adst + (4 * C::NPIX + q * C::NPIX + g * 4 + k) * 16) = mid;
+        }
+    };
+
+    const int cb = a.chunk_begin, nrounds = a.chunk_end - cb;
+    if (nrounds > 0) {
+        load_round(cb, wbuf(0));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        split_store(abuf(0));
+    }
+    __syncthreads();
+
+    for (int round = 0; round < nrounds; ++round) {
+        const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
+        if (round + 1 < nrounds) load_round(cb + round + 1, wbuf((round + 1) & 1));
+        sp_bf16x8 bh[NT], bm[NT], ah[C::MP], am[C::MP];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            bh[n] = *reinterpret_cast<const sp_bf16x8 *>(wb + ((n * 2 + 0) * 64 + lane) * 16);
+            bm[n] = *reinterpret_cast<const sp_bf16x8 *>(wb + ((n * 2 + 1) * 64 + lane) * 16);
+        }
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m) {
+            ah[m] = *reinterpret_cast<const sp_bf16x8 *>(ab + aoff[m]);
+            am[m] = *reinterpret_cast<const sp_bf16x8 *>(ab + 4 * C::NPIX * 16 + aoff[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bm[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+        if (round + 1 < nrounds) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            split_store(abuf((round + 1) & 1));
+        }
+        __syncthreads();
+    }
+
+    if (EPI == 0) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = (tile0 + n) * 16 + (lane & 15);
+            if (co >= a.Cout) continue;
+#pragma unroll
+            for (int m = 0; m < C::MP; ++m) {
+                const int mt = wave * C::MP + m;
+                const int oy = tileY * C::TH + mt / C::MTR;
+                const int ox = tileX * C::TW + (mt % C::MTR) * 16 + (lane >> 4) * 4;
+                if (oy >= a.Hout || ox >= a.Wout) continue;
+                sp_f32x4 v = acc[m][n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] += biasv[n];
+                    if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                }
+                epi_store(a, b, co, oy, ox, v);
+            }
+        }
+    } else {
+        // fused stages (conv_epilogue.h), as in conv_dma.hip: residual window of this tile -> LDS (the main-loop buffers
+        // are free after the last barrier), then pixel-group outer / channel inner
+        ResWin rw = ResWin();
+        const lds_float *res_lds = nullptr;
+        const bool has_res = a.res && a.res_lds_off >= 0;
+        if (has_res) {
+            rw = res_window(a, tileY * C::TH, C::TH, tileX * C::TW, C::TW);
+            res_stage(a, rw, b, tile0 * 16, NT * 16, (lds_float *)(reinterpret_cast<float *>(smem_raw) + a.res_lds_off), tid, 256);
+            res_lds = (const lds_float *)(reinterpret_cast<float *>(smem_raw) + a.res_lds_off);
+            __syncthreads();
+        }
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m) {
+            const int mt = wave * C::MP + m;
+            const int oy = tileY * C::TH + mt / C::MTR;
+            const int ox = tileX * C::TW + (mt % C::MTR) * 16 + (lane_e >> 4) * 4;
+            if (oy >= a.Hout || ox >= a.Wout) continue;
+            const bool pool_top = a.pool && ((m / C::MTR) & 1) == 0 && m + C::MTR < C::MP && oy + 1 < a.Hout;
+            if (a.pool && !pool_top) continue;
+            ResTaps t0, t1;
+            if (has_res) {
+                t0 = res_taps(a, rw, oy, ox);
+                if (pool_top) t1 = res_taps(a, rw, oy + 1, ox);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = (tile0 + n) * 16 + (lane_e & 15);
+                if (co >= a.Cout) continue;
+                const lds_float *chan = res_lds + (n * 16 + (lane_e & 15)) * rw.cs;
+                const sp_f32x4 top = epi_finish(a, b, co, oy, ox, acc[m][n], biasv[n], has_res, chan, &t0);
+                if (!a.pool) epi_store(a, b, co, oy, ox, top);
+                else epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, acc[(m + C::MTR) % C::MP][n], biasv[n], has_res, chan, &t1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#endif
+}
+
+template <int NT, int EPI>
+static int launch_split1_cfg(const ConvArgs &a0, int B, hipStream_t s) {
+    using C = Split1Cfg<NT>;
+    ConvArgs a = a0;
+    a.tilesX = (a.Wout + C::TW - 1) / C::TW;
+    a.tilesY = (a.Hout + C::TH - 1) / C::TH;
+    size_t lds = C::MAIN;
+    a.res_lds_off = -1;
+    if (a.res) {
+        const size_t need = (size_t)NT * 16 * res_chan_stride(res_extent(C::TH, a.res_sh), res_extent(C::TW, a.res_sw)) * sizeof(float);
+        if (need > 64 * 1024) return fail(PF_EUNSUPPORTED, "conv_split1: residual window of %zu B does not fit LDS", need);
+        a.res_lds_off = 0;
+        if (need > lds) lds = need;
+    }
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_split1_kernel<NT, EPI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    char label[112];
+    snprintf(label, sizeof(label), "void pf::conv_split1_kernel<%d, %d>(pf::ConvArgs)", NT, EPI);
+    if (a.res) strncat(label, " +res", sizeof(label) - strlen(label) - 1);
+    if (a.pool) strncat(label, " +pool", sizeof(label) - strlen(label) - 1);
+    if (a.no_bias) strncat(label, " lowres-half", sizeof(label) - strlen(label) - 1);
+    const double px = (double)B * a.Hout * a.Wout;
+    ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin, 4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin));
+    hipLaunchKernelGGL((conv_split1_kernel<NT, EPI>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(256), lds, s, a);
+    PF_LAUNCH_CHECK("conv_split1_kernel");
+    return PF_OK;
+}
+
+// 1x1/s1: a.wpk = pack_conv_weights_split1() output; chunks of 32 channels.  nt = cout tiles per workgroup (1..4).
+int launch_conv_split1(const ConvArgs &a, int nt, int B, hipStream_t s) {
+    if ((a.Wout & 3) != 0 || a.Hin != a.Hout || a.Win != a.Wout) return fail(PF_EUNSUPPORTED, "conv_split1: 1x1/s1, width % 4 == 0 only");
+    nt = nt < 1 ? 1 : (nt > a.ntiles ? a.ntiles : nt);
+    nt = nt > 4 ? 4 : nt;
+    const bool fused = a.pool || a.res || a.no_bias;
+#define PF_S1(NT_) \
+    if (nt == NT_) return fused ? launch_split1_cfg<NT_, 1>(a, B, s) : launch_split1_cfg<NT_, 0>(a, B, s);
+    PF_S1(1) PF_S1(2) PF_S1(3) PF_S1(4)
+#undef PF_S1
+    return PF_EUNSUPPORTED;
+}
+
+int split1_chunks(const int *src_ch, int n_src) {
+    int n = 0;
+    for (int j = 0; j < n_src; ++j) n += (src_ch[j] + 31) / 32;
+    return n;
+}
+
+static unsigned short bf16_rne(float x);
+static float bf16_to_f32(unsigned short h);
+
+// bytes as floats: [tile][chunk of 32 ch][term 2][lane 64][8 bf16]; lane = (cout n = lane & 15, k-group lane >> 4)
+size_t split1_packed_floats(const int *src_ch, int n_src, int cout) {
+    return (size_t)((cout + 15) / 16) * split1_chunks(src_ch, n_src) * 2 * 64 * 4;
+}
+
+void pack_conv_weights_split1(const float *w, int cin, int cout, const int *src_ch, int n_src, float *out_f) {
+    unsigned short *out = reinterpret_cast<unsigned short *>(out_f);
+    const int ntiles = (cout + 15) / 16;
+    size_t o = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        int c0 = 0;
+        for (int j = 0; j < n_src; ++j) {
+            for (int lc = 0; lc * 32 < src_ch[j]; ++lc)
+                for (int term = 0; term < 2; ++term)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = t * 16 + (lane & 15), cl = lc * 32 + (lane >> 4) * 8 + e;
+                            const float v = (co < cout && cl < src_ch[j]) ? w[(size_t)co * cin + c0 + cl] : 0.f;
+                            const unsigned short hi = bf16_rne(v);
+                            out[o++] = term == 0 ? hi : bf16_rne(v - bf16_to_f32(hi));
+                        }
+            c0 += src_ch[j];
+        }
+    }
+}
+
 static unsigned short bf16_rne(float x) {
     unsigned u;
     memcpy(&u, &x, 4);

@@ -179,8 +179,8 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         }
         if (g_conv_force.kind == 1) ch = g_conv_force;
         if (g_conv_force.kind == 3 && p->conv[i].has_valu && !need) ch = g_conv_force;
-        if (g_conv_force.kind == 4 && p->conv[i].has_split && !need) ch = g_conv_force;
-        if (ch.kind == 4 && (!p->conv[i].has_split || need || !g_opt_split_bf16)) ch = ConvChoice{1, 0, 0, 0};
+        if (g_conv_force.kind == 4 && p->conv[i].has_split && (!need || o.k == 1)) ch = g_conv_force;
+        if (ch.kind == 4 && (!p->conv[i].has_split || (need && o.k != 1) || !g_opt_split_bf16)) ch = ConvChoice{1, 0, 0, 0};
         if (ch.kind == 3 && (!p->conv[i].has_valu || need)) ch = ConvChoice{1, 0, 0, 0};
         int rc = PF_EUNSUPPORTED;
         auto set_chunks = [&](int kc) {
@@ -193,8 +193,8 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         if (ch.kind == 4) {
             a.wpk = p->dev_weights + p->conv[i].split_off;
             a.nchunks = p->conv[i].split_chunks;
-            set_chunks(8);
-            rc = launch_conv_split(a, ch.p0, ch.p1, B, s);
+            set_chunks(o.k == 1 ? 32 : 8);
+            rc = o.k == 1 ? launch_conv_split1(a, ch.p0, B, s) : launch_conv_split(a, ch.p0, ch.p1, B, s);
             if (rc != PF_EUNSUPPORTED) return rc;
             ch = ConvChoice{1, 0, 0, 0};
         }
@@ -443,6 +443,14 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
             c.has_split = true;
             host.resize(host.size() + split_packed_floats(src_ch, (int)o.n_src, (int)o.cout));
             pack_conv_weights_split(wts + o.w_off, (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, host.data() + c.split_off);
+        }
+        if (o.k == 1 && o.stride == 1) {
+            host.resize(align_up(host.size(), 16), 0.f);
+            c.split_off = host.size();
+            c.split_chunks = split1_chunks(src_ch, (int)o.n_src);
+            c.has_split = true;
+            host.resize(host.size() + split1_packed_floats(src_ch, (int)o.n_src, (int)o.cout));
+            pack_conv_weights_split1(wts + o.w_off, (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, host.data() + c.split_off);
         }
         if (o.k == 3 && o.stride == 1 && conv_valu_supports((int)o.cout)) {
             host.resize(align_up(host.size(), 16), 0.f);

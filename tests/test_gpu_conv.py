@@ -255,3 +255,69 @@ def test_split_bf16_conv(cin, cout, h, w, nt, wide, force_conv):
     err = (net.tensor('c').cpu() - ref).abs().max().item()
     assert err <= 2e-4 * (1.0 + ref.abs().max().item()), (err, ref.abs().max().item())
     net.close()
+
+
+def _tol_split(ref):
+    return 2e-4 * (1.0 + ref.abs().max().item())
+
+
+@pytest.mark.parametrize('nt', [1, 2, 3, 4])
+@pytest.mark.parametrize('cin,cout,h,w,b', [(48, 64, 16, 64, 2), (78, 96, 9, 36, 1), (45, 70, 20, 40, 2), (160, 11, 8, 32, 1),
+                                            (5, 3, 7, 12, 1), (214, 224, 4, 8, 2)])
+def test_split_bf16_conv1x1(cin, cout, h, w, b, nt, force_conv):
+    """conv_split1 (1x1, K = 4 groups of 8 channels per bf16 MFMA): two input ranges (channel chunks of 32 with tails)."""
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    from panoptic_forecasting_amd import lib as pflib
+    g = torch.Generator().manual_seed(cin + cout * 3)
+    x = torch.randn(b, cin, h, w, generator=g) * torch.exp(torch.randn(b, cin, 1, 1, generator=g))
+    spec = MiniSpec(cin)
+    a, bch = cin // 3, cin - cin // 3
+    srcs = [arch.Src(0, bch, a), arch.Src(0, 0, bch)] if a > 0 else [arch.Src(0, 0, cin)]
+    spec.conv('c', srcs, cout, 1, relu=False)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    bias = torch.randn(cout, generator=g)
+    force_conv(4, nt, 0, 0)
+    pflib.profile(True)
+    net = MiniNet(spec, {'c': (wt, bias)}).run(x.cuda())
+    labels = [r['label'] for r in pflib.profile_results()]
+    pflib.profile(False)
+    assert any('conv_split1_kernel' in l for l in labels), labels
+    xin = torch.cat([x[:, bch:], x[:, :bch]], 1) if a > 0 else x
+    ref = F.conv2d(xin.double(), wt.double(), bias.double()).float()
+    err = (net.tensor('c').cpu() - ref).abs().max().item()
+    assert err <= _tol_split(ref), (err, ref.abs().max().item())
+    net.close()
+
+
+@pytest.mark.parametrize('nt', [1, 2, 4])
+@pytest.mark.parametrize('h,w,b', [(32, 64, 1), (20, 40, 2), (34, 52, 1)])
+def test_split_bf16_fused_pool_and_commuted_upsample(h, w, b, nt, fuse_upsample, force_conv):
+    """The fused epilogue stages (2x2 pool; TransitionUp + 1x1 evaluated as W_skip*skip + up(W_x*x)) behind the bf16-split
+    1x1 kernel; the 3x3 layers of the little network run on conv_split as well."""
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    g = torch.Generator().manual_seed(h * 7 + w)
+    x = torch.randn(b, 12, h, w, generator=g)
+    spec = MiniSpec(12)
+    c1 = spec.conv('c1', [arch.Src(0, 0, 12)], 20, 3)
+    c2 = spec.conv('c2', [arch.Src(c1, 0, 20)], 24, 1)
+    p = spec.pool('p', c2)
+    c3 = spec.conv('c3', [arch.Src(p, 0, 24)], 40, 3)
+    up = spec.upsample('up', c3, c1)
+    spec.conv('c4', [arch.Src(up, 0, 40), arch.Src(c1, 0, 20)], 37, 1)
+    P = {}
+    for name, cin, cout, k in [('c1', 12, 20, 3), ('c2', 20, 24, 1), ('c3', 24, 40, 3), ('c4', 60, 37, 1)]:
+        P[name] = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.randn(cout, generator=g))
+    force_conv(4, nt, 0, 0)
+    net = MiniNet(spec, P).run(x.cuda())
+    r1 = F.relu(F.conv2d(x, *P['c1'], padding=1))
+    r2 = F.relu(F.conv2d(r1, *P['c2']))
+    rp = F.avg_pool2d(r2, 2, 2)
+    r3 = F.relu(F.conv2d(rp, *P['c3'], padding=1))
+    ru = F.interpolate(r3, size=(h, w), mode='bilinear', align_corners=True)
+    r4 = F.relu(F.conv2d(torch.cat([ru, r1], 1), *P['c4']))
+    assert (net.tensor('p').cpu() - rp).abs().max() <= _tol_split(rp)
+    assert (net.tensor('c3').cpu() - r3).abs().max() <= _tol_split(r3)
+    assert (net.tensor('c4').cpu() - r4).abs().max() <= 2 * _tol_split(r4)
+    net.close()

@@ -33,7 +33,7 @@ batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
 
 CONFIGS = [(0, 0, 0, 0)] + [(1, wm, nt, 0) for wm in (4, 2, 1) for nt in (1, 2, 3, 4) if not (wm == 1 and nt > 2)] + \
           [(2, mh, nt, wk) for mh in (1, 2, 4) for nt in (1, 2) for wk in (2, 4, 8, 16)] + [(3, 1, 0, 0), (3, 2, 0, 0)] + \
-          ([(4, nt, wd, 0) for nt in (1, 2, 3) for wd in (0, 1)] if os.environ.get('PF_TUNE_SPLIT', '1') != '0' else [])
+          ([(4, nt, wd, 0) for nt in (1, 2, 3, 4) for wd in (0, 1)] if os.environ.get('PF_TUNE_SPLIT', '1') != '0' else [])
 
 
 def run(cfg):
@@ -76,7 +76,9 @@ for tag in sorted(table):
             return True
         if c[0] == 1:     # conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI, RV>
             return 'conv_dma' in kern and len(nums) == 7 and nums[2] == c[1] and nums[4] <= c[2]
-        if c[0] == 4:     # conv_split_kernel<NT>
+        if c[0] == 4 and 'conv_split1' in kern:     # conv_split1_kernel<NT, EPI> (1x1 layers)
+            return len(nums) == 2 and nums[0] <= c[1] and c[2] == 0
+        if c[0] == 4:     # conv_split_kernel<NT, TW>
             return 'conv_split' in kern and len(nums) == 2 and nums[0] <= c[1] and nums[1] == (64 if c[2] else 32)
         if c[0] == 3:     # conv_valu_kernel<CP, ROWS, KC>
             return 'conv_valu' in kern and len(nums) == 3 and nums[1] == c[1]
