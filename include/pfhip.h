@@ -162,6 +162,19 @@ int pf_panoptic_encode(const void *seg, int seg_is_i64, int convert_to_ids, int 
                        int32_t *out_ids, uint8_t *out_present, void *stream);
 int pf_panoptic_max_ids(void);
 
+/* ------------------------------------------------------------------------------------------
+ * Validation loss of the bg model (forward part) - replaces BGModel.loss (bg_model.py:73-89):
+ * nn.CrossEntropyLoss(ignore_index) of the bilinearly upsampled (align_corners, hardnet.py:372-384) logits and the
+ * accuracy counters, fused: the full-resolution logits are never materialised.
+ *   logits [B,C,Hin,Win] f32 (the network's orig_size_logits, C = 11 or 19)   labels [B,out_h,out_w] i64 or u8
+ *   out3 (device) = { sum over valid pixels of -log softmax(logits)[label], #valid pixels, #pixels with argmax == label }
+ *   => loss = out3[0]/out3[1], accuracy = out3[2]/out3[1].  Deterministic (fixed-order fp64 reduction).
+ * Workspace: pf_seg_loss_workspace(B, out_h, out_w).  The backward pass / training step is not built.
+ */
+int pf_seg_loss_workspace(int B, int out_h, int out_w, size_t *bytes);
+int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void *labels, int labels_i64, int out_h,
+                int out_w, int ignore_index, double *out3, void *ws, size_t ws_bytes, void *stream);
+
 /* Process-wide execution options (not thread-safe; set before launching work):
  *   "fuse_pool"     (default 1) a 1x1 conv followed by AvgPool2d(2,2) (hardnet.py:296) pools in the conv epilogue;
  *   "fuse_upsample" (default 1) TransitionUp + 1x1 conv over cat([up(x), skip]) (hardnet.py:248-258,365-368) is

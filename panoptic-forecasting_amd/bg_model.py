@@ -207,8 +207,26 @@ class BGModel(BaseModel):
         _, logits, orig = self.run(inps, depths, depth_masks, True, return_orig_size)
         return (logits, orig) if return_orig_size else logits
 
+    @torch.no_grad()
     def loss(self, inputs, labels):
-        raise NotImplementedError('bg training step (bg_model.py:73-89) is scope row f4 — not built yet')
+        """Validation form of reference ``BGModel.loss`` (bg_model.py:73-89): ``{'loss', 'accuracy'}`` for a batch, eval-mode
+        network (folded BN).  One network forward + ``pf_seg_loss`` (upsample + cross entropy + accuracy fused; the
+        full-resolution logits are never written).  There is no backward pass: training is scope row f4."""
+        L = _lib.load()
+        seg_labels = labels['seg']
+        _, _, orig = self.run(inputs['seg'], inputs.get('depth'), inputs.get('depth_mask'), want_logits=False, want_orig=True)
+        if seg_labels.dtype not in (torch.uint8, torch.int64):
+            seg_labels = seg_labels.long()
+        seg_labels = _lib.require_cuda(seg_labels.contiguous(), 'labels')
+        b, c, hin, win = orig.shape
+        oh, ow = seg_labels.shape[-2], seg_labels.shape[-1]
+        need = ctypes.c_size_t()
+        _lib.check(L.pf_seg_loss_workspace(b, oh, ow, ctypes.byref(need)), 'pf_seg_loss_workspace')
+        ws = torch.empty(need.value, dtype=torch.uint8, device=orig.device)
+        out3 = torch.empty(3, dtype=torch.float64, device=orig.device)
+        _lib.check(L.pf_seg_loss(orig.data_ptr(), b, c, hin, win, seg_labels.data_ptr(), int(seg_labels.dtype == torch.int64), oh, ow,
+                                 255, out3.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'pf_seg_loss')
+        return {'loss': (out3[0] / out3[1]).float(), 'accuracy': (out3[2] / out3[1]).float()}
 
     @torch.no_grad()
     def predict(self, inputs, labels=None):

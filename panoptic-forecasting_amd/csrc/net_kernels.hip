@@ -383,6 +383,110 @@ __global__ __launch_bounds__(256) void head_tile_kernel(HeadArgs a, int win_rows
 }
 
 // ------------------------------------------------------------------------------------------------
+// Validation loss of the bg model (scope row f4, forward part): BGModel.loss (bg_model.py:73-89) =
+// nn.CrossEntropyLoss(ignore_index=255)(logits, labels) + accuracy, with logits = the bilinearly upsampled network output
+// (hardnet.py:372-384).  Fused like the head: a workgroup stages the low-resolution logits of its 16 x 256 output tile in
+// LDS, every lane interpolates the C logits of its pixels, forms log-sum-exp, the negative log-likelihood of the label
+// and "argmax == label" - the full-resolution logits (92 MB per frame) are never written.  Per-workgroup partial sums
+// (fp64) go to the workspace and a second one-block kernel adds them in index order: deterministic.
+struct LossArgs {
+    const float *logits;   // [B,C,Hin,Win]
+    const void *labels;    // [B,Hout,Wout] i64 or u8
+    double *partial;       // [blocks][3]: sum of nll, valid pixels, correct pixels
+    int labels_i64, B, Hin, Win, Hout, Wout, ignore;
+};
+
+template <int CC>
+__global__ __launch_bounds__(256) void seg_loss_tile_kernel(LossArgs a) {
+    extern __shared__ float hl[];
+    __shared__ double red[4][3];
+    const float sh = a.Hout > 1 ? (float)(a.Hin - 1) / (float)(a.Hout - 1) : 0.f;
+    const float sw = a.Wout > 1 ? (float)(a.Win - 1) / (float)(a.Wout - 1) : 0.f;
+    const size_t opl = (size_t)a.Hout * a.Wout, ipl = (size_t)a.Hin * a.Win;
+    const int ty0 = blockIdx.y * kHeadTH, tx0 = blockIdx.x * kHeadTW, b = blockIdx.z;
+    const int ylast = min(ty0 + kHeadTH, a.Hout) - 1, xlast = min(tx0 + kHeadTW, a.Wout) - 1;
+    const int sy0 = min((int)(sh * (float)ty0), a.Hin - 1), sx0 = min((int)(sw * (float)tx0), a.Win - 1);
+    const int rows = min(min((int)(sh * (float)ylast), a.Hin - 1) + 1, a.Hin - 1) - sy0 + 1;
+    const int cols = min(min((int)(sw * (float)xlast), a.Win - 1) + 1, a.Win - 1) - sx0 + 1;
+    const int per = rows * cols;
+    const float *src = a.logits + (size_t)b * CC * ipl;
+    for (int e = threadIdx.x; e < per; e += 256) {
+        const int r = e / cols, x = e - r * cols;
+        const size_t off = (size_t)(sy0 + r) * a.Win + sx0 + x;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) hl[c * per + e] = src[(size_t)c * ipl + off];
+    }
+    __syncthreads();
+    double nll = 0.0, valid = 0.0, correct = 0.0;
+    const int x = tx0 + threadIdx.x;
+    if (x < a.Wout) {
+        int x0, x1;
+        float lx0, lx1;
+        lin_coord(x, sw, a.Win, x0, x1, lx0, lx1);
+        for (int ry = 0; ry < kHeadTH; ++ry) {
+            const int y = ty0 + ry;
+            if (y >= a.Hout) break;
+            const size_t o = (size_t)b * opl + (size_t)y * a.Wout + x;
+            const int lab = a.labels_i64 ? (int)reinterpret_cast<const long long *>(a.labels)[o] : (int)reinterpret_cast<const uint8_t *>(a.labels)[o];
+            int y0, y1;
+            float hy0, hy1;
+            lin_coord(y, sh, a.Hin, y0, y1, hy0, hy1);
+            const float *r0 = hl + (y0 - sy0) * cols - sx0, *r1 = hl + (y1 - sy0) * cols - sx0;
+            float v[CC], best = -INFINITY;
+            int arg = 0;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const float t0 = lx0 * r0[c * per + x0] + lx1 * r0[c * per + x1];
+                const float t1 = lx0 * r1[c * per + x0] + lx1 * r1[c * per + x1];
+                v[c] = hy0 * t0 + hy1 * t1;
+                if (v[c] > best) { best = v[c]; arg = c; }
+            }
+            if (lab == a.ignore || lab < 0 || lab >= CC) {
+                // ignored pixel: no loss term, not in the accuracy denominator; a prediction never equals 255
+                continue;
+            }
+            float se = 0.f, vl = 0.f;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                se += expf(v[c] - best);
+                vl = c == lab ? v[c] : vl;
+            }
+            nll += (double)((best + logf(se)) - vl);
+            valid += 1.0;
+            correct += arg == lab ? 1.0 : 0.0;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        nll += __shfl_xor(nll, o);
+        valid += __shfl_xor(valid, o);
+        correct += __shfl_xor(correct, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6][0] = nll; red[threadIdx.x >> 6][1] = valid; red[threadIdx.x >> 6][2] = correct;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *p = a.partial + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 3;
+        p[0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        p[1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+        p[2] = ((red[0][2] + red[1][2]) + red[2][2]) + red[3][2];
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_loss_finish_kernel(const double *partial, int n, double *out3) {
+    __shared__ double red[256][3];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { s0 += partial[i * 3]; s1 += partial[i * 3 + 1]; s2 += partial[i * 3 + 2]; }
+    red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1; red[threadIdx.x][2] = s2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 256; ++i) { s0 += red[i][0]; s1 += red[i][1]; s2 += red[i][2]; }
+        out3[0] = s0; out3[1] = s1; out3[2] = s2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 static unsigned grid_for(size_t total) {
     size_t g = (total + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -448,3 +552,45 @@ int launch_head(const HeadArgs &a, hipStream_t s) {
 }
 
 }  // namespace pf
+
+extern "C" int pf_seg_loss_workspace(int B, int out_h, int out_w, size_t *bytes) {
+    if (!bytes || B <= 0 || out_h <= 0 || out_w <= 0) return pf::fail(PF_EINVAL, "pf_seg_loss_workspace: bad arguments");
+    const size_t blocks = (size_t)B * ((out_h + pf::kHeadTH - 1) / pf::kHeadTH) * ((out_w + pf::kHeadTW - 1) / pf::kHeadTW);
+    *bytes = pf::align_up(blocks * 3 * sizeof(double), 256);
+    return PF_OK;
+}
+
+extern "C" int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void *labels, int labels_i64, int out_h,
+                           int out_w, int ignore_index, double *out3, void *ws, size_t ws_bytes, void *stream) {
+    if (!logits || !labels || !out3 || !ws || B <= 0 || Hin <= 0 || Win <= 0 || out_h <= 0 || out_w <= 0)
+        return pf::fail(PF_EINVAL, "pf_seg_loss: bad arguments");
+    if (C != 11 && C != 19) return pf::fail(PF_EUNSUPPORTED, "pf_seg_loss: built for 11 or 19 classes, got %d", C);
+    size_t need = 0;
+    pf_seg_loss_workspace(B, out_h, out_w, &need);
+    if (ws_bytes < need) return pf::fail(PF_EWORKSPACE, "pf_seg_loss: workspace %zu B < required %zu B", ws_bytes, need);
+    const float sh = out_h > 1 ? (float)(Hin - 1) / (float)(out_h - 1) : 0.f, sw = out_w > 1 ? (float)(Win - 1) / (float)(out_w - 1) : 0.f;
+    const int wr = (int)(sh * (pf::kHeadTH - 1)) + 3, wc = (int)(sw * (pf::kHeadTW - 1)) + 3;
+    const size_t lds = (size_t)wr * wc * C * sizeof(float);
+    if (lds > 60 * 1024) return pf::fail(PF_EUNSUPPORTED, "pf_seg_loss: source window of %zu B per tile does not fit LDS (downsampling heads are not built)", lds);
+    pf::LossArgs a{logits, labels, (double *)ws, labels_i64 ? 1 : 0, B, Hin, Win, out_h, out_w, ignore_index};
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((out_w + pf::kHeadTW - 1) / pf::kHeadTW, (out_h + pf::kHeadTH - 1) / pf::kHeadTH, B);
+    {
+        pf::ProfScope ps(s, C == 11 ? "void pf::seg_loss_tile_kernel<11>(pf::LossArgs)" : "void pf::seg_loss_tile_kernel<19>(pf::LossArgs)", 0.0,
+                         4.0 * B * C * Hin * Win + (double)B * out_h * out_w * (labels_i64 ? 8 : 1));
+        if (C == 11) {
+            static bool set11 = false;
+            if (!set11) { PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pf::seg_loss_tile_kernel<11>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024)); set11 = true; }
+            hipLaunchKernelGGL(pf::seg_loss_tile_kernel<11>, grid, dim3(256), lds, s, a);
+        } else {
+            static bool set19 = false;
+            if (!set19) { PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pf::seg_loss_tile_kernel<19>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024)); set19 = true; }
+            hipLaunchKernelGGL(pf::seg_loss_tile_kernel<19>, grid, dim3(256), lds, s, a);
+        }
+        PF_LAUNCH_CHECK("seg_loss_tile_kernel");
+    }
+    hipLaunchKernelGGL(pf::seg_loss_finish_kernel, dim3(1), dim3(256), 0, s, (const double *)ws, (int)(grid.x * grid.y * grid.z), out3);
+    PF_LAUNCH_CHECK("seg_loss_finish_kernel");
+    return PF_OK;
+}
+

@@ -34,6 +34,8 @@ SIGNATURES = {
                                _vp, _i, _vp, _sz, _vp]),
     'pf_panoptic_encode': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'pf_panoptic_max_ids': (_i, []),
+    'pf_seg_loss_workspace': (_i, [_i, _i, _i, _c.POINTER(_sz)]),
+    'pf_seg_loss': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'pf_set_option': (_i, [_c.c_char_p, _i]),
     'pf_debug_force_conv': (_i, [_i, _i, _i, _i]),
     'pf_debug_probe_read': (_i, [_c.POINTER(_c.c_longlong)]),
