@@ -26,7 +26,14 @@ from panoptic_forecasting_amd import lib as pflib  # noqa: E402
 from panoptic_forecasting_amd import pq as pfpq  # noqa: E402
 from panoptic_forecasting_amd import synth  # noqa: E402
 from panoptic_forecasting_amd.pc_transform_model import host_inverse  # noqa: E402
-from panoptic_forecasting_amd.registry import build_model  # noqa: E402
+from panoptic_forecasting_amd.registry import build_model as _build_model  # noqa: E402
+
+
+def build_model(params):
+    """The registry prints like the reference's does (models/__init__.py:18); stdout carries only the JSON line here."""
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        return _build_model(params)
 
 H, W, T = 1024, 2048, 3
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
