@@ -65,3 +65,34 @@ def test_fused_matches_two_stage_oracle(h, w, b, gap):
     agree = (out['seg'].cpu().long() == ref['seg']).float().mean().item()
     assert err <= 1e-3, err
     assert agree >= 0.999, agree
+
+
+def test_fp32_mfma_only_option():
+    """pf_set_option("split_bf16", 0): every convolution on the fp32 matrix/vector pipes - the logits then agree with the
+    torch-CPU oracle an order of magnitude closer than the stated 1e-3 (pure fp32 FMA chains, only the summation order
+    differs); with the default (bf16-split 3x3/1x1 layers where tuned or large) they stay inside 1e-3."""
+    from panoptic_forecasting_amd import lib as pflib
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.registry import build_model
+    h, w = 256, 512          # large enough for the heuristic to pick the split kernels when they are enabled
+    sd = _sd()
+    inp = synth.make_inputs(b=1, h=h, w=w, seed=4, gap_len=3)
+    ref, _, _ = oracle_pipeline(sd, inp, h, w)
+    errs = {}
+    L = pflib.load()
+    try:
+        for split in (1, 0):
+            pflib.check(L.pf_set_option(b'split_bf16', split), 'pf_set_option')
+            m = build_model(_params(h, w, return_logits=True))
+            m.load_state_dict(sd)
+            pflib.profile(True)
+            out = m.predict({k: v.cuda() for k, v in inp.items()}, None)
+            labels = [r['label'] for r in pflib.profile_results()]
+            pflib.profile(False)
+            assert any('conv_split' in l for l in labels) == bool(split), labels
+            errs[split] = (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max().item()
+            assert (out['seg'].cpu().long() == ref['seg']).float().mean().item() >= 0.999
+    finally:
+        L.pf_set_option(b'split_bf16', 1)
+    assert errs[0] <= 1e-4, errs
+    assert errs[1] <= 1e-3, errs
