@@ -13,7 +13,7 @@ mask = d>0, clamp to [min_depth, max_depth]) so outputs match the two-stage refe
 """
 import torch
 
-from .base_model import BaseModel
+from .model_api import BaseModel
 from .bg_model import BGModel
 from .pc_transform_model import WarpSplat
 

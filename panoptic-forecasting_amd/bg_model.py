@@ -15,7 +15,7 @@ from torch import nn
 from . import hardnet_arch as arch
 from . import lib as _lib
 from . import packing
-from .base_model import BaseModel
+from .model_api import BaseModel
 from .pc_transform_model import _as_u8
 
 

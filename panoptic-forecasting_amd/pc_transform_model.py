@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import lib as _lib
-from .base_model import BaseModel
+from .model_api import BaseModel
 
 
 def host_inverse(m):

@@ -1,36 +1,43 @@
-"""Task registry — same dispatch as reference ``models/__init__.py:16-41``.
+"""Task registry: ``build_model(params)`` for the tasks of the MI355X path.
 
-``build_model(params)`` keys on ``params['task']`` (``bg``, ``pc_transform``, plus the fused
-``bg_forecast``), moves the model to the GPU unless ``params['no_gpu']`` and loads
-``working_dir/best_model`` or ``load_model`` exactly like the reference.
+Call contract of the reference's ``panoptic_forecasting.models.build_model`` (``models/__init__.py:16-41``), so its
+experiment scripts run with one import changed: the task comes from ``params['task']``; the model is
+moved to the GPU unless ``params['no_gpu']``; ``load_best_model`` restores ``<working_dir>/best_model``, otherwise
+``load_model`` names a checkpoint.  Tasks outside the hot path (``fg``, ``odom``) are refused with a pointer to the
+reference — this package has no fallback implementations.
 """
+import importlib
 import os
 
 import torch
 
-from .bg_model import BGModel
-from .pc_transform_model import PCTransformModel
+# task -> (module, class); imported lazily so that e.g. ``pc_transform`` users never touch the HarDNet packing code
+_TASKS = {
+    'bg': ('bg_model', 'BGModel'),
+    'pc_transform': ('pc_transform_model', 'PCTransformModel'),
+    'bg_forecast': ('bg_forecast_model', 'BGForecastModel'),       # the two stages fused on the device (new)
+}
+_OUT_OF_SCOPE = ('fg', 'odom')
+
+
+def _checkpoint_path(params):
+    if params.get('load_best_model'):
+        return os.path.join(params['working_dir'], 'best_model')
+    return params.get('load_model') or None
 
 
 def build_model(params):
     task = params['task']
-    print("Building model for task: ", task)
-    if task == 'bg':
-        model = BGModel(params)
-    elif task == 'pc_transform':
-        model = PCTransformModel(params)
-    elif task == 'bg_forecast':
-        from .bg_forecast_model import BGForecastModel
-        model = BGForecastModel(params)
-    elif task in ('fg', 'odom'):
+    print("Building model for task: ", task)          # the reference announces the task the same way
+    if task in _OUT_OF_SCOPE:
         raise ValueError('task %r is outside the MI355X hot path (SURVEY.md §8): use the reference for it' % task)
-    else:
+    if task not in _TASKS:
         raise ValueError('task not recognized: ', task)
+    module, cls = _TASKS[task]
+    model = getattr(importlib.import_module('.' + module, __package__), cls)(params)
     if not params.get('no_gpu'):
         model.to(torch.device('cuda'))
-    if params.get('load_best_model'):
-        model.load(os.path.join(params['working_dir'], 'best_model'))
-    elif params.get('load_model'):
-        print("LOADING MODEL FROM SPECIFIED PATH")
-        model.load(params['load_model'])
+    ckpt = _checkpoint_path(params)
+    if ckpt:
+        model.load(ckpt)
     return model
