@@ -23,6 +23,15 @@
 #include "conv_epilogue.h"
 #include "pf_prof.h"
 
+#ifndef PF_PROBE
+#define PF_PROBE 0
+#endif
+#if PF_PROBE   // shader-clock stamps of one workgroup in the middle of the grid (tools/probe_split.py)
+#define SPLIT_PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2 && a.probe && (i) < 60) a.probe[i] = clock64(); } while (0)
+#else
+#define SPLIT_PROBE(i) do { } while (0)
+#endif
+
 namespace pf {
 
 typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
@@ -159,7 +168,9 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
 
     for (int round = 0; round < nrounds; ++round) {
         const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
+        SPLIT_PROBE(round * 6 + 0);
         if (round + 1 < nrounds) load_round(cb + round + 1, wbuf((round + 1) & 1));   // in flight during the MFMAs
+        SPLIT_PROBE(round * 6 + 1);
         // Units of work: (tap step s, group of 4 M-tiles), written as fetch(u+1) before the MFMAs of unit u.  hipcc re-sinks
         // most of the reads towards their uses (fewer live registers, one more wave per SIMD); pinning the prefetch with
         // sched_barriers was measured 5-20 % SLOWER (188 registers -> 2 waves per SIMD).
@@ -201,11 +212,15 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
                 for (int n = 0; n < NT; ++n)
                     acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[set][m], fb_h[set][n], acc[m0 + m][n], 0, 0, 0);
         }
+        SPLIT_PROBE(round * 6 + 2);   // all MFMAs of the round issued
         if (round + 1 < nrounds) {
             __syncthreads();   // everyone is done reading the activation buffer
+            SPLIT_PROBE(round * 6 + 3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SPLIT_PROBE(round * 6 + 4);
             split_store(abuf((round + 1) & 1));
         }
+        SPLIT_PROBE(round * 6 + 5);
         __syncthreads();
     }
 
