@@ -7,12 +7,26 @@ One "step" = one pass of the hot path over one batch of synthetic, HBM-resident 
 Ranks are independent (sequences shard by batch); the only collective is the end-of-run all-gather of
 the PQ accumulators.  Prints ONE JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-graph] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-graph] [--no-cpu-baseline] [--no-legs]
+
+``--gpus N`` with N > 1 and no launcher environment (WORLD_SIZE unset) re-executes this file under
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` — one rank per GPU over
+RCCL; started by an external launcher it reads RANK/LOCAL_RANK/WORLD_SIZE from the environment.  It refuses to run
+when the ranks that joined differ from ``--gpus`` or the node has fewer GPUs than ranks.
+
+At N=1 the same line also carries (driver-timed, same process):
+    by_batch   frames/s of ONE stream at B = 1, 2, 4 frames per step (SURVEY.md 8d Config 2; the reference loop batches 2)
+    fp32_only  the headline workload with every convolution on the fp32 MFMA (no bf16 operand split) + its parity
+    roofline   dominant kernel (live hipEvent timing) + ``step``: whole-step algorithmic bytes / kernel time, per stage
+    cpu_baseline  the oracle pipeline on all host cores
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,25 +36,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from panoptic_forecasting_amd import dist as pfdist  # noqa: E402
-from panoptic_forecasting_amd import lib as pflib  # noqa: E402
-from panoptic_forecasting_amd import pq as pfpq  # noqa: E402
 from panoptic_forecasting_amd import synth  # noqa: E402
-from panoptic_forecasting_amd.pc_transform_model import host_inverse  # noqa: E402
-from panoptic_forecasting_amd.registry import build_model as _build_model  # noqa: E402
-
-
-def build_model(params):
-    """The registry prints like the reference's does (models/__init__.py:18); stdout carries only the JSON line here."""
-    import contextlib
-    with contextlib.redirect_stdout(sys.stderr):
-        return _build_model(params)
 
 H, W, T = 1024, 2048, 3
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec (6.3 TB/s achievable)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (2495 measured)
-CPU_THREADS = 32                # torch-CPU threads for the baseline leg (more oversubscribes these small convs)
 CPU_BUDGET_S = 20.0             # stop starting new baseline frames after this much CPU time
+SUB_BATCH = 16                  # frames per concurrent sub-batch of the headline workload
+
+
+def build_model(params):
+    """The registry prints like the reference's does (models/__init__.py:18); stdout carries only the JSON line here."""
+    import contextlib
+    from panoptic_forecasting_amd.registry import build_model as _build_model
+    with contextlib.redirect_stdout(sys.stderr):
+        return _build_model(params)
 
 
 def calibrated_state_dict():
@@ -49,73 +60,277 @@ def calibrated_state_dict():
     return synth.make_state_dict(seed=1234, calib=calib)
 
 
-def model_params():
-    return {'task': 'bg_forecast', 'no_gpu': False, 'load_model': None, 'load_best_model': False,
-            'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])],
-                     'min_depth': 0.1, 'max_depth': 200},
-            'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True,
-                      'final_h': H, 'final_w': W, 'emulate_disk_hop': True, 'seg_is_label_id': True}}
+def model_params(**model_kw):
+    p = {'task': 'bg_forecast', 'no_gpu': False, 'load_model': None, 'load_best_model': False,
+         'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])],
+                  'min_depth': 0.1, 'max_depth': 200},
+         'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True,
+                   'final_h': H, 'final_w': W, 'emulate_disk_hop': True, 'seg_is_label_id': True,
+                   # every frame gets the sentinel the reference gives it at batch size 1 (outputs independent of how the
+                   # frames are batched and sharded; the reference's batch-global max couples the samples of a call)
+                   'per_sample_sentinel': True}}
+    p['model'].update(model_kw)
+    return p
 
 
 TERM = {'short': dict(gap_len=3, predicted=False), 'mid': dict(gap_len=9, predicted=True)}   # configs[1] / configs[2]
 
 
 def make_batch(b, seed0, device, term='short'):
+    from panoptic_forecasting_amd.pc_transform_model import host_inverse
     parts = [synth.make_inputs(b=1, t=T, h=H, w=W, seed=seed0 + i, **TERM[term]) for i in range(b)]
     inp = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
-    # camera inverses are per-sequence constants prepared with the inputs (host LAPACK)
+    # camera inverses are per-sequence constants prepared with the inputs (host LAPACK); a caller that
+    # does not pass them pays one cached host inverse per distinct camera (pc_transform_model.InverseCache)
     inp['intrinsics_inv'] = host_inverse(inp['intrinsics'])
     inp['extrinsics_inv'] = host_inverse(inp['extrinsics'])
     return {k: v.to(device) for k, v in inp.items()}
 
 
+def source_sha():
+    """Hash of the device sources the loaded library was built from: profiles/pmc_latest.json records it, and a PMC
+    file measured on other kernels is refused (roofline.traffic = null) instead of being quoted."""
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, 'panoptic-forecasting_amd', 'csrc', '*'))):
+        if p.endswith(('.hip', '.h', '.cpp', '.inc', 'Makefile')):
+            h.update(os.path.basename(p).encode())
+            with open(p, 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_label):
-    """HBM bytes per launch of `kernel_label` from the committed PMC passes (profiles/pmc_latest.json: FETCH_SIZE +
-    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command and calibrated on a known-size copy,
-    tools/profile_gpu.sh + tools/profile_summarise.py), or None when that kernel was not profiled."""
+    """(HBM bytes per launch of `kernel_label`, note) from the committed PMC passes (profiles/pmc_latest.json: FETCH_SIZE
+    + WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command and calibrated on a known-size copy,
+    tools/profile_gpu.sh + tools/profile_summarise.py)."""
     path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
     if not os.path.exists(path):
-        return None
+        return None, 'profiles/pmc_latest.json missing'
     with open(path) as f:
-        # labels are the rocprofv3 symbol + optional " +res"/" +pool"/" lowres-half" annotations of the launch
-        k = json.load(f).get('kernels', {}).get(kernel_label.split(')')[0] + ')')
-    return k.get('hbm_bytes_per_launch') if k else None
+        pmc = json.load(f)
+    if pmc.get('source_sha') != source_sha():
+        return None, 'profiles/pmc_latest.json was measured on other kernel sources (sha %s, now %s): refused' % (
+            pmc.get('source_sha'), source_sha())
+    # labels are the rocprofv3 symbol + optional " +res"/" +pool"/" lowres-half" annotations of the launch
+    k = pmc.get('kernels', {}).get(kernel_label.split(')')[0] + ')')
+    if not k or k.get('hbm_bytes_per_launch') is None:
+        return None, 'kernel not in profiles/pmc_latest.json'
+    return k['hbm_bytes_per_launch'], 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, calibrated), profiles/pmc_latest.json'
+
+
+def cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _oracle_splats(seed, term):
+    """The three per-frame warp/splats of one forecast frame + the hop quantisation, on the C oracle (3 host threads:
+    the C call releases the GIL)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import warp_splat as ow
+    inp = synth.make_inputs(b=1, t=T, h=H, w=W, seed=seed, **TERM[term])
+
+    def one(t):
+        o = ow.predict(inp, only_this_ind=t)
+        tid = torch.from_numpy(synth.ID2TRAINID)[o['seg'].long()]
+        q = ((o['depth'] + 1).clamp(0, 255) * 256).round().numpy().astype(np.uint16)
+        d = torch.from_numpy(q.astype(np.float32)) / 256.0 - 1
+        m = d > 0
+        d[~m] = -1
+        d[m & (d > 200)] = 200
+        d[m & (d < 0.1)] = 0.1
+        return tid, d
+    with ThreadPoolExecutor(T) as ex:
+        res = list(ex.map(one, range(T)))
+    return torch.stack([r[0] for r in res], 1).long(), torch.stack([r[1] for r in res], 1)
 
 
 def cpu_baseline(sd, n_frames, term='short'):
-    """The oracle (CPU port of the reference path) timed on this box's host cores."""
-    import numpy as np
+    """The oracle (CPU port of the reference path) timed on ALL of this box's host cores: the three splats of a frame
+    run on three threads (scalar C, the scatter itself is sequential like pytorch_scatter's CPU loop) and are
+    prefetched one frame ahead while torch-CPU runs the network of the current frame on os.cpu_count() threads."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import hardnet_ref
     from oracle import warp_splat as ow
-    torch.set_num_threads(min(os.cpu_count(), CPU_THREADS))
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(ncpu)
     ow.lib()
     last = None
+    pre = ThreadPoolExecutor(1)
     t0 = time.perf_counter()
+    nxt = pre.submit(_oracle_splats, 0, term)
+    done = 0
     for f in range(n_frames):
-        if f > 0 and time.perf_counter() - t0 > CPU_BUDGET_S:
-            n_frames = f
-            break
-        inp = synth.make_inputs(b=1, t=T, h=H, w=W, seed=f, **TERM[term])
-        segs, deps = [], []
-        for t in range(T):
-            o = ow.predict(inp, only_this_ind=t)
-            tid = torch.from_numpy(synth.ID2TRAINID)[o['seg'].long()]
-            q = ((o['depth'] + 1).clamp(0, 255) * 256).round().numpy().astype(np.uint16)
-            d = torch.from_numpy(q.astype(np.float32)) / 256.0 - 1
-            m = d > 0
-            d[~m] = -1
-            d[m & (d > 200)] = 200
-            d[m & (d < 0.1)] = 0.1
-            segs.append(tid)
-            deps.append(d)
-        seg, dep = torch.stack(segs, 1).long(), torch.stack(deps, 1)
+        seg, dep = nxt.result()
+        more = f + 1 < n_frames and time.perf_counter() - t0 <= CPU_BUDGET_S
+        if more:
+            nxt = pre.submit(_oracle_splats, f + 1, term)
         last = hardnet_ref.bg_predict(sd, {'seg': seg, 'depth': dep, 'depth_mask': dep > 0}, final_size=(H, W))
+        done = f + 1
+        if not more:
+            break
     dt = time.perf_counter() - t0
+    pre.shutdown()
     # the generation of synthetic inputs is inside the loop but is <3 % of it
-    return n_frames / dt, dt, last, n_frames
+    return done / dt, dt, last, done, ncpu
 
 
-def main():
+class Workload:
+    """B forecast frames per step as S concurrent sub-batches (own model object, workspaces and HIP stream each) inside
+    one captured hipGraph.  The low-resolution layers of one sub-batch (small grids, latency-bound) and its memory-bound
+    splat/stem kernels overlap the matrix-bound high-resolution layers of another."""
+
+    def __init__(self, sd, B, S, dev, seed0, term, use_graph=True, **model_kw):
+        if B % S:
+            raise SystemExit('--batch must be a multiple of --streams')
+        self.B, self.S, self.use_graph = B, S, use_graph
+        self.batch = make_batch(B, seed0=seed0, device=dev, term=term)
+        self.models = []
+        for _ in range(S):
+            m = build_model(model_params(**model_kw))
+            m.load_state_dict(sd)
+            m.eval()
+            self.models.append(m)
+        sub = B // S
+        self.subs = [{k: v[i * sub:(i + 1) * sub].contiguous() for k, v in self.batch.items()} for i in range(S)]
+        self.side = [torch.cuda.Stream() for _ in range(S - 1)]
+        self.out = self.step()          # builds the plans, sizes the workspaces
+        torch.cuda.synchronize()
+        self.run = self.step
+        if use_graph:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self.step()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self.step()
+            self.run = self.graph.replay
+
+    def step(self):
+        cur = torch.cuda.current_stream()
+        outs = [None] * self.S
+        for i in range(1, self.S):
+            self.side[i - 1].wait_stream(cur)
+            with torch.cuda.stream(self.side[i - 1]):
+                outs[i] = self.models[i].predict(self.subs[i], None)
+        outs[0] = self.models[0].predict(self.subs[0], None)
+        for i in range(1, self.S):
+            cur.wait_stream(self.side[i - 1])
+        return outs
+
+    def timed(self, steps, warmup, dev, barrier=False):
+        for _ in range(warmup):
+            self.run()
+        if barrier and pfdist.is_dist():
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.run()
+        torch.cuda.synchronize()
+        if barrier and pfdist.is_dist():
+            torch.distributed.barrier()
+        return pfdist.max_over_ranks(time.perf_counter() - t0, dev) if barrier else time.perf_counter() - t0
+
+    def outputs(self):
+        return {k: torch.cat([o[k] for o in self.out]) for k in self.out[0]}
+
+
+STAGES = (('splat', ('bin_kernel', 'raster_kernel', 'splat')), ('stem', ('stem',)), ('head', ('head',)),
+          ('convs', ('conv_',)))
+
+
+def stage_of(label):
+    for name, keys in STAGES:
+        if any(k in label for k in keys):
+            return name
+    return 'other'
+
+
+def roofline_of(recs, n_steps, frames, measured_on):
+    """Dominant kernel + whole-step accounting from the live hipEvent records [{label, launches, ms, flops, bytes}]."""
+    tot = sum(r['ms'] for r in recs)
+    dom = max(recs, key=lambda r: r['ms'])
+    per_launch_ms = dom['ms'] / dom['launches']
+    gbs = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
+    if dom['flops'] > 0:
+        achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+        if 'conv_split' in dom['label'] or 'hblock' in dom['label']:
+            # every algorithmic fp32 MAC is 3 bf16 MFMA MACs (hi*hi + hi*mid + mid*hi): the matrix ceiling of this
+            # scheme, in algorithmic flops, is the dense bf16 peak / 3
+            peak, note = PEAK_BF16_MFMA_TFLOPS / 3.0, 'dense bf16 MFMA peak 2500 TFLOP/s / 3 products per fp32 MAC'
+        else:
+            peak, note = PEAK_FP32_MFMA_TFLOPS, 'fp32 MFMA (= fp32 vector) peak'
+        mf, hf = achieved / peak, gbs / PEAK_HBM_GBPS
+        # both fractions are reported (SURVEY.md 8d); `bound` names the larger one
+        if mf >= hf:
+            roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': mf, 'peak_note': note,
+                        'hbm_frac': hf, 'hbm_GBps_algorithmic': gbs}
+        else:
+            roofline = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': hf,
+                        'mfma_frac': mf, 'mfma_TFLOPs_algorithmic': achieved, 'mfma_peak': peak, 'peak_note': note}
+    else:
+        roofline = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBPS}
+    conv = [r for r in recs if r['flops'] > 0]
+    conv_ms = sum(r['ms'] for r in conv)
+    traffic, tnote = pmc_traffic(dom['label'])
+    roofline.update({'traffic': traffic, 'traffic_note': tnote, 'kernel': dom['label'],
+                     'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
+                     'launches_per_step': dom['launches'] // n_steps,
+                     'avg_launch_us': per_launch_ms * 1e3, 'share_of_step': dom['ms'] / tot,
+                     'all_conv_tflops': sum(r['flops'] for r in conv) / (conv_ms * 1e-3) / 1e12 if conv_ms else None,
+                     'kernel_ms_per_step': tot / n_steps, 'measured_on': measured_on})
+    # whole step: sum of the algorithmic bytes of every launch / sum of kernel time, against the HBM peak
+    stages = {}
+    for r in recs:
+        st = stages.setdefault(stage_of(r['label']), {'ms': 0.0, 'bytes': 0.0, 'flops': 0.0})
+        st['ms'] += r['ms'] / n_steps
+        st['bytes'] += r['bytes'] / n_steps
+        st['flops'] += r['flops'] / n_steps
+    for st in stages.values():
+        st['GBps'] = st['bytes'] / (st['ms'] * 1e-3) / 1e9 if st['ms'] > 0 else None
+        st['hbm_frac'] = st['GBps'] / PEAK_HBM_GBPS if st['GBps'] else None
+        st['MB_per_frame'] = st.pop('bytes') / frames / 1e6
+        st['GFLOP_per_frame'] = st.pop('flops') / frames / 1e9
+    tot_bytes = sum(r['bytes'] for r in recs) / n_steps
+    roofline['step'] = {'bound': 'hbm', 'algorithmic_MB_per_frame': tot_bytes / frames / 1e6,
+                        'kernel_ms': tot / n_steps, 'achieved': tot_bytes / (tot / n_steps * 1e-3) / 1e9,
+                        'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                        'frac': tot_bytes / (tot / n_steps * 1e-3) / 1e9 / PEAK_HBM_GBPS, 'stages': stages}
+    return roofline
+
+
+def profile_records(fn, n_steps):
+    from panoptic_forecasting_amd import lib as pflib
+    pflib.profile(True)
+    for _ in range(n_steps):
+        fn()
+    torch.cuda.synchronize()
+    recs = pflib.profile_results()
+    pflib.profile(False)
+    return recs
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -124,19 +339,62 @@ def main():
                     'batches 2; throughput saturates around 32-48 frames in flight as two or three concurrent sub-batches of 16)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-legs', action='store_true', help='skip the by_batch / fp32_only legs (N=1 only)')
     ap.add_argument('--cpu-frames', type=int, default=12)
     ap.add_argument('--profile-steps', type=int, default=3)
-    ap.add_argument('--fp32-mfma-only', action='store_true', help='disable the bf16-split 3x3 kernels (pf_set_option split_bf16=0): '
-                    'every convolution on v_mfma_f32_16x16x4_f32 / the fp32 VALU')
+    ap.add_argument('--fp32-mfma-only', action='store_true', help='headline itself without the bf16-split kernels '
+                    "(model param split_bf16=0): every convolution on v_mfma_f32_16x16x4_f32 / the fp32 VALU")
     ap.add_argument('--streams', type=int, default=0, help='sub-batches run concurrently on this many HIP streams '
                     '(0 = one per 16 frames of the batch)')
     ap.add_argument('--term', choices=['short', 'mid'], default='short',
                     help="short = BASELINE configs[1] (dt=3, the headline); mid = configs[2] (dt=9, predicted odometry)")
-    args = ap.parse_args()
+    ap.add_argument('--dry-run', action='store_true', help='rendezvous + the sharded metric exchange only (gloo, no GPU '
+                    'work): checks that --gpus N really starts N ranks')
+    return ap.parse_args(argv)
 
-    rank, world, local = pfdist.init_distributed_mode()
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+
+def relaunch_under_torchrun(args):
+    """python bench.py --gpus N (N > 1) from a plain shell: become the launcher of N ranks."""
+    if not args.dry_run and torch.cuda.device_count() < args.gpus:
+        raise SystemExit('bench.py: --gpus %d but this node has %d GPU(s)' % (args.gpus, torch.cuda.device_count()))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (RCCL across processes needs it on this pool)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        relaunch_under_torchrun(args)
+    rank, world, local = pfdist.init_distributed_mode(backend='gloo' if args.dry_run else None)
+    joined = torch.distributed.get_world_size() if pfdist.is_dist() else 1
+    if world != args.gpus or joined != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but %d rank(s) joined (WORLD_SIZE=%d)' % (args.gpus, joined, world))
+
+    if args.dry_run:
+        from panoptic_forecasting_amd import pq as pfpq
+        acc = torch.zeros(11, 4, dtype=torch.float64)
+        acc[:, 1] = rank + 1           # every rank contributes a different count
+        allacc = pfdist.gather_accumulators(acc)
+        ok = allacc.shape[0] == world and float(allacc[:, 0, 1].sum()) == world * (world + 1) / 2
+        if rank == 0:
+            print(json.dumps({'metric': 'forecast frames/sec @1024x2048, 3-in->dt=3 bg', 'value': None, 'unit': 'frames/s',
+                              'n_gpus': joined, 'dry_run': True, 'backend': 'gloo', 'gather_ok': bool(ok),
+                              'sharding': 'batch over %d rank(s), no data-path collective' % world}))
+        if pfdist.is_dist():
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        if not ok:
+            raise SystemExit(1)
+        return
+
+    if torch.cuda.device_count() < (local + 1):
+        raise SystemExit('bench.py: rank %d (local %d) has no GPU: %d visible' % (rank, local, torch.cuda.device_count()))
+    from panoptic_forecasting_amd import lib as pflib
+    from panoptic_forecasting_amd import pq as pfpq
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     L = pflib.load()   # fails loudly if libpfhip.so is missing
@@ -144,169 +402,114 @@ def main():
         k, v = kv.split('=')
         pflib.check(L.pf_set_option(k.encode(), int(v)), 'pf_set_option')
 
-    if args.fp32_mfma_only:
-        pflib.check(L.pf_set_option(b'split_bf16', 0), 'pf_set_option')
     sd = calibrated_state_dict()
-    model = build_model(model_params())
-    model.load_state_dict(sd)
-    model.eval()
     B = args.batch
-    batch = make_batch(B, seed0=rank * B, device=dev, term=args.term)
-
-    # --streams S > 1: the per-rank batch is cut into S sub-batches, each with its own model object (own workspaces,
-    # weights re-packed per plan) on its own HIP stream inside the captured step; the low-resolution layers of one
-    # sub-batch (small grids, latency-bound) and its memory-bound splat/stem kernels then overlap the matrix-bound
-    # high-resolution layers of another.
-    S = max(1, min(args.streams, B)) if args.streams > 0 else max(1, B // 16)
-    if S > 1:
-        if B % S:
-            raise SystemExit('--batch must be a multiple of --streams')
-        models = [model] + [build_model(model_params()) for _ in range(S - 1)]
-        for m in models[1:]:
-            m.load_state_dict(sd)
-            m.eval()
-        sub = B // S
-        subs = [{k: v[i * sub:(i + 1) * sub].contiguous() for k, v in batch.items()} for i in range(S)]
-        side = [torch.cuda.Stream() for _ in range(S - 1)]
-
-    def step():
-        if S == 1:
-            return model.predict(batch, None)
-        cur = torch.cuda.current_stream()
-        outs = [None] * S
-        for i in range(1, S):
-            side[i - 1].wait_stream(cur)
-            with torch.cuda.stream(side[i - 1]):
-                outs[i] = models[i].predict(subs[i], None)
-        outs[0] = models[0].predict(subs[0], None)
-        for i in range(1, S):
-            cur.wait_stream(side[i - 1])
-        return outs
-
-    out = step()          # builds the plan, sizes the workspaces
-    torch.cuda.synchronize()
+    S = max(1, min(args.streams, B)) if args.streams > 0 else max(1, B // SUB_BATCH)
     use_graph = not args.no_graph
-    graph = None
-    if use_graph:
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                step()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = step()
-        run = graph.replay
-    else:
-        run = step
-
-    for _ in range(args.warmup):
-        run()
-    if pfdist.is_dist():
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    if pfdist.is_dist():
-        torch.distributed.barrier()
-    elapsed = pfdist.max_over_ranks(time.perf_counter() - t0, dev)
+    head_kw = {'split_bf16': 0} if args.fp32_mfma_only else {}
+    wl = Workload(sd, B, S, dev, seed0=rank * B, term=args.term, use_graph=use_graph, **head_kw)
+    elapsed = wl.timed(args.steps, args.warmup, dev, barrier=True)
     frames = world * B * args.steps
     value = frames / elapsed
 
-    if S > 1:   # the sub-batch outputs are concatenated outside the timed region
-        out = {k: torch.cat([o[k] for o in out]) for k in out[0]}
     # ---- sharded metric exchange: PQ accumulators of this rank's forecasts vs a synthetic ground truth
-    gt = torch.from_numpy(synth.ID2TRAINID).to(dev)[batch['seg'][:, T - 1].long()].long()
+    out = wl.outputs()   # the sub-batch outputs are concatenated outside the timed region
+    gt = torch.from_numpy(synth.ID2TRAINID).to(dev)[wl.batch['seg'][:, T - 1].long()].long()
     acc = pfpq.pq_accumulate(out['seg'].long(), gt, 11)
     allacc = pfdist.gather_accumulators(acc)
     pq_synth = pfpq.pq_from_acc(allacc.sum(0))['pq']
 
-    # ---- per-kernel timing pass (eager, hipEvents on the launch stream) -> roofline of the dominant kernel
+    # ---- per-kernel timing pass (eager, hipEvents on the launch stream) -> roofline of the dominant kernel + whole step
     roofline = None
     if rank == 0:
         # one sub-batch alone on the launch stream: kernels of concurrent streams share the chip, which would inflate
         # the per-launch durations the roofline fraction is computed from
-        prof_step = (lambda: models[0].predict(subs[0], None)) if S > 1 else step
-        pflib.profile(True)
-        for _ in range(args.profile_steps):
-            prof_step()
-        torch.cuda.synchronize()
-        recs = pflib.profile_results()
-        pflib.profile(False)
-        tot = sum(r['ms'] for r in recs)
-        dom = max(recs, key=lambda r: r['ms'])
-        per_launch_ms = dom['ms'] / dom['launches']
-        gbs = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
-        if dom['flops'] > 0:
-            achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-            if 'conv_split' in dom['label']:
-                # every algorithmic fp32 MAC is 3 bf16 MFMA MACs (hi*hi + hi*mid + mid*hi): the matrix ceiling of this
-                # scheme, in algorithmic flops, is the dense bf16 peak / 3
-                peak, note = PEAK_BF16_MFMA_TFLOPS / 3.0, 'dense bf16 MFMA peak 2500 TFLOP/s / 3 products per fp32 MAC'
-            else:
-                peak, note = PEAK_FP32_MFMA_TFLOPS, 'fp32 MFMA (= fp32 vector) peak'
-            mf, hf = achieved / peak, gbs / PEAK_HBM_GBPS
-            # both fractions are reported; `bound` names the larger one
-            if mf >= hf:
-                roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': mf, 'peak_note': note,
-                            'hbm_frac': hf, 'hbm_GBps_algorithmic': gbs}
-            else:
-                roofline = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': hf,
-                            'mfma_frac': mf, 'mfma_TFLOPs_algorithmic': achieved, 'mfma_peak': peak, 'peak_note': note}
-        else:
-            roofline = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBPS}
-        conv = [r for r in recs if r['flops'] > 0]
-        conv_ms = sum(r['ms'] for r in conv)
-        roofline.update({'traffic': pmc_traffic(dom['label']), 'kernel': dom['label'], 'launches_per_step': dom['launches'] // args.profile_steps,
-                         'avg_launch_us': per_launch_ms * 1e3, 'share_of_step': dom['ms'] / tot,
-                         'all_conv_tflops': sum(r['flops'] for r in conv) / (conv_ms * 1e-3) / 1e12 if conv_ms else None,
-                         'kernel_ms_per_step': tot / args.profile_steps,
-                         'measured_on': 'one sub-batch of %d frames alone on the launch stream (eager, hipEvents)' % (B // S)})
+        recs = profile_records(lambda: wl.models[0].predict(wl.subs[0], None), args.profile_steps)
+        roofline = roofline_of(recs, args.profile_steps, B // S,
+                               'one sub-batch of %d frames alone on the launch stream (eager, hipEvents)' % (B // S))
         if os.environ.get('PF_BENCH_KERNELS'):
             for r in sorted(recs, key=lambda r: -r['ms']):
                 print('# %-70s n=%3d %8.3f ms  %7.2f TF/s %8.1f GB/s' % (
                     r['label'][:70], r['launches'] // args.profile_steps, r['ms'] / args.profile_steps,
                     r['flops'] / max(r['ms'], 1e-9) / 1e9, r['bytes'] / max(r['ms'], 1e-9) / 1e6), file=sys.stderr)
 
-    cpu = None
-    parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        fps, secs, ref, n_done = cpu_baseline(sd, args.cpu_frames, args.term)
-        cpu = {'value': fps, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-               'sample': '%d forecast frames @%dx%d (3 C-oracle splats on 1 thread + torch-CPU HarDNet on %d threads each), %.1f s'
-                         % (n_done, H, W, torch.get_num_threads(), secs)}
-        # full-size parity of the LAST cpu frame (seed cpu_frames-1) against the HIP path
-        chk = make_batch(1, seed0=n_done - 1, device=dev, term=args.term)
-        pl = model_params()
-        pl['model']['return_logits'] = True
-        lmodel = build_model(pl)
-        lmodel.load_state_dict(sd)
-        lmodel.eval()
-        res = lmodel.predict(chk, None)
-        got = res['seg'].long().cpu()
+    cpu = parity = by_batch = fp32_only = None
+    single = rank == 0 and world == 1
+    ref = None
+    n_done = 0
+    if single and not args.no_cpu_baseline:
+        fps, secs, ref, n_done, ncpu = cpu_baseline(sd, args.cpu_frames, args.term)
+        cpu = {'value': fps, 'unit': 'frames/s', 'cores': ncpu, 'kind': 'port', 'cpu_model': cpu_model_name(),
+               'sample': '%d forecast frames @%dx%d in %.1f s: per frame 3 C-oracle splats on 3 threads (prefetched one frame '
+                         'ahead) + torch-CPU HarDNet with torch.set_num_threads(%d = os.cpu_count())' % (n_done, H, W, secs, ncpu)}
+
+    def parity_of(sub, model_kw):
+        """Full-size parity of the LAST cpu frame (seed n_done-1) against the HIP path, computed inside the SAME
+        16-frame sub-batch the timed region runs (the per-layer kernel choice depends on the batch size)."""
+        idx = n_done - 1
+        if idx >= sub['depth'].shape[0]:
+            sub, idx = make_batch(1, seed0=idx, device=dev, term=args.term), 0
+        lm = build_model(model_params(return_logits='orig', **model_kw))
+        lm.load_state_dict(sd)
+        lm.eval()
+        res = lm.predict(sub, None)
+        got = res['seg'][idx:idx + 1].long().cpu()
         agree = float((got == ref['seg']).float().mean())
         pq_ref = pfpq.pq_from_acc(pfpq.pq_accumulate(got, ref['seg'], 11))['pq']
-        dlogit = float((res['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max())
-        parity = {'argmax_agreement_vs_oracle': agree, 'pq_vs_oracle_as_gt': pq_ref, 'max_abs_dlogit_vs_oracle': dlogit,
-                  'logit_tolerance': 1e-3}
+        dlogit = float((res['orig_size_logits'][idx:idx + 1].cpu() - ref['orig_size_logits']).abs().max())
+        return {'argmax_agreement_vs_oracle': agree, 'pq_vs_oracle_as_gt': pq_ref, 'max_abs_dlogit_vs_oracle': dlogit,
+                'logit_tolerance': 1e-3, 'checked_in_batch_of': int(sub['depth'].shape[0])}
+
+    sub0 = wl.subs[0]
+    if ref is not None:
+        parity = parity_of(sub0, head_kw)
+
+    if single and not args.no_legs:
+        del wl
+        torch.cuda.empty_cache()
+        # SURVEY.md 8d Config 2: B in {1, 2, 4} frames per step on ONE stream (B=1 is the latency configuration)
+        by_batch = {}
+        leg_steps = max(args.steps, 30)
+        for b in (1, 2, 4):
+            leg = Workload(sd, b, 1, dev, seed0=0, term=args.term, use_graph=use_graph, **head_kw)
+            dt = leg.timed(leg_steps, args.warmup, dev)
+            by_batch[str(b)] = {'value': b * leg_steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / leg_steps,
+                                'steps': leg_steps, 'streams': 1}
+            del leg
+            torch.cuda.empty_cache()
+        if not args.fp32_mfma_only:
+            # strict-precision configuration: no bf16 operand split anywhere (fp32 MFMA / fp32 VALU only)
+            leg = Workload(sd, B, S, dev, seed0=0, term=args.term, use_graph=use_graph, split_bf16=0)
+            dt = leg.timed(args.steps, args.warmup, dev)
+            fp32_only = {'value': B * args.steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / args.steps,
+                         'frames_per_gpu_per_step': B, 'streams': S, 'dtype': 'f32'}
+            recs = profile_records(lambda: leg.models[0].predict(leg.subs[0], None), args.profile_steps)
+            r32 = roofline_of(recs, args.profile_steps, B // S, 'one sub-batch, eager, hipEvents')
+            fp32_only['roofline'] = {k: r32[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'avg_launch_us',
+                                                         'kernel_ms_per_step')}
+            fp32_only['roofline_step_frac'] = r32['step']['frac']
+            if ref is not None:
+                p32 = parity_of(leg.subs[0], {'split_bf16': 0})
+                fp32_only['max_abs_dlogit'] = p32['max_abs_dlogit_vs_oracle']
+                fp32_only['argmax_agreement_vs_oracle'] = p32['argmax_agreement_vs_oracle']
+            del leg
+            torch.cuda.empty_cache()
 
     if rank == 0:
         line = {'metric': 'forecast frames/sec @1024x2048, 3-in->dt=%d bg' % (3 if args.term == 'short' else 9), 'value': value, 'unit': 'frames/s',
-                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+                'n_gpus': joined, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                'dtype': 'f32' if args.fp32_mfma_only else 'f32 (storage, accumulation, 1x1/strided/low-res convs: fp32 MFMA; tuned 3x3 layers: '
+                'dtype': 'f32' if args.fp32_mfma_only else 'f32 (storage, accumulation, strided/low-res convs: fp32 MFMA; tuned 3x3 and 1x1 layers: '
                          'operands split into bf16 hi+mid, 3 products on the bf16 MFMA, fp32 accumulate)', 'data': 'synthetic',
                 'config': {'workload': ('configs[1]: bg short-term forecast, 3 frames in, dt=3' if args.term == 'short' else
                                         'configs[2]: bg mid-term forecast, 3 frames in, dt=9, predicted-odometry ego chain') +
                                        ', 1024x2048, random-init calibrated weights; step = 3 warp/splats + HarDNet + upsample/argmax',
                            'frames_per_gpu_per_step': B, 'streams': S, 'launch': 'hipGraph replay' if use_graph else 'eager',
-                           'sharding': 'batch over %d rank(s), no data-path collective' % world},
-                'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity,
-                'pq_gather_check': {'pq_vs_last_input_labels': pq_synth,
+                           'sharding': 'batch over %d rank(s), no data-path collective' % world,
+                           'world': joined, 'device': torch.cuda.get_device_name(local),
+                           'backend': 'nccl (RCCL)' if pfdist.is_dist() else 'single process'},
+                'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity, 'by_batch': by_batch, 'fp32_only': fp32_only,
+                'pq_gather_check': {'pq_vs_last_input_labels': pq_synth, 'ranks_gathered': int(allacc.shape[0]),
                                     'note': 'random-init weights: value is meaningless, it exercises the sharded PQ all-gather'}}
         print(json.dumps(line))
     if pfdist.is_dist():

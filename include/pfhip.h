@@ -55,10 +55,15 @@ const char *pf_last_error(void);
  *   Kinv,K     [B,3,3] f32   E,Einv [B,4,4] f32   T_tgt [B,T_total,4,4] f32
  *     (Kinv/Einv are the caller's torch.inverse(K)/torch.inverse(E): LAPACK bits decide floor())
  *   frames t_first .. t_first+T-1 are warped (only_this_ind => t_first=ind, T=1; else 0, T_total).
- *   per_frame = 0: all T frames share ONE z-buffer (reference semantics of a single predict call)
+ *   per_frame is a bit set (PF_SPLAT_*):
+ *   PF_SPLAT_PER_FRAME clear: all T frames share ONE z-buffer (reference semantics of a single predict call)
  *                  out_seg [B,H,W,C] u8, out_depth [B,H,W] f32
- *   per_frame = 1: every frame gets its own z-buffer and its own sentinel, i.e. T independent
+ *   PF_SPLAT_PER_FRAME set:   every frame gets its own z-buffer and its own sentinel, i.e. T independent
  *                  only_this_ind=t calls in one launch: out_seg [B,T,H,W,C], out_depth [B,T,H,W]
+ *   PF_SPLAT_PER_SAMPLE_SENTINEL set: the sentinel max+1 (:105) is taken per sample instead of over the whole batch
+ *                  of the call (the reference's `.max()` spans the batch, so the depth written at holes won by
+ *                  invalid points depends on which samples share a predict call; with this bit a sample's output is
+ *                  what the reference gives for it at batch size 1 — SURVEY.md 8e opt-in)
  *   out_result2d (nullable) [B,T,H,W,2] i64: clamped (x,y) of the floor/floor corner (:147)
  *
  * Winner rule: minimum depth; ties -> lowest source element index e = r*P + t*N + n (r = corner
@@ -66,6 +71,8 @@ const char *pf_last_error(void);
  * points yield seg=0, depth=max+1 (:105,:133); untouched bins seg=0, depth=-1 (:136-138).
  * Out of contract: non-finite projected coordinates, |z| >= 2^24.
  */
+#define PF_SPLAT_PER_FRAME 1
+#define PF_SPLAT_PER_SAMPLE_SENTINEL 2
 int pf_warp_splat_workspace(int B, int T, int H, int W, int per_frame, size_t *bytes);
 int pf_warp_splat(const float *depth, const uint8_t *depth_mask, const uint8_t *seg, int seg_channels,
                   const float *Kinv, const float *E, const float *T_tgt, const float *Einv,
@@ -186,6 +193,13 @@ int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void 
  *                   2e-4*(1+max|ref|) of fp64; the fp32 kernels 2e-5); 0 = every convolution on fp32 MFMA / fp32 VALU;
  *   "valu_remainder" (default 1) trailing cout % 16 <= 8 channels of a conv_dma layer on the vector ALU. */
 int pf_set_option(const char *name, int value);
+/* The same options per plan: a plan copies the process-wide values when it is created; this call changes them for
+ * that plan only (read at forward time by forwards of that plan; a plan is used from one thread at a time).  One more
+ * name exists only here:
+ *   "table_batch"   (default 0) n > 0: the per-layer kernel table is consulted as if every forward had a batch of n —
+ *                   a frame's logits then do not depend on how many frames share the call (the tuned table is keyed on
+ *                   the batch size, and the bf16-split and fp32 kernels differ in the last bits). */
+int pf_hardnet_plan_set_option(pf_plan *plan, const char *name, int value);
 
 /* Introspection for per-stage parity tests: where tensor `name` (packing.py tensor names, e.g.
  * "base.4.out") lives inside the workspace for this (B,H,W): byte offset, channels, height, width. */

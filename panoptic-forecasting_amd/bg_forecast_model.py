@@ -29,7 +29,8 @@ class BGForecastModel(BaseModel):
         self.bg = BGModel(params)
         self.emulate_disk_hop = mp.get('emulate_disk_hop', True)
         self.seg_is_label_id = mp.get('seg_is_label_id', True)   # export run used --convert_to_trainid
-        self.return_logits = mp.get('return_logits', False)
+        self.return_logits = mp.get('return_logits', False)   # True: full-size + network-size logits; 'orig': network-size only
+        self.per_sample_sentinel = bool(mp.get('per_sample_sentinel', False))   # see pc_transform_model.PCTransformModel
         self._splat = WarpSplat()
 
     # checkpoint compatibility: a reference bg_model.pt loads straight into the fused model
@@ -43,17 +44,19 @@ class BGForecastModel(BaseModel):
         seg_w, depth_w, _ = self._splat(inputs['depth'], inputs['depth_mask'], inputs['seg'],
                                         inputs['intrinsics'], inputs['extrinsics'], inputs['target_T'],
                                         Kinv=inputs.get('intrinsics_inv'), Einv=inputs.get('extrinsics_inv'),
-                                        per_frame=True, want_result2d=False)
+                                        per_frame=True, want_result2d=False,
+                                        per_sample_sentinel=self.per_sample_sentinel)
         hop = 0
         if self.emulate_disk_hop:
             hop |= PF_HOP_DEPTH_U16
         if self.seg_is_label_id:
             hop |= PF_HOP_TRAINID_LUT
         mask = None if (hop & PF_HOP_DEPTH_U16) else (depth_w > 0)
-        seg, logits, orig = self.bg.run(seg_w, depth_w, mask, want_logits=self.return_logits,
-                                        want_orig=self.return_logits, hop_flags=hop, seg_dtype=torch.uint8)
+        seg, logits, orig = self.bg.run(seg_w, depth_w, mask, want_logits=self.return_logits is True,
+                                        want_orig=bool(self.return_logits), hop_flags=hop, seg_dtype=torch.uint8)
         out = {'seg': seg, 'warped_seg': seg_w, 'warped_depth': depth_w}
         if logits is not None:
             out['logits'] = logits
+        if orig is not None:
             out['orig_size_logits'] = orig
         return out

@@ -19,6 +19,11 @@ from .model_api import BaseModel
 from .pc_transform_model import _as_u8
 
 
+# params['model'] key -> option name of pf_hardnet_plan_set_option
+PLAN_OPTIONS = {'split_bf16': 'split_bf16', 'fuse_pool': 'fuse_pool', 'fuse_upsample': 'fuse_upsample',
+                'use_tuned_table': 'use_tuned_table', 'valu_remainder': 'valu_remainder', 'conv_table_batch': 'table_batch'}
+
+
 class _Node(nn.Module):
     """Anonymous container: gives dotted state_dict paths without any behaviour."""
 
@@ -99,6 +104,12 @@ class BGModel(BaseModel):
         pretrain = params['model'].get('hardnet', {}).get('pretrain_path')
         if pretrain is not None:
             self.model.load_pretrained(pretrain)
+        # execution options of this model's device plan (include/pfhip.h: pf_hardnet_plan_set_option); absent keys keep
+        # the library defaults.  ``split_bf16: 0`` = strict fp32 arithmetic in every convolution (logits within 1e-4 of
+        # the fp32 reference instead of 1e-3); ``conv_table_batch: n`` pins the per-layer kernel choice to the one made
+        # for batches of n, so a frame's logits do not depend on the size of the batch it arrives in.
+        self.plan_options = {c_name: int(params['model'][key]) for key, c_name in PLAN_OPTIONS.items()
+                             if params['model'].get(key) is not None}
         self._plan = None
         self._ws = None
         self._norm = None
@@ -131,6 +142,8 @@ class BGModel(BaseModel):
             _lib.check(L.pf_hardnet_plan_create(buf, len(blob), self.in_ch, self.num_classes, ctypes.byref(plan)),
                        'pf_hardnet_plan_create')
             self._plan = plan
+            for name, value in self.plan_options.items():
+                _lib.check(L.pf_hardnet_plan_set_option(plan, name.encode(), value), 'pf_hardnet_plan_set_option')
             if self.use_depth_inps:
                 self._norm = (float(self.depth_mean.item()), float(self.depth_std.item()))
         return self._plan

@@ -117,7 +117,7 @@ struct ConvChoice {
     int kind, p0, p1, p2;
 };
 // need: bit 1 = even tile rows if conv_wave is chosen (pooling epilogue)
-ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B, int need = 0);
+ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B, int need = 0, int use_tuned = 1);
 long long *probe_buffer();
 // tuning hook (pf_debug_force_conv): kind 0 = automatic
 extern ConvChoice g_conv_force;

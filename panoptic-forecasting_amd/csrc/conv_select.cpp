@@ -26,10 +26,10 @@ size_t wave_lds_bytes(int ks, int mh, int nt, int wk) {
 }
 }  // namespace
 
-ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B, int need) {
+ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B, int need, int use_tuned) {
     if (stride != 1) return ConvChoice{1, 0, 0, 0};           // conv_dma, shape by its cost model
     for (const Tuned &t : kTuned)
-        if (g_opt_use_tuned && t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == B &&
+        if (use_tuned && t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == B &&
             (!(need & 2) || t.c.kind != 2 || t.c.p0 != 1))
             return t.c;
     // Untuned shape.  Large stride-1 3x3 layers go to the bf16-split kernel: on every measured shape with >= 64x128

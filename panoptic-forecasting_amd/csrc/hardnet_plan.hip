@@ -43,6 +43,10 @@ struct pf_plan {
     float *dev_weights = nullptr;
     uint8_t *dev_lut = nullptr;
     size_t dev_floats = 0;
+    // execution options of THIS plan (pf_hardnet_plan_set_option); initialised from the process-wide defaults
+    // (pf_set_option) when the plan is created and read only by forwards of this plan
+    int opt_fuse_pool = 1, opt_fuse_upsample = 1, opt_valu_rem = 1, opt_split_bf16 = 1, opt_use_tuned = 1;
+    int opt_table_batch = 0;   // > 0: per-layer kernel choice as if the batch were this (batch-invariant numerics)
 };
 
 namespace pf {
@@ -58,6 +62,18 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "valu_remainder")) g_opt_valu_rem = value;
     else if (!strcmp(name, "split_bf16")) g_opt_split_bf16 = value;
     else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);
+    return PF_OK;
+}
+
+extern "C" int pf_hardnet_plan_set_option(pf_plan *p, const char *name, int value) {
+    if (!p || !name) return fail(PF_EINVAL, "pf_hardnet_plan_set_option: null argument");
+    if (!strcmp(name, "fuse_pool")) p->opt_fuse_pool = value;
+    else if (!strcmp(name, "fuse_upsample")) p->opt_fuse_upsample = value;
+    else if (!strcmp(name, "use_tuned_table")) p->opt_use_tuned = value;
+    else if (!strcmp(name, "valu_remainder")) p->opt_valu_rem = value;
+    else if (!strcmp(name, "split_bf16")) p->opt_split_bf16 = value;
+    else if (!strcmp(name, "table_batch")) p->opt_table_batch = value < 0 ? 0 : value;
+    else return fail(PF_EINVAL, "pf_hardnet_plan_set_option: unknown option '%s'", name);
     return PF_OK;
 }
 
@@ -136,7 +152,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
     };
 
     static const bool tag_ops = getenv("PF_PROFILE_OPS") != nullptr;
-    const bool fuse = g_opt_fuse_pool != 0;      // pf_set_option("fuse_pool", 0/1)
+    const bool fuse = p->opt_fuse_pool != 0;      // option "fuse_pool"
 
     auto fill_conv_args = [&](const BlobOp &o, size_t i, const Dims &in, const Dims &out, ConvArgs &a) {
         memset(&a, 0, sizeof(a));
@@ -172,7 +188,8 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.nchunks = p->conv[i].tiling.nchunks;
             return launch_conv(a, p->conv[i].tiling, B, s);
         }
-        ConvChoice ch = choose_conv((int)o.k, (int)o.stride, a.Cin, a.Cout, a.Hout, a.Wout, B, need);
+        ConvChoice ch = choose_conv((int)o.k, (int)o.stride, a.Cin, a.Cout, a.Hout, a.Wout, p->opt_table_batch > 0 ? p->opt_table_batch : B, need,
+                                    p->opt_use_tuned);
         if (g_conv_force.kind == 2 && o.stride == 1) {
             ch = g_conv_force;
             if ((need & 2) && ch.p0 == 1) ch.p0 = 2;
@@ -180,7 +197,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         if (g_conv_force.kind == 1) ch = g_conv_force;
         if (g_conv_force.kind == 3 && p->conv[i].has_valu && !need) ch = g_conv_force;
         if (g_conv_force.kind == 4 && p->conv[i].has_split && (!need || o.k == 1)) ch = g_conv_force;
-        if (ch.kind == 4 && (!p->conv[i].has_split || (need && o.k != 1) || !g_opt_split_bf16)) ch = ConvChoice{1, 0, 0, 0};
+        if (ch.kind == 4 && (!p->conv[i].has_split || (need && o.k != 1) || !p->opt_split_bf16)) ch = ConvChoice{1, 0, 0, 0};
         if (ch.kind == 3 && (!p->conv[i].has_valu || need)) ch = ConvChoice{1, 0, 0, 0};
         int rc = PF_EUNSUPPORTED;
         auto set_chunks = [&](int kc) {
@@ -219,7 +236,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             // the trailing rem_count output channels of a big image go to the vector ALU instead of an MFMA tile
             // (conv_dma WM=4 shapes only: forced or cost-model-chosen WM is checked inside, which falls back)
             a.rem = 0;
-            if (g_opt_valu_rem && p->conv[i].rem_off && !need && a.src_begin == 0 && a.src_end == a.n_src &&
+            if (p->opt_valu_rem && p->conv[i].rem_off && !need && a.src_begin == 0 && a.src_end == a.n_src &&
                 (ch.p0 == 0 || ch.p0 == 4)) {
                 a.rem = p->conv[i].rem_count;
                 a.wrem = p->dev_weights + p->conv[i].rem_off;
@@ -235,7 +252,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         return rc;
     };
     // pf_set_option("fuse_upsample", 0/1); at B=4: transUp.3 + conv1x1_up.3 144 us fused vs 233 us as two passes
-    const bool fuse_up = g_opt_fuse_upsample != 0;   // pf_set_option("fuse_upsample", 0/1)
+    const bool fuse_up = p->opt_fuse_upsample != 0;   // option "fuse_upsample"
     auto can_commute_upsample = [&](size_t i, const Dims &in, const Dims &out) -> bool {
         if (!fuse || !fuse_up || i + 1 >= p->ops.size()) return false;
         const BlobOp &o = p->ops[i], &n = p->ops[i + 1];
@@ -371,6 +388,8 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
     if ((int)h.in_ch != in_ch || (int)h.n_cls != n_cls)
         return fail(PF_EINVAL, "blob is for in_ch=%u n_cls=%u, caller asked for %d/%d", h.in_ch, h.n_cls, in_ch, n_cls);
     pf_plan *p = new pf_plan();
+    p->opt_fuse_pool = g_opt_fuse_pool; p->opt_fuse_upsample = g_opt_fuse_upsample; p->opt_valu_rem = g_opt_valu_rem;
+    p->opt_split_bf16 = g_opt_split_bf16; p->opt_use_tuned = g_opt_use_tuned;
     p->hdr = h;
     p->tensors.resize(h.n_tensors);
     p->ops.resize(h.n_ops);

@@ -61,6 +61,7 @@ struct SplatArgs {
     float *out_depth;
     long long *out_r2d;
     int B, T_total, t_first, T, H, W, C, per_frame;
+    int zgroups_per_sample;   // 0: one sentinel per z-buffer group over the whole call (:105); G: one per (sample, group)
     int stx, sty;         // source tiles per row / column
     int dtx, dty;         // destination tiles per row / column
     long long *probe;     // PF_PROBE builds only
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
         const long long ntile = (long long)a.stx * a.sty;
         // :105 the sentinel is max(z)+1 over the whole predict call (one frame's points in per_frame mode): one
         // order-independent atomicMax per source tile instead of every raster workgroup re-reducing all partials
-        atomicMax(&a.zmax_part[(a.per_frame ? tl : 0) * kZSlots + ((tile + b) & (kZSlots - 1))], float_to_ordered(zmax));
+        atomicMax(&a.zmax_part[(b * a.zgroups_per_sample + (a.per_frame ? tl : 0)) * kZSlots + ((tile + b) & (kZSlots - 1))], float_to_ordered(zmax));
         a.bbox[((long long)b * a.T + tl) * ntile + tile] = make_int4(bx0, by0, bx1, by1);
     }
 }
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
 
     // sentinel = max(z over the whole predict call) + 1 (:105); one frame's points in per_frame mode
     if (threadIdx.x < 64) {
-        unsigned m = a.zmax_part[(a.per_frame ? g : 0) * kZSlots + threadIdx.x];
+        unsigned m = a.zmax_part[(b * a.zgroups_per_sample + (a.per_frame ? g : 0)) * kZSlots + threadIdx.x];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
         if (threadIdx.x == 0) sentinel_s = __fadd_rn(ordered_to_float(m), 1.0f);
@@ -419,7 +420,7 @@ static SplatLayout splat_layout(int B, int T, int H, int W, int per_frame) {
     const size_t ntile = (size_t)L.stx * L.sty, N = (size_t)H * W;
     L.bbox_off = 0;
     L.zmax_off = align_up(L.bbox_off + (size_t)B * T * ntile * sizeof(int4), 256);
-    L.mark_off = align_up(L.zmax_off + (size_t)T * kZSlots * sizeof(unsigned), 256);   // zmax slots sit right before the marks: one memset
+    L.mark_off = align_up(L.zmax_off + (size_t)B * T * kZSlots * sizeof(unsigned), 256);   // zmax slots sit right before the marks: one memset
     L.mark_bytes = (size_t)B * (per_frame ? T : 1) * N;
     L.proj_off = align_up(L.mark_off + L.mark_bytes, 256);
     L.total = align_up(L.proj_off + (size_t)B * T * N * sizeof(uint2), 256);
@@ -435,7 +436,7 @@ extern "C" int pf_warp_splat_workspace(int B, int T, int H, int W, int per_frame
         return pf::fail(PF_EUNSUPPORTED, "pf_warp_splat: 4*T*H*W must be < 2^32 (element index packs in 32 bits)");
     if (H > 8192 || W > 8192)
         return pf::fail(PF_EUNSUPPORTED, "pf_warp_splat: H and W must be <= 8192 (13-bit bin coordinates)");
-    *bytes = pf::splat_layout(B, T, H, W, per_frame).total;
+    *bytes = pf::splat_layout(B, T, H, W, per_frame & PF_SPLAT_PER_FRAME).total;
     return PF_OK;
 }
 
@@ -457,7 +458,7 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     if (ws_bytes < need)
         return pf::fail(PF_EWORKSPACE, "pf_warp_splat: workspace %zu B < required %zu B", ws_bytes, need);
 
-    const pf::SplatLayout L = pf::splat_layout(B, T, H, W, per_frame);
+    const pf::SplatLayout L = pf::splat_layout(B, T, H, W, per_frame & PF_SPLAT_PER_FRAME);
     pf::SplatArgs a;
     a.depth = depth; a.mask = depth_mask; a.seg = seg;
     a.Kinv = Kinv; a.E = E; a.Tt = T_tgt; a.Einv = Einv; a.K = K;
@@ -467,14 +468,15 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     a.proj = (uint2 *)((char *)ws + L.proj_off);
     a.out_seg = out_seg; a.out_depth = out_depth; a.out_r2d = (long long *)out_result2d;
     a.B = B; a.T_total = T_total; a.t_first = t_first; a.T = T; a.H = H; a.W = W; a.C = seg_channels;
-    a.per_frame = per_frame ? 1 : 0;
+    a.per_frame = (per_frame & PF_SPLAT_PER_FRAME) ? 1 : 0;
+    a.zgroups_per_sample = (per_frame & PF_SPLAT_PER_SAMPLE_SENTINEL) ? (a.per_frame ? T : 1) : 0;
     a.stx = L.stx; a.sty = L.sty; a.dtx = L.dtx; a.dty = L.dty;
     a.probe = nullptr;
 #if PF_PROBE
     a.probe = getenv("PF_PROBE") ? pf::probe_buffer() : nullptr;
 #endif
     hipStream_t s = (hipStream_t)stream;
-    const int G = per_frame ? T : 1;
+    const int G = a.per_frame ? T : 1;
 
     // algorithmic bytes: source side depth 4 + mask 1 B/px; destination side seg 1 in, seg 1 + depth 4 out
     const double src_px = (double)B * T * H * W, dst_px = (double)B * G * H * W;

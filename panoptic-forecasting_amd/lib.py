@@ -37,6 +37,7 @@ SIGNATURES = {
     'pf_seg_loss_workspace': (_i, [_i, _i, _i, _c.POINTER(_sz)]),
     'pf_seg_loss': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'pf_set_option': (_i, [_c.c_char_p, _i]),
+    'pf_hardnet_plan_set_option': (_i, [_vp, _c.c_char_p, _i]),
     'pf_debug_force_conv': (_i, [_i, _i, _i, _i]),
     'pf_debug_probe_read': (_i, [_c.POINTER(_c.c_longlong)]),
     'pf_profile_enable': (_i, [_i]),

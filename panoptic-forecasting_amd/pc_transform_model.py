@@ -11,17 +11,59 @@ from . import lib as _lib
 from .model_api import BaseModel
 
 
+PF_SPLAT_PER_FRAME, PF_SPLAT_PER_SAMPLE_SENTINEL = 1, 2      # include/pfhip.h
+
+
 def host_inverse(m):
     """torch.inverse on the HOST (LAPACK), as the oracle fixes it: the low bits of K^-1 / E^-1 decide
     which pixel floor() picks for near-integer coordinates (pc_transform_model.py:51,71)."""
     return torch.inverse(m.detach().float().cpu()).to(m.device)
 
 
+class InverseCache:
+    """K^-1 / E^-1 per distinct camera tensor.  The inverse has to come from host LAPACK (see ``host_inverse``), which
+    costs a device->host copy = a stream sync; cameras are per-sequence constants, so ``predict`` pays it once per
+    (tensor storage, version) and afterwards enqueues without touching the host (include/pfhip.h: calls only enqueue).
+    Entries keep the source tensor alive, so a data_ptr can not be recycled for another matrix while it is a key; an
+    in-place edit bumps ``_version`` and misses."""
+
+    def __init__(self, capacity=16):
+        self.capacity, self._d = capacity, {}
+
+    def __call__(self, m):
+        key = (m.data_ptr(), m._version, tuple(m.shape), m.dtype, str(m.device))
+        hit = self._d.get(key)
+        if hit is None:
+            if len(self._d) >= self.capacity:
+                self._d.pop(next(iter(self._d)))
+            hit = (m, host_inverse(m))
+            self._d[key] = hit
+        return hit[1]
+
+
+_inverse_cache = InverseCache()
+
+
 def _as_u8(mask):
-    """bool tensors are one 0/1 byte per element: reinterpret instead of converting."""
+    """bool tensors are one 0/1 byte per element: reinterpret instead of converting; other dtypes mean "!= 0" (a float
+    mask of 0.5 is True for the reference's ``bool_mask &`` arithmetic, not truncated to 0)."""
     if mask.dtype == torch.bool:
         return mask.contiguous().view(torch.uint8)
-    return mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
+    return mask if mask.dtype == torch.uint8 else (mask != 0).view(torch.uint8)
+
+
+def _seg_as_u8(seg):
+    """The device splat carries labels as bytes.  Wider integer maps are accepted when every value fits (checked: one
+    device reduction + sync per call for non-u8 inputs — pass u8 to stay asynchronous); anything else is an error, never
+    a silent wrap-around (the reference gathers in the input dtype, pc_transform_model.py:120-131)."""
+    if seg.dtype == torch.uint8:
+        return seg
+    if seg.is_floating_point():
+        raise _lib.PfError('seg must be an integer label map or a u8 image (got %s)' % seg.dtype)
+    if seg.numel() and (int(seg.max()) > 255 or int(seg.min()) < 0):
+        raise _lib.PfError('seg holds values outside 0..255 (min %d, max %d): the device splat gathers u8 payloads'
+                           % (int(seg.min()), int(seg.max())))
+    return seg.to(torch.uint8)
 
 
 class WarpSplat:
@@ -40,7 +82,7 @@ class WarpSplat:
         return self._ws
 
     def __call__(self, depth, depth_mask, seg, K, E, target_T, Kinv=None, Einv=None, t_first=0, T=None,
-                 per_frame=False, is_img=False, want_result2d=True):
+                 per_frame=False, is_img=False, want_result2d=True, per_sample_sentinel=False):
         L = _lib.load()
         b, t_total, h, w = depth.shape
         T = t_total - t_first if T is None else T
@@ -48,9 +90,9 @@ class WarpSplat:
         depth = _lib.require_cuda(depth.float(), 'depth')
         mask = _lib.require_cuda(_as_u8(depth_mask), 'depth_mask')
         seg_dtype = seg.dtype
-        seg8 = _lib.require_cuda(seg if seg.dtype == torch.uint8 else seg.to(torch.uint8), 'seg')
-        Kinv = host_inverse(K) if Kinv is None else Kinv
-        Einv = host_inverse(E) if Einv is None else Einv
+        seg8 = _lib.require_cuda(_seg_as_u8(seg), 'seg')
+        Kinv = _inverse_cache(K) if Kinv is None else Kinv
+        Einv = _inverse_cache(E) if Einv is None else Einv
         mats = [_lib.require_cuda(m.float().contiguous(), n) for m, n in
                 ((Kinv, 'Kinv'), (E, 'extrinsics'), (target_T, 'target_T'), (Einv, 'Einv'), (K, 'intrinsics'))]
         c = 3 if is_img else 1
@@ -60,9 +102,10 @@ class WarpSplat:
         out_depth = torch.empty(shape, dtype=torch.float32, device=dev)
         r2d = torch.empty((b, T, h, w, 2), dtype=torch.int64, device=dev) if want_result2d else None
         ws = self._workspace(b, T, h, w, per_frame, dev)
+        flags = (PF_SPLAT_PER_FRAME if per_frame else 0) | (PF_SPLAT_PER_SAMPLE_SENTINEL if per_sample_sentinel else 0)
         rc = L.pf_warp_splat(depth.data_ptr(), mask.data_ptr(), seg8.data_ptr(), c,
                              mats[0].data_ptr(), mats[1].data_ptr(), mats[2].data_ptr(), mats[3].data_ptr(),
-                             mats[4].data_ptr(), b, t_total, t_first, T, h, w, int(per_frame),
+                             mats[4].data_ptr(), b, t_total, t_first, T, h, w, flags,
                              out_seg.data_ptr(), out_depth.data_ptr(),
                              r2d.data_ptr() if r2d is not None else None,
                              ws.data_ptr(), ws.numel(), _lib.stream_ptr())
@@ -78,6 +121,8 @@ class PCTransformModel(BaseModel):
         self.ind = params['model'].get('only_this_ind')
         self.is_img = params['model'].get('is_img')
         self.debug = params['model'].get('debug')
+        # opt-in (not a reference key): sentinel max+1 per sample instead of over the batch of the call
+        self.per_sample_sentinel = bool(params['model'].get('per_sample_sentinel', False))
         self._splat = WarpSplat()
 
     @torch.no_grad()
@@ -87,5 +132,6 @@ class PCTransformModel(BaseModel):
         seg, dep, r2d = self._splat(depth, inputs['depth_mask'], inputs['seg'], inputs['intrinsics'],
                                     inputs['extrinsics'], inputs['target_T'],
                                     Kinv=inputs.get('intrinsics_inv'), Einv=inputs.get('extrinsics_inv'),
-                                    t_first=t_first, T=T, per_frame=False, is_img=bool(self.is_img))
+                                    t_first=t_first, T=T, per_frame=False, is_img=bool(self.is_img),
+                                    per_sample_sentinel=self.per_sample_sentinel)
         return {'seg': seg, 'result2d': r2d, 'depth': dep}

@@ -55,3 +55,42 @@ def test_shard_indices_partition():
     for world in (1, 2, 4, 8):
         seen = sorted(i for r in range(world) for i in pfdist.shard_indices(37, r, world))
         assert seen == list(range(37))
+
+
+def _run_bench(*flags, env=None):
+    import json
+    import subprocess
+    e = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(flags), capture_output=True, text=True,
+                       timeout=600, env=e)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` from a plain shell must become the launcher of 2 ranks (it used to run 1 rank and print
+    n_gpus: 1); --dry-run does the rendezvous + the sharded metric gather on gloo and no GPU work."""
+    r, line = _run_bench('--gpus', '2', '--dry-run')
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['n_gpus'] == 2 and line['gather_ok'] is True and line['dry_run'] is True
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    """Launched with WORLD_SIZE=1 semantics but --gpus 2 in a launcher environment of another size: error, not a silent
+    1-rank run."""
+    r, line = _run_bench('--gpus', '2', '--dry-run', env={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and line is None
+    assert 'rank(s) joined' in r.stderr
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """Without --dry-run the launcher checks the node's GPU count first (0 in the CPU container)."""
+    import torch as _t
+    if _t.cuda.is_available() and _t.cuda.device_count() >= 2:
+        return
+    r, line = _run_bench('--gpus', '2')
+    assert r.returncode != 0 and line is None
+    assert 'GPU(s)' in r.stderr

@@ -49,14 +49,17 @@ def oracle_pipeline(sd, inp, h, w):
     return hardnet_ref.bg_predict(sd, {'seg': seg, 'depth': dep, 'depth_mask': dep > 0}, final_size=(h, w)), seg, dep
 
 
-@pytest.mark.parametrize('h,w,b,gap', [(128, 256, 2, 3), (192, 320, 1, 9)])
-def test_fused_matches_two_stage_oracle(h, w, b, gap):
+@pytest.mark.parametrize('h,w,b,gap,predicted', [(128, 256, 2, 3, False), (192, 320, 1, 9, False), (192, 320, 2, 9, True)],
+                         ids=['short', 'mid_measured_odom', 'mid_predicted_odom'])
+def test_fused_matches_two_stage_oracle(h, w, b, gap, predicted):
+    """BASELINE configs[1] and configs[2] (dt=9 with the predicted-odometry ego chain, pc_transform_dataset.py:156-186)
+    through the fused model."""
     from panoptic_forecasting_amd import synth
     from panoptic_forecasting_amd.registry import build_model
     sd = _sd()
     m = build_model(_params(h, w, return_logits=True))
     m.load_state_dict(sd)
-    inp = synth.make_inputs(b=b, h=h, w=w, seed=21, gap_len=gap)
+    inp = synth.make_inputs(b=b, h=h, w=w, seed=21, gap_len=gap, predicted=predicted)
     ref, seg_w, dep_w = oracle_pipeline(sd, inp, h, w)
     out = m.predict({k: v.cuda() for k, v in inp.items()}, None)
     # the splat stage is bit-exact, so the hop inputs are too
@@ -96,3 +99,51 @@ def test_fp32_mfma_only_option():
         L.pf_set_option(b'split_bf16', 1)
     assert errs[0] <= 1e-4, errs
     assert errs[1] <= 1e-3, errs
+
+
+@pytest.mark.parametrize('b,split,tol', [(1, 1, 1e-3), (1, 0, 1e-4), (16, 1, 1e-3), (16, 0, 1e-4)],
+                         ids=['B1_split', 'B1_fp32', 'B16_split', 'B16_fp32'])
+def test_full_size_timed_configuration_vs_oracle(b, split, tol):
+    """The configuration bench.py times (1024x2048, the B=1 and B=16 rows of csrc/conv_tuned.inc, bf16-split kernels on
+    and off) against the oracle pipeline at its own size: logits of the first and the last frame of the batch, argmax
+    agreement and bit-exact warped inputs.  The per-layer kernel choice is keyed on (shape, B), so the small-size tests
+    above never execute these table rows."""
+    from panoptic_forecasting_amd import lib as pflib
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.registry import build_model
+    h, w = 1024, 2048
+    sd = _sd()
+    m = build_model(_params(h, w, return_logits='orig', split_bf16=split, emulate_disk_hop=True, seg_is_label_id=True,
+                            per_sample_sentinel=True))
+    m.load_state_dict(sd)
+    parts = [synth.make_inputs(b=1, h=h, w=w, seed=40 + i, gap_len=3) for i in range(b)]
+    inp = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+    pflib.profile(True)
+    out = m.predict({k: v.cuda() for k, v in inp.items()}, None)
+    labels = [r['label'] for r in pflib.profile_results()]
+    pflib.profile(False)
+    assert any('conv_split' in l for l in labels) == bool(split), labels
+    for i in sorted({0, b - 1}):
+        ref, seg_w, dep_w = oracle_pipeline(sd, parts[i], h, w)
+        assert torch.equal(torch.from_numpy(synth.ID2TRAINID)[out['warped_seg'][i:i + 1].cpu().long()].long(), seg_w)
+        err = (out['orig_size_logits'][i:i + 1].cpu() - ref['orig_size_logits']).abs().max().item()
+        agree = (out['seg'][i:i + 1].cpu().long() == ref['seg']).float().mean().item()
+        assert err <= tol, (i, err)
+        assert agree >= 0.999, (i, agree)
+
+
+def test_batch_pinned_kernel_table_makes_logits_batch_invariant():
+    """conv_table_batch pins the per-layer kernel choice: the same frame alone and inside a batch of 4 gives bit-identical
+    logits (without the pin the B=1 and B=4 rows of the tuned table may pick kernels that differ in the last bits)."""
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.registry import build_model
+    h, w = 256, 512
+    sd = _sd()
+    m = build_model(_params(h, w, return_logits='orig', conv_table_batch=4, per_sample_sentinel=True))
+    m.load_state_dict(sd)
+    inp = {k: v.cuda() for k, v in synth.make_inputs(b=4, h=h, w=w, seed=9).items()}
+    # per-sample sentinel: the reference's batch-global max+1 (pc_transform_model.py:105) would couple the samples
+    m4 = m.predict(inp, None)['orig_size_logits']
+    one = {k: v[2:3].contiguous() for k, v in inp.items()}
+    m1 = m.predict(one, None)['orig_size_logits']
+    assert torch.equal(m4[2:3], m1)

@@ -66,9 +66,39 @@ def test_per_frame_mode_equals_three_single_calls():
         assert torch.equal(dep[:, t].view(torch.int32), o['depth'].view(torch.int32))
 
 
+@pytest.mark.parametrize('term', [dict(gap_len=3), dict(gap_len=9, predicted=True)], ids=['short', 'mid_predicted'])
+@pytest.mark.parametrize('ind', [None, 0, 2])
+def test_full_size_bit_exact_vs_oracle(term, ind):
+    """1024x2048 (BASELINE configs[1] / configs[2]) against the C oracle, bit for bit: result2d, seg, depth.  The oracle
+    needs about half a second per splat at this size."""
+    from oracle import warp_splat as oracle
+    from panoptic_forecasting_amd import synth
+    inp = synth.make_inputs(b=1, seed=5, **term)
+    ref = oracle.predict(inp, only_this_ind=ind)
+    out = _model(ind, False).predict({k: v.cuda() for k, v in inp.items()}, None)
+    assert torch.equal(out['result2d'].cpu(), ref['result2d'])
+    assert torch.equal(out['seg'].cpu(), ref['seg'])
+    assert torch.equal(out['depth'].cpu().view(torch.int32), ref['depth'].view(torch.int32))
+
+
+def test_full_size_per_frame_batch_vs_oracle():
+    """The launch shape bench.py times: per-frame z-buffers for a batch of frames in one call (B=4 here)."""
+    from oracle import warp_splat as oracle
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.pc_transform_model import WarpSplat
+    parts = [synth.make_inputs(b=1, seed=70 + i) for i in range(4)]
+    inp = {k: torch.cat([p[k] for p in parts], 0).cuda() for k in parts[0]}
+    seg, dep, _ = WarpSplat()(inp['depth'], inp['depth_mask'], inp['seg'], inp['intrinsics'], inp['extrinsics'],
+                              inp['target_T'], per_frame=True, want_result2d=False, per_sample_sentinel=True)
+    for i in (0, 3):
+        for t in range(3):
+            ref = oracle.predict(parts[i], only_this_ind=t)
+            assert torch.equal(seg[i, t].cpu(), ref['seg'][0])
+            assert torch.equal(dep[i, t].cpu().view(torch.int32), ref['depth'][0].view(torch.int32))
+
+
 def test_full_size_properties():
-    """1024x2048 (BASELINE config 2): sizes the oracle would take minutes on are checked through
-    size-independent properties: determinism, every output depth is either -1, the sentinel, or the z of
+    """1024x2048 size-independent properties: determinism, every output depth is either -1, the sentinel, or the z of
     a valid source, identity warp reproduces the input exactly where the mask holds."""
     from panoptic_forecasting_amd import synth
     inp = {k: v.cuda() for k, v in synth.make_inputs(b=1, seed=0).items()}

@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 # one sub-batch (16 frames) on one stream: the launches bench.py times for its roofline line; the headline runs 2 of
 # these concurrently on 2 streams inside one hipGraph
-BENCH="python $REPO/bench.py --batch 16 --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --no-graph --profile-steps 1 $*"
+BENCH="python $REPO/bench.py --batch 16 --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --no-legs --no-graph --profile-steps 1 $*"
 cd /tmp
 # 1. kernel trace + stats (timing)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BENCH > "$OUT/bench_trace.log" 2>"$OUT/trace.err"
@@ -21,6 +21,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d "$OUT/cal_$C" -o c -- python $REPO/tools/pmc_calib.py > "$OUT/cal_$C.log" 2>&1
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -o p -- $BENCH > "$OUT/bench_pmc_mfma.log" 2>"$OUT/pmc_mfma.err"
+# issue/wait breakdown of the non-matrix kernels (quad-cycle units, MI355X_MICROARCH.md "rocprofv3 PMC slots")
+rocprofv3 -L > "$OUT/counters_list.txt" 2>&1 || true
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_sq" -o p -- $BENCH > "$OUT/bench_pmc_sq.log" 2>"$OUT/pmc_sq.err"
 # keep only the CSVs (sizes are bounded by the 64 MiB pull limit)
 find "$OUT" -name '*.db' -delete
 ls -R "$OUT" | head -50

@@ -59,7 +59,10 @@ def main(tag, prefix):
         f.write('%-90s %7s %12s %11s %11s %11s %6s\n' % ('kernel', 'calls', 'total_ns', 'avg_ns', 'min_ns', 'max_ns', '%'))
         for k, (c, tot, avg, mn, mx) in sorted(ks.items(), key=lambda kv: -kv[1][1]):
             f.write('%-90s %7d %12d %11.0f %11d %11d %6.2f\n' % (k[:90], c, tot, avg, mn, mx, 100.0 * tot / total))
-    out = {'note': 'per-launch averages; FETCH_SIZE/WRITE_SIZE are reported by rocprofv3 in KiB-like units and are '
+    sys.path.insert(0, ROOT)
+    import bench as _bench
+    out = {'source_sha': _bench.source_sha(),
+           'note': 'per-launch averages; FETCH_SIZE/WRITE_SIZE are reported by rocprofv3 in KiB-like units and are '
                    'calibrated here on a 256 MiB copy kernel run under the same counter (factor = known bytes / raw)',
            'kernels': {}}
     cal = {}
@@ -83,11 +86,14 @@ def main(tag, prefix):
             e[c + '_raw'] = raw
             if c in cal:
                 e[c + '_bytes'] = raw * cal[c]['factor_bytes_per_unit']
-    cc = counters(os.path.join(src, 'pmc_mfma'))
-    for k, d in cc.items():
-        e = out['kernels'].setdefault(k, {})
-        for name, v in d.items():
-            e[name] = sum(v) / len(v)
+    for sub in ('pmc_mfma', 'pmc_sq'):
+        cc = counters(os.path.join(src, sub))
+        for k, d in cc.items():
+            e = out['kernels'].setdefault(k, {})
+            for name, v in d.items():
+                e[name] = sum(v) / len(v)
+    for k, d in list(out['kernels'].items()):
+        e = d
         if e.get('SQ_BUSY_CYCLES') and 'SQ_VALU_MFMA_BUSY_CYCLES' in e:
             e['mfma_busy_over_sq_busy'] = e['SQ_VALU_MFMA_BUSY_CYCLES'] / e['SQ_BUSY_CYCLES']
     for k, e in out['kernels'].items():
