@@ -476,9 +476,9 @@ static void pick_shape(const ConvArgs &a, int ks, int stride, int B, int &wm, in
     }
 }
 
-int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t s, int force_wm, int force_nt) {
+int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t s, int force_wm, int force_nt, int model_B) {
     int wm = 4, wk = 1, nt = 1;
-    pick_shape(a, ks, stride, B, wm, wk, nt);
+    pick_shape(a, ks, stride, model_B > 0 ? model_B : B, wm, wk, nt);   // the K split (WK) changes the summation order
     if (force_wm > 0) {
         const int model_nt = wm == force_wm ? nt : 2;
         wm = force_wm;

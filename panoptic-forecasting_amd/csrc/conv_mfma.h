@@ -76,8 +76,9 @@ inline int dma_valu_split(int cout, bool peel_full) {
 }
 void pack_conv_weights_rem(const float *w_oihw, int cin, int cout, int rem, int ks, int kc, const int *src_ch, int n_src, float *out);
 void pack_conv_weights_tiled(const float *w_oihw, int cin, int cout, int ks, int kc, const int *src_ch, int n_src, float *out);
-// force_wm/force_nt > 0 override the cost model (tuning runs)
-int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t stream, int force_wm = 0, int force_nt = 0);
+// force_wm/force_nt > 0 override the cost model (tuning runs); model_B > 0: the cost model sees this batch size
+// instead of B (batch-invariant shape choice, plan option "table_batch")
+int launch_conv_dma(const ConvArgs &a, int ks, int stride, int B, hipStream_t stream, int force_wm = 0, int force_nt = 0, int model_B = 0);
 
 // Wave-autonomous path (conv_wave.hip; stride 1, Win % 4 == 0): a.wpk must point at pack_conv_weights_wave()
 // output and a.nchunks = ceil(Cin / wave_kc(ks)).  Tile = mh rows x 16 pixels, nt cout tiles, wk-way K split.

@@ -241,13 +241,13 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                 a.rem = p->conv[i].rem_count;
                 a.wrem = p->dev_weights + p->conv[i].rem_off;
                 a.ntiles = ((int)o.cout - a.rem) / 16;
-                rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s, 4, ch.p0 == 4 && ch.p1 > 0 ? ch.p1 : 0);
+                rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s, 4, ch.p0 == 4 && ch.p1 > 0 ? ch.p1 : 0, p->opt_table_batch);
                 if (rc == PF_EUNSUPPORTED) {
                     a.rem = 0;
                     a.ntiles = ((int)o.cout + 15) / 16;
                 }
             }
-            if (a.rem == 0) rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s, ch.p0, ch.p1);
+            if (a.rem == 0) rc = launch_conv_dma(a, (int)o.k, (int)o.stride, B, s, ch.p0, ch.p1, p->opt_table_batch);
         }
         return rc;
     };

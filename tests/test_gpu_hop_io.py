@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from PIL import Image
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), 'golden')
@@ -96,3 +97,39 @@ def test_file_hop_equals_in_register_hop(tmp_path):
     one = fused.predict(inp, None)
     assert torch.equal(two_stage['seg'].long(), one['seg'].long())
     assert torch.equal(two_stage['orig_size_logits'], one['orig_size_logits'])
+
+
+def test_export_driver_with_reference_flags(tmp_path):
+    """export_bg.py = scripts/bg/run_export_bg_val.sh with the python path changed: --config_file / --load_model (with the
+    config.yaml stored next to the checkpoint) / --no_convert / --export_name / --working_dir, on synthetic samples; the
+    files it writes equal a direct model.predict + the reference's naming (export_cityscapes_segmentation_results.py:65-107)."""
+    import json
+    import yaml
+    from panoptic_forecasting_amd import export_bg, synth
+    from panoptic_forecasting_amd.registry import build_model
+    h, w = 64, 128
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'calib_seed1234.json')) as f:
+        sd = synth.make_state_dict(seed=1234, calib=json.load(f))
+    ck = tmp_path / 'ck'
+    ck.mkdir()
+    stored = {'task': 'bg', 'data': {'num_classes': 11, 'depth_norm_params': None, 'min_depth': 0.1, 'max_depth': 200},
+              'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True}}
+    (ck / 'config.yaml').write_text(yaml.dump(stored))
+    torch.save(sd, str(ck / 'bg_model.pt'))
+    cfg = tmp_path / 'bg_val.yaml'
+    cfg.write_text(yaml.dump({'task': 'bg', 'data': {'data_splits': ['val']}, 'model': {'final_w': w, 'final_h': h},
+                              'training': {'batch_size': 2, 'num_data_workers': 0}}))
+    written = export_bg.main(['--config_file', str(cfg), '--load_model', str(ck / 'bg_model.pt'), '--no_convert',
+                              '--export_name', 'exported_predictions_short_trainids', '--working_dir', str(tmp_path),
+                              '--synthetic', '3'])
+    assert len(written) == 3
+    params = dict(stored, no_gpu=False, load_model=None, load_best_model=False)
+    params['model'] = dict(stored['model'], final_w=w, final_h=h)
+    m = build_model(params)
+    m.load_state_dict(sd)
+    for i, path in enumerate(written):
+        assert path == str(tmp_path / 'exported_predictions_short_trainids' / 'val' / 'synth' /
+                           ('synth_%06d_000019_gtFine_labelIds.png' % i))
+        inp = {k: v.cuda() for k, v in synth.make_bg_inputs(b=1, h=h, w=w, seed=i).items()}
+        want = m.predict(inp, None)['seg'][0].cpu().numpy().astype(np.uint8)      # --no_convert: trainIds as predicted
+        assert np.array_equal(np.array(Image.open(path)), want)
