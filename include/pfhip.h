@@ -201,6 +201,46 @@ int pf_set_option(const char *name, int value);
  *                   the batch size, and the bf16-split and fp32 kernels differ in the last bits). */
 int pf_hardnet_plan_set_option(pf_plan *plan, const char *name, int value);
 
+/* ------------------------------------------------------------------------------------------
+ * bg training step (scope row f4) — replaces, per batch, training/train.py:185-222 for task `bg`:
+ *   loss_dict = model.loss(inputs, labels)  (bg_model.py:73-89: train-mode BatchNorm, F.interpolate align_corners,
+ *   CrossEntropyLoss(ignore_index=255), accuracy) ; loss.backward() ; clip_grad_value_/clip_grad_norm_ ; SGD step.
+ *
+ * A pf_train is built from the same blob as a plan (only the op table is used).  Parameters are ONE flat fp32 device
+ * array `theta`; per conv op of the table, in table order:  W[cout][cin][k][k], then gamma, beta, running_mean,
+ * running_var [cout each] for conv+BatchNorm layers (hardnet.py:16-25) or bias[cout] for a plain conv (finalConv).
+ * `grad` has the same layout (the running-stat slots stay 0).  pf_train_param_layout gives the offsets of one op.
+ *
+ * pf_train_forward_backward: forward in training mode (batch statistics; running stats updated in theta when
+ * update_running_stats), loss, backward.  Inputs either as the reference batch (seg [B,T,H,W] u8/i64 trainIds, depth,
+ * depth_mask, depth_mean/std: one-hot + normalised masked depth built on the device, bg_model.py:53-69) or as a dense
+ * x_dense [B,in_ch,H,W].  labels [B,out_h,out_w] u8/i64.  grad is zeroed first unless accumulate_grads (train.py's
+ * accumulate_steps; loss_scale = 1/accumulate_steps multiplies the gradient).  out3 (device, 3 doubles) = {sum of the
+ * per-pixel losses, number of labels != ignore_index, number of correct argmax}: loss = out3[0]/out3[1], accuracy =
+ * out3[2]/out3[1].  Only enqueues on `stream`; every reduction runs in a fixed order (bit-reproducible).
+ *
+ * pf_sgd_step: g *= min(1, clip_norm/(||g||+1e-6)) if clip_norm > 0 (clip_grad_norm_); clamp to +-clip_value if > 0
+ * (clip_grad_value_); g += weight_decay*p; buf = first_step ? g : momentum*buf + g; p -= lr*buf (torch.optim.SGD) on
+ * the elements with trainable[i] != 0 (the running statistics are buffers, not parameters).  For data-parallel
+ * training all-reduce `grad` (one RCCL call, ~16.5 MB) between the two calls (reference: DDP, train.py:96-103). */
+typedef struct pf_train pf_train;
+int pf_train_create(const void *blob, size_t blob_bytes, int in_ch, int n_cls, pf_train **out);
+void pf_train_destroy(pf_train *t);
+int pf_train_param_count(const pf_train *t, size_t *n_floats);
+int pf_train_param_layout(const pf_train *t, int op_index, size_t *w_off, size_t *aux_off, int *has_bn);
+int pf_train_workspace(const pf_train *t, int B, int H, int W, int out_h, int out_w, size_t *bytes);
+int pf_train_forward_backward(const pf_train *t, float *theta, float *grad, int accumulate_grads, const void *seg, int seg_is_i64,
+                              const float *depth, const uint8_t *depth_mask, float depth_mean, float depth_std, int T,
+                              const float *x_dense, int B, int H, int W, const void *labels, int labels_i64, int out_h, int out_w,
+                              int ignore_index, float loss_scale, float bn_momentum, float bn_eps, int update_running_stats,
+                              double *out3, void *ws, size_t ws_bytes, void *stream);
+/* where tensor `name` (activation, or its gradient with want_grad) lives in the training workspace (tests) */
+int pf_train_tensor_view(const pf_train *t, const char *name, int want_grad, int B, int H, int W, int out_h, int out_w,
+                         size_t *ws_offset, int *channels, int *h, int *w);
+int pf_sgd_workspace(size_t *bytes);
+int pf_sgd_step(float *theta, float *grad, float *momentum_buf, const uint8_t *trainable, size_t n, float lr, float momentum,
+                float weight_decay, float clip_norm, float clip_value, int first_step, void *ws, size_t ws_bytes, void *stream);
+
 /* Introspection for per-stage parity tests: where tensor `name` (packing.py tensor names, e.g.
  * "base.4.out") lives inside the workspace for this (B,H,W): byte offset, channels, height, width. */
 int pf_hardnet_tensor_view(const pf_plan *plan, const char *name, int B, int H, int W,

@@ -19,12 +19,16 @@ N_LAYERS = (4, 4, 8, 8, 8)
 N_CLS_BG = 11
 
 
+_TRAINING = False      # module switch set by bg_train_step only (keeps the inference signatures unchanged)
+
+
 def _conv_bn_relu(sd, p, x, stride=1):
-    """ConvLayer (hardnet.py:16-25): conv(no bias, pad k//2) -> BN(eval) -> ReLU."""
+    """ConvLayer (hardnet.py:16-25): conv(no bias, pad k//2) -> BN -> ReLU.  BN in eval form, or (inside bg_train_step)
+    nn.BatchNorm2d's training form: batch statistics, running stats updated in place with momentum 0.1."""
     w = sd[p + '.conv.weight']
     x = F.conv2d(x, w, None, stride=stride, padding=w.shape[2] // 2)
     x = F.batch_norm(x, sd[p + '.norm.running_mean'], sd[p + '.norm.running_var'],
-                     sd[p + '.norm.weight'], sd[p + '.norm.bias'], training=False, eps=1e-5)
+                     sd[p + '.norm.weight'], sd[p + '.norm.bias'], training=_TRAINING, momentum=0.1, eps=1e-5)
     return F.relu(x)
 
 
@@ -102,3 +106,58 @@ def bg_predict(sd, inputs, final_size=None, taps=None):
     x = bg_inputs_to_tensor(sd, inputs['seg'], inputs['depth'], inputs['depth_mask'])
     logits, orig = hardnet_forward(sd, x, final_size, taps=taps)
     return {'seg': logits.argmax(1), 'logits': logits, 'orig_size_logits': orig}
+
+
+def trainable_keys(sd):
+    """model.parameters() with requires_grad of the reference BGModel: conv weights, BN affine, finalConv weight/bias
+    (depth_mean/depth_std are requires_grad=False, bg_model.py:40-41; running stats are buffers)."""
+    return [k for k in sd if k.startswith('model.') and (k.endswith('.weight') or k.endswith('.bias'))]
+
+
+def bg_loss(sd, inputs, labels, final_size=None):
+    """BGModel.loss (bg_model.py:73-89): logits at final_size (or the input size) -> CrossEntropyLoss(ignore_index=255),
+    accuracy = #(argmax == label) / #(label != 255)."""
+    x = bg_inputs_to_tensor(sd, inputs['seg'], inputs['depth'], inputs['depth_mask'])
+    logits, _ = hardnet_forward(sd, x, final_size)
+    lab = labels['seg'].long()
+    loss = F.cross_entropy(logits, lab, ignore_index=255)
+    correct = (logits.argmax(1) == lab).sum()
+    total = (lab != 255).sum()
+    return {'loss': loss, 'accuracy': correct.float() / total.float()}
+
+
+def bg_train_step(sd, inputs, labels, momentum_bufs=None, lr=2e-3, mom=0.9, wd=1e-4, clip_grad_norm=5.0, clip_grad=None,
+                  final_size=None, apply_update=True):
+    """One batch of the reference training loop (training/train.py:185-216, accumulate_steps=1) on a state_dict:
+    model.train(); loss; backward; clip_grad_value_ | clip_grad_norm_; torch.optim.SGD step (weight decay added to the
+    gradient, buf = g on the first step, then mom*buf + g; p -= lr*buf).  Updates ``sd`` in place (parameters and BN
+    running statistics).  Returns {'loss','accuracy','grads' (after clipping),'grad_norm' (before),'momentum_bufs'}."""
+    global _TRAINING
+    keys = trainable_keys(sd)
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
+    work = dict(sd)
+    work.update(leaves)
+    _TRAINING = True
+    try:
+        with torch.enable_grad():
+            out = bg_loss(work, inputs, labels, final_size)
+            out['loss'].backward()
+    finally:
+        _TRAINING = False
+    grads = {k: leaves[k].grad.detach() for k in keys}
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    if clip_grad is not None:
+        grads = {k: g.clamp(-clip_grad, clip_grad) for k, g in grads.items()}
+    elif clip_grad_norm is not None:
+        coef = torch.clamp(clip_grad_norm / (total + 1e-6), max=1.0)
+        grads = {k: g * coef for k, g in grads.items()}
+    new_bufs = {}
+    if apply_update:
+        with torch.no_grad():
+            for k in keys:
+                g = grads[k] + wd * sd[k]
+                buf = g.clone() if (momentum_bufs is None or mom == 0) else mom * momentum_bufs[k] + g
+                new_bufs[k] = buf
+                sd[k] = sd[k] - lr * buf
+    return {'loss': out['loss'].detach(), 'accuracy': out['accuracy'].detach(), 'grads': grads, 'grad_norm': total,
+            'momentum_bufs': new_bufs}

@@ -113,6 +113,9 @@ class BGModel(BaseModel):
         self._plan = None
         self._ws = None
         self._norm = None
+        self._trainer = None
+        self._params_for_trainer = {'data': dict(params['data']), 'model': dict(params['model']),
+                                    'training': dict(params.get('training') or {})}
 
     # ---- plan lifecycle -------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
@@ -220,11 +223,40 @@ class BGModel(BaseModel):
         _, logits, orig = self.run(inps, depths, depth_masks, True, return_orig_size)
         return (logits, orig) if return_orig_size else logits
 
-    @torch.no_grad()
     def loss(self, inputs, labels):
-        """Validation form of reference ``BGModel.loss`` (bg_model.py:73-89): ``{'loss', 'accuracy'}`` for a batch, eval-mode
-        network (folded BN).  One network forward + ``pf_seg_loss`` (upsample + cross entropy + accuracy fused; the
-        full-resolution logits are never written).  There is no backward pass: training is scope row f4."""
+        """Reference ``BGModel.loss`` (bg_model.py:73-89): ``{'loss', 'accuracy'}`` for a batch.
+
+        ``model.train()`` with autograd enabled (the reference's training loop, train.py:186-201): forward with
+        batch-statistics BatchNorm, cross entropy and the whole backward pass run as ONE device call
+        (``pf_train_forward_backward``); the returned loss carries an autograd node that delivers the parameter
+        gradients on ``backward()`` (``bg_train.TrainStepFunction``), so ``clip_grad_norm_`` / ``opt.step()`` / DDP work
+        unchanged.  Otherwise the validation form: eval-mode network (folded BN) + ``pf_seg_loss`` (upsample + cross
+        entropy + accuracy fused; the full-resolution logits are never written)."""
+        if self.training and torch.is_grad_enabled():
+            return self._train_loss(inputs, labels)
+        with torch.no_grad():
+            return self._eval_loss(inputs, labels)
+
+    def _get_trainer(self):
+        from . import bg_train
+        if self._trainer is None:
+            self._trainer = bg_train.BGTrainer(self._params_for_trainer, device='cuda')
+        if not self._trainer.is_adopted():
+            self._trainer.adopt(self)
+        return self._trainer
+
+    def _train_loss(self, inputs, labels):
+        from . import bg_train
+        tr = self._get_trainer()
+        self.invalidate()            # the folded-BN inference plan goes stale as soon as the parameters move
+        loss, acc = bg_train.TrainStepFunction.apply(tr, inputs, labels, *tr._adopted)
+        torch._foreach_add_(self._bn_counters(), 1)          # nn.BatchNorm2d.num_batches_tracked
+        return {'loss': loss, 'accuracy': acc}
+
+    def _bn_counters(self):
+        return [b for k, b in self.named_buffers() if k.endswith('num_batches_tracked')]
+
+    def _eval_loss(self, inputs, labels):
         L = _lib.load()
         seg_labels = labels['seg']
         _, _, orig = self.run(inputs['seg'], inputs.get('depth'), inputs.get('depth_mask'), want_logits=False, want_orig=True)

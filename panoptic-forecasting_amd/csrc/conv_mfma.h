@@ -40,6 +40,7 @@ struct ConvArgs {
     int src_begin, src_end;      // input ranges to accumulate (whole conv: 0, n_src)
     int chunk_begin, chunk_end;  // = src_chunk0[src_begin], src_chunk0[src_end] (filled at launch)
     long long *probe;        // PF_PROBE builds only: in-kernel timestamps of workgroup 0 / wave 0 (else nullptr)
+    int accum;               // generic kernel (conv_mfma.hip) only: dst += result (gradient accumulation of the training path)
 };
 
 // Tiling choice for one conv (depends on shape only; fixed at plan time for the weight packing).

@@ -132,11 +132,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             }
             float *p = dplane + (size_t)oy * a.Wout + ox;
             if (ox + 3 < a.Wout && (a.Wout & 3) == 0) {
+                if (a.accum) v += *reinterpret_cast<const f32x4 *>(p);
                 *reinterpret_cast<f32x4 *>(p) = v;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (ox + r < a.Wout) p[r] = v[r];
+                    if (ox + r < a.Wout) p[r] = a.accum ? p[r] + v[r] : v[r];
             }
         }
     }

@@ -1,0 +1,37 @@
+// Training-side kernels — interface (train_kernels.hip); orchestrated by train_plan.hip.
+#pragma once
+#include "conv_mfma.h"
+
+namespace pf {
+
+int launch_onehot_dense(const void *seg, int seg_i64, const float *depth, const uint8_t *mask, float mean, float stdv, int B, int T,
+                        int n_cls, int H, int W, float *x, hipStream_t s);
+// OIHW (device) -> fragment order of the generic MFMA conv (conv_mfma.hip); transpose_flip = 1 packs the backward-data
+// weights of forward input range [c0, c0 + ch)
+int launch_pack_weights(const float *w, int cin_f, int cout_f, const ConvTiling &t, int transpose_flip, int c0, int ch, float *out,
+                        hipStream_t s);
+size_t bn_partial_doubles(int C);
+int launch_bn_forward(const float *y, int B, int C, int H, int W, float eps, float momentum, const float *gamma, const float *beta,
+                      float *running_mean, float *running_var, float *mean, float *invstd, double *partial, float *dst, int dst_ctotal,
+                      int dst_choff, int relu, hipStream_t s);
+int launch_bn_backward(const float *g, const float *z, int t_ctotal, int choff, const float *y, const float *mean, const float *invstd,
+                       const float *gamma, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial, float *sums,
+                       float *dy, hipStream_t s);
+int launch_bias_backward(const float *g, int t_ctotal, int choff, int B, int C, int H, int W, float *dbias, float *dy, hipStream_t s);
+int wgrad_slabs(int cout, int cin, int B, int Hout);
+size_t wgrad_partial_floats(int cout, int cin, int ks, int B, int Hout);
+// a: the forward conv's arguments (sources, Cin/Cout, Hin/Win/Hout/Wout); dw (OIHW) accumulates
+int launch_wgrad(const ConvArgs &a, int ks, int stride, const float *dy, int B, float *partial, float *dw, hipStream_t s);
+int launch_zero_stuff(const float *dy, int planes, int Hout, int Wout, int Hin, int Win, float *up, hipStream_t s);
+int launch_avgpool2_bwd(const float *gout, int planes, int Hin, int Win, float *gin, hipStream_t s);
+// gin (+)= bilinear^T(gout) [* scale / *count when count != nullptr]
+int launch_upsample_bwd(const float *gout, int planes, int Hi, int Wi, int Ho, int Wo, const double *count, float scale, int accumulate,
+                        float *gin, hipStream_t s);
+size_t ce_partial_doubles(int B, int Ho, int Wo);
+int launch_ce_fwd_bwd(const float *logits, int B, int C, int Hi, int Wi, const void *labels, int lab_i64, int Ho, int Wo, int ignore,
+                      float *dfull, double *partial, double *out3, hipStream_t s);
+size_t sgd_ws_bytes();
+int launch_sgd(float *theta, float *grad, float *mom, const uint8_t *trainable, long long n, float lr, float momentum, float wd, float clip_norm,
+               float clip_value, int first, void *ws, hipStream_t s);
+
+}  // namespace pf

@@ -1,0 +1,575 @@
+// Training-side kernels of the bg network (scope row f4): everything `BGModel.loss(...).backward()` + the optimiser
+// step do in the reference (models/bg/bg_model.py:73-89, training/train.py:185-222) that the inference path does not:
+//   train-mode BatchNorm (batch statistics, running-stat update, backward), the convolution gradients
+//   (backward-weight on the fp32 matrix cores; backward-data reuses the forward MFMA kernel on flipped/transposed
+//   weights, see train_plan.hip), average-pool / bilinear-upsample backward, bilinear-upsampled cross entropy with its
+//   gradient, global-norm / value clipping and SGD with momentum and weight decay.
+// All reductions are two-stage with fp64 partials in a fixed order: a step is bit-reproducible run to run.
+#include "conv_epilogue.h"
+#include "pf_prof.h"
+#include "train_kernels.h"
+
+namespace pf {
+
+typedef float tr_f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ block reduce helper
+template <int NV>
+__device__ __forceinline__ void block_reduce_d(double (&v)[NV], double *smem /* [NV][4] */) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) smem[k * 4 + wave] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = ((smem[k * 4 + 0] + smem[k * 4 + 1]) + smem[k * 4 + 2]) + smem[k * 4 + 3];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ input: one-hot + depth
+// bg_model.py:53-69: labels >= n_cls -> zero vector; depth channels = (d - mean) / std * mask, after the T one-hot groups
+__global__ __launch_bounds__(256) void onehot_dense_kernel(const void *seg, int seg_i64, const float *depth, const uint8_t *mask,
+                                                           float mean, float stdv, int B, int T, int n_cls, long long HW, float *x) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int bt = blockIdx.y, b = bt / T, t = bt - b * T;
+    if (i >= HW) return;
+    const long long in = (long long)bt * HW + i;
+    const long long lab = seg_i64 ? reinterpret_cast<const long long *>(seg)[in] : (long long)reinterpret_cast<const uint8_t *>(seg)[in];
+    const int C = T * (n_cls + 1);
+    float *xb = x + (long long)b * C * HW + i;
+    for (int c = 0; c < n_cls; ++c) xb[(long long)(t * n_cls + c) * HW] = (lab == c) ? 1.f : 0.f;
+    const float dn = (depth[in] - mean) / stdv;
+    xb[(long long)(T * n_cls + t) * HW] = dn * (mask[in] ? 1.f : 0.f);
+}
+
+int launch_onehot_dense(const void *seg, int seg_i64, const float *depth, const uint8_t *mask, float mean, float stdv, int B, int T,
+                        int n_cls, int H, int W, float *x, hipStream_t s) {
+    const long long HW = (long long)H * W;
+    hipLaunchKernelGGL(onehot_dense_kernel, dim3((unsigned)((HW + 255) / 256), B * T), dim3(256), 0, s, seg, seg_i64, depth, mask, mean,
+                       stdv, B, T, n_cls, HW, x);
+    PF_LAUNCH_CHECK("onehot_dense_kernel");
+    return PF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing on the device
+// OIHW -> the fragment order of conv_mfma.hip::pack_conv_weights ([cout_block][chunk][kgroup][tap][nt][64 lanes]).
+// transpose_flip = 0: forward weights.  transpose_flip = 1: the backward-data convolution of input range [c0, c0+ch):
+//   Wd[co_d][ci_d][tap] = W[ci_d][c0 + co_d][ks2-1-tap]   (ci_d runs over the forward cout)
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float *w, int cin_f, int cout_f, int ks2, int kc, int nt, int nchunks,
+                                                           long long total, int transpose_flip, int c0, int ch, float *out) {
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    long long r = o;
+    const int lane = (int)(r % 64); r /= 64;
+    const int n = (int)(r % nt); r /= nt;
+    const int tap = (int)(r % ks2); r /= ks2;
+    const int kg = (int)(r % (kc / 4)); r /= (kc / 4);
+    const int chunk = (int)(r % nchunks); r /= nchunks;
+    const int cb = (int)r;
+    const int co = (cb * nt + n) * 16 + (lane & 15), ci = chunk * kc + kg * 4 + (lane >> 4);
+    float v = 0.f;
+    if (!transpose_flip) {
+        if (co < cout_f && ci < cin_f) v = w[((long long)co * cin_f + ci) * ks2 + tap];
+    } else {
+        if (co < ch && ci < cout_f) v = w[((long long)ci * cin_f + c0 + co) * ks2 + (ks2 - 1 - tap)];
+    }
+    out[o] = v;
+}
+
+int launch_pack_weights(const float *w, int cin_f, int cout_f, const ConvTiling &t, int transpose_flip, int c0, int ch, float *out,
+                        hipStream_t s) {
+    const long long total = (long long)t.packed_floats();
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, cin_f, cout_f, t.ks * t.ks, t.kc, t.nt,
+                       t.nchunks, total, transpose_flip, c0, ch, out);
+    PF_LAUNCH_CHECK("pack_weights_kernel");
+    return PF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm (training mode)
+// partial[c][slab][k]: k = 0 sum(y), 1 sum(y^2)  (stats)   or   0 sum(g'), 1 sum(g' * xhat)  (backward)
+constexpr int kBnSlabs = 64;
+
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float *y, int B, int C, long long HW, double *partial) {
+    const int c = blockIdx.x, slab = blockIdx.y;
+    __shared__ double sm[2 * 4];
+    double v[2] = {0.0, 0.0};
+    const long long per = (long long)B * HW;
+    for (long long i = (long long)slab * 256 + threadIdx.x; i < per; i += (long long)kBnSlabs * 256) {
+        const long long b = i / HW, p = i - b * HW;
+        const double x = (double)y[((long long)b * C + c) * HW + p];
+        v[0] += x;
+        v[1] += x * x;
+    }
+    block_reduce_d<2>(v, sm);
+    if (threadIdx.x == 0) {
+        partial[((long long)c * kBnSlabs + slab) * 2 + 0] = v[0];
+        partial[((long long)c * kBnSlabs + slab) * 2 + 1] = v[1];
+    }
+}
+
+// mean / invstd of the batch + running-stat update (nn.BatchNorm2d: momentum 0.1, unbiased variance in the running stat)
+__global__ void bn_stats_final_kernel(const double *partial, int C, double n, float eps, float momentum, float *mean, float *invstd,
+                                      float *running_mean, float *running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < kBnSlabs; ++k) {
+        s += partial[((long long)c * kBnSlabs + k) * 2 + 0];
+        q += partial[((long long)c * kBnSlabs + k) * 2 + 1];
+    }
+    const double m = s / n;
+    double var = q / n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
+// z = relu(gamma * (y - mean) * invstd + beta) into channel slice [choff, choff + C) of the destination tensor
+__global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *y, const float *mean, const float *invstd, const float *gamma,
+                                                            const float *beta, int C, long long HW, float *dst, int dst_ctotal, int dst_choff,
+                                                            int relu) {
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= HW) return;
+    const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+    const float *yp = y + (long long)bc * HW + i4;
+    float *dp = dst + ((long long)b * dst_ctotal + dst_choff + c) * HW + i4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i4 + k < HW) {
+            // (y - mean) * invstd * gamma + beta, written as one scale/shift like ATen's batch_norm CPU/CUDA transforms
+            float v = yp[k] * sc + sh;
+            dp[k] = relu ? fmaxf(v, 0.f) : v;
+        }
+}
+
+int launch_bn_forward(const float *y, int B, int C, int H, int W, float eps, float momentum, const float *gamma, const float *beta,
+                      float *running_mean, float *running_var, float *mean, float *invstd, double *partial, float *dst, int dst_ctotal,
+                      int dst_choff, int relu, hipStream_t s) {
+    const long long HW = (long long)H * W;
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, y, B, C, HW, partial);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, C, (double)B * HW, eps, momentum, mean, invstd,
+                       running_mean, running_var);
+    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3((unsigned)((HW / 4 + 256) / 256), B * C), dim3(256), 0, s, y, mean, invstd, gamma, beta, C, HW,
+                       dst, dst_ctotal, dst_choff, relu);
+    PF_LAUNCH_CHECK("bn_forward");
+    return PF_OK;
+}
+size_t bn_partial_doubles(int C) { return (size_t)C * kBnSlabs * 2; }
+
+// backward through ReLU + BN:  g' = g * [z > 0];  dbeta = sum g';  dgamma = sum g' * xhat;
+//                              dy = gamma * invstd * (g' - dbeta / N - xhat * dgamma / N)
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
+                                                             const float *mean, const float *invstd, int B, int C, long long HW, int relu,
+                                                             double *partial) {
+    const int c = blockIdx.x, slab = blockIdx.y;
+    __shared__ double sm[2 * 4];
+    double v[2] = {0.0, 0.0};
+    const long long per = (long long)B * HW;
+    const float mu = mean[c], is = invstd[c];
+    for (long long i = (long long)slab * 256 + threadIdx.x; i < per; i += (long long)kBnSlabs * 256) {
+        const long long b = i / HW, p = i - b * HW;
+        const long long ti = ((long long)b * t_ctotal + choff + c) * HW + p;
+        const float gp = (!relu || z[ti] > 0.f) ? g[ti] : 0.f;
+        const float xh = (y[((long long)b * C + c) * HW + p] - mu) * is;
+        v[0] += (double)gp;
+        v[1] += (double)gp * (double)xh;
+    }
+    block_reduce_d<2>(v, sm);
+    if (threadIdx.x == 0) {
+        partial[((long long)c * kBnSlabs + slab) * 2 + 0] = v[0];
+        partial[((long long)c * kBnSlabs + slab) * 2 + 1] = v[1];
+    }
+}
+__global__ void bn_bwd_final_kernel(const double *partial, int C, float *dgamma, float *dbeta, float *sums /* [2][C] */) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < kBnSlabs; ++k) {
+        s += partial[((long long)c * kBnSlabs + k) * 2 + 0];
+        q += partial[((long long)c * kBnSlabs + k) * 2 + 1];
+    }
+    dbeta[c] += (float)s;      // gradient arenas accumulate (zeroed once per step)
+    dgamma[c] += (float)q;
+    sums[c] = (float)s;
+    sums[C + c] = (float)q;
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
+                                                           const float *mean, const float *invstd, const float *gamma, const float *sums,
+                                                           int B, int C, long long HW, int relu, float *dy) {
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float n = (float)((double)B * (double)HW);
+    const long long ti = ((long long)b * t_ctotal + choff + c) * HW + i;
+    const float gp = (!relu || z[ti] > 0.f) ? g[ti] : 0.f;
+    const float xh = (y[(long long)bc * HW + i] - mean[c]) * invstd[c];
+    dy[(long long)bc * HW + i] = gamma[c] * invstd[c] * (gp - sums[c] / n - xh * sums[C + c] / n);
+}
+
+int launch_bn_backward(const float *g, const float *z, int t_ctotal, int choff, const float *y, const float *mean, const float *invstd,
+                       const float *gamma, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial, float *sums,
+                       float *dy, hipStream_t s) {
+    const long long HW = (long long)H * W;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd, B, C, HW, relu, partial);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((HW + 255) / 256), B * C), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd,
+                       gamma, sums, B, C, HW, relu, dy);
+    PF_LAUNCH_CHECK("bn_backward");
+    return PF_OK;
+}
+
+// bias gradient of a conv without BN (finalConv): dbias[c] += sum over (b, pixels) of g; also copies g -> dy (contiguous)
+__global__ __launch_bounds__(256) void bias_bwd_kernel(const float *g, int t_ctotal, int choff, int B, int C, long long HW, float *dbias,
+                                                       float *dy) {
+    const int c = blockIdx.x;
+    __shared__ double sm[4];
+    double v[1] = {0.0};
+    const long long per = (long long)B * HW;
+    for (long long i = threadIdx.x; i < per; i += 256) {
+        const long long b = i / HW, p = i - b * HW;
+        const float x = g[((long long)b * t_ctotal + choff + c) * HW + p];
+        dy[((long long)b * C + c) * HW + p] = x;
+        v[0] += (double)x;
+    }
+    block_reduce_d<1>(v, sm);
+    if (threadIdx.x == 0) dbias[c] += (float)v[0];
+}
+int launch_bias_backward(const float *g, int t_ctotal, int choff, int B, int C, int H, int W, float *dbias, float *dy, hipStream_t s) {
+    hipLaunchKernelGGL(bias_bwd_kernel, dim3(C), dim3(256), 0, s, g, t_ctotal, choff, B, C, (long long)H * W, dbias, dy);
+    PF_LAUNCH_CHECK("bias_bwd_kernel");
+    return PF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ conv backward-weight
+// dW[co][ci][tap] = sum over (b, oy, ox) of dy[b][co][oy][ox] * x[b][ci][oy*S + ky - P][ox*S + kx - P]
+// GEMM on v_mfma_f32_16x16x4_f32: M = 16 couts, N = 16 cins, K = pixels (4 per instruction).  Workgroup = (cout tile,
+// cin tile, slab of output rows); its 4 waves take the 16-pixel chunks of the slab's rows round-robin, keep the k*k
+// tap accumulators in registers and are combined through LDS; partial sums go to partial[slab][co][ci][tap] and are
+// added up by wgrad_reduce_kernel in slab order (no atomics: deterministic).
+template <int KS, int STRIDE>
+__global__ __launch_bounds__(256) void wgrad_partial_kernel(ConvArgs a, const float *dy, int B, int slabs, float *partial) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KS2 = KS * KS, P = KS / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int co = blockIdx.x * 16 + (lane & 15), ci = blockIdx.y * 16 + (lane & 15), kq = lane >> 4;
+    const int slab = blockIdx.z;
+    // this lane's input channel -> (source tensor, channel inside it)
+    const float *xsrc = nullptr;
+    long long xplane0 = 0;
+    int x_ctotal = 0;
+    if (ci < a.Cin) {
+        int sidx = 0;
+        while (sidx + 1 < a.n_src && ci >= a.src_cstart[sidx + 1]) ++sidx;
+        xsrc = a.src[sidx];
+        x_ctotal = a.src_ctotal[sidx];
+        xplane0 = a.src_choff[sidx] + (ci - a.src_cstart[sidx]);
+    }
+    const long long in_plane = (long long)a.Hin * a.Win, out_plane = (long long)a.Hout * a.Wout;
+    tr_f32x4 acc[KS2];
+#pragma unroll
+    for (int t = 0; t < KS2; ++t) acc[t] = tr_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int chunks_per_row = (a.Wout + 15) / 16;
+    const long long rows = (long long)B * a.Hout;
+    int work = 0;
+    for (long long row = slab; row < rows; row += slabs) {
+        const int b = (int)(row / a.Hout), oy = (int)(row - (long long)b * a.Hout);
+        const float *dyp = (co < a.Cout) ? dy + ((long long)b * a.Cout + co) * out_plane + (long long)oy * a.Wout : nullptr;
+        const float *xp = xsrc ? xsrc + ((long long)b * x_ctotal + xplane0) * in_plane : nullptr;
+        for (int ch = 0; ch < chunks_per_row; ++ch, ++work) {
+            if ((work & 3) != wave) continue;
+            const int ox0 = ch * 16 + kq * 4;
+            float av[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[j] = (dyp && ox0 + j < a.Wout) ? dyp[ox0 + j] : 0.f;
+#pragma unroll
+            for (int t = 0; t < KS2; ++t) {
+                const int ky = t / KS, kx = t - ky * KS;
+                const int iy = oy * STRIDE + ky - P;
+                float bv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ix = (ox0 + j) * STRIDE + kx - P;
+                    bv[j] = (xp && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && ox0 + j < a.Wout) ? xp[(long long)iy * a.Win + ix] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // combine the 4 waves: D fragment = rows m = 4*(lane>>4)+i (cout), column n = lane&15 (cin)
+    __shared__ float red[4][KS2][4][64];
+#pragma unroll
+    for (int t = 0; t < KS2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][t][i][lane] = acc[t][i];
+    __syncthreads();
+    const int ci_pad = gridDim.y * 16, co_pad = gridDim.x * 16;
+    for (int e = threadIdx.x; e < KS2 * 4 * 64; e += 256) {
+        const int l = e & 63, i = (e >> 6) & 3, t = e >> 8;
+        const float v = ((red[0][t][i][l] + red[1][t][i][l]) + red[2][t][i][l]) + red[3][t][i][l];
+        const int m = blockIdx.x * 16 + 4 * (l >> 4) + i, n = blockIdx.y * 16 + (l & 15);
+        partial[(((long long)slab * co_pad + m) * ci_pad + n) * KS2 + t] = v;
+    }
+#endif
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial, int slabs, int co_pad, int ci_pad, int ks2, int Cout, int Cin,
+                                                           float *dw) {
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)Cout * Cin * ks2;
+    if (o >= total) return;
+    const int t = (int)(o % ks2);
+    const int ci = (int)((o / ks2) % Cin), co = (int)(o / ((long long)ks2 * Cin));
+    float s = 0.f;
+    for (int k = 0; k < slabs; ++k) s += partial[(((long long)k * co_pad + co) * ci_pad + ci) * ks2 + t];
+    dw[o] += s;
+}
+
+int wgrad_slabs(int cout, int cin, int B, int Hout) {
+    const long long tiles = (long long)((cout + 15) / 16) * ((cin + 15) / 16);
+    long long s = 2048 / tiles;
+    s = s < 1 ? 1 : s;
+    const long long rows = (long long)B * Hout;
+    return (int)(s > rows ? rows : s);
+}
+size_t wgrad_partial_floats(int cout, int cin, int ks, int B, int Hout) {
+    return (size_t)wgrad_slabs(cout, cin, B, Hout) * ((cout + 15) / 16 * 16) * ((cin + 15) / 16 * 16) * ks * ks;
+}
+
+int launch_wgrad(const ConvArgs &a, int ks, int stride, const float *dy, int B, float *partial, float *dw, hipStream_t s) {
+    const int slabs = wgrad_slabs(a.Cout, a.Cin, B, a.Hout);
+    const dim3 grid((a.Cout + 15) / 16, (a.Cin + 15) / 16, slabs);
+    const double flops = 2.0 * B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks;
+    {
+        ProfScope ps(s, "wgrad_partial_kernel", flops, 4.0 * B * ((double)a.Cout * a.Hout * a.Wout + (double)a.Cin * a.Hin * a.Win));
+        if (ks == 3 && stride == 1) hipLaunchKernelGGL((wgrad_partial_kernel<3, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
+        else if (ks == 3 && stride == 2) hipLaunchKernelGGL((wgrad_partial_kernel<3, 2>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
+        else if (ks == 1 && stride == 1) hipLaunchKernelGGL((wgrad_partial_kernel<1, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
+        else return fail(PF_EUNSUPPORTED, "wgrad: k=%d stride=%d", ks, stride);
+        PF_LAUNCH_CHECK("wgrad_partial_kernel");
+    }
+    const long long total = (long long)a.Cout * a.Cin * ks * ks;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, slabs, (int)grid.x * 16, (int)grid.y * 16,
+                       ks * ks, a.Cout, a.Cin, dw);
+    PF_LAUNCH_CHECK("wgrad_reduce_kernel");
+    return PF_OK;
+}
+
+// zero-stuffing for the backward-data pass of a stride-2 conv: up[b][c][2*oy][2*ox] = dy[b][c][oy][ox], zeros elsewhere
+__global__ __launch_bounds__(256) void zero_stuff_kernel(const float *dy, int Hout, int Wout, int Hin, int Win, float *up) {
+    const int bc = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)Hin * Win) return;
+    const int y = (int)(i / Win), x = (int)(i - (long long)y * Win);
+    float v = 0.f;
+    if (!(y & 1) && !(x & 1) && (y >> 1) < Hout && (x >> 1) < Wout) v = dy[((long long)bc * Hout + (y >> 1)) * Wout + (x >> 1)];
+    up[(long long)bc * Hin * Win + i] = v;
+}
+int launch_zero_stuff(const float *dy, int planes, int Hout, int Wout, int Hin, int Win, float *up, hipStream_t s) {
+    hipLaunchKernelGGL(zero_stuff_kernel, dim3((unsigned)(((long long)Hin * Win + 255) / 256), planes), dim3(256), 0, s, dy, Hout, Wout, Hin, Win, up);
+    PF_LAUNCH_CHECK("zero_stuff_kernel");
+    return PF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pool / upsample backward
+// AvgPool2d(2,2): gin[2y+dy][2x+dx] += 0.25 * gout[y][x]   (rows/cols dropped by the floor division get no gradient)
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float *gout, int Hin, int Win, float *gin) {
+    const int bc = blockIdx.y, Ho = Hin >> 1, Wo = Win >> 1;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)Hin * Win) return;
+    const int y = (int)(i / Win), x = (int)(i - (long long)y * Win);
+    if ((y >> 1) < Ho && (x >> 1) < Wo) gin[(long long)bc * Hin * Win + i] += 0.25f * gout[((long long)bc * Ho + (y >> 1)) * Wo + (x >> 1)];
+}
+int launch_avgpool2_bwd(const float *gout, int planes, int Hin, int Win, float *gin, hipStream_t s) {
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3((unsigned)(((long long)Hin * Win + 255) / 256), planes), dim3(256), 0, s, gout, Hin, Win, gin);
+    PF_LAUNCH_CHECK("avgpool2_bwd_kernel");
+    return PF_OK;
+}
+
+// transpose of bilinear align_corners=True interpolation, gather form (deterministic): every source pixel sums the output
+// pixels whose two taps per axis (lin_coord, the same function the forward kernels use) include it.
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *gout, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
+                                                           const double *inv_count /* nullable: multiply by scale / *inv_count */, float scale,
+                                                           int accumulate, float *gin) {
+    const int bc = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)Hi * Wi) return;
+    const int iy = (int)(i / Wi), ix = (int)(i - (long long)iy * Wi);
+    // candidate output rows: r = sh * oy in (iy - 1, iy + 1)  ->  widen by one on both sides, test the indices exactly
+    int oy_lo = 0, oy_hi = Ho - 1, ox_lo = 0, ox_hi = Wo - 1;
+    if (sh > 0.f) {
+        oy_lo = max(0, (int)floorf((float)(iy - 1) / sh) - 1);
+        oy_hi = min(Ho - 1, (int)ceilf((float)(iy + 1) / sh) + 1);
+    }
+    if (sw > 0.f) {
+        ox_lo = max(0, (int)floorf((float)(ix - 1) / sw) - 1);
+        ox_hi = min(Wo - 1, (int)ceilf((float)(ix + 1) / sw) + 1);
+    }
+    const float *gp = gout + (long long)bc * Ho * Wo;
+    float sum = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        int y0, y1;
+        float hy0, hy1;
+        lin_coord(oy, sh, Hi, y0, y1, hy0, hy1);
+        const float wy = (y0 == iy ? hy0 : 0.f) + (y1 == iy ? hy1 : 0.f);
+        if (wy == 0.f) continue;
+        float rs = 0.f;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            int x0, x1;
+            float lx0, lx1;
+            lin_coord(ox, sw, Wi, x0, x1, lx0, lx1);
+            const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+            if (wx != 0.f) rs += wx * gp[(long long)oy * Wo + ox];
+        }
+        sum += wy * rs;
+    }
+    if (inv_count) sum = (float)((double)sum * (double)scale / fmax(*inv_count, 1.0));
+    float *d = gin + (long long)bc * Hi * Wi + i;
+    *d = accumulate ? *d + sum : sum;
+}
+int launch_upsample_bwd(const float *gout, int planes, int Hi, int Wi, int Ho, int Wo, const double *count, float scale, int accumulate,
+                        float *gin, hipStream_t s) {
+    const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)(((long long)Hi * Wi + 255) / 256), planes), dim3(256), 0, s, gout, Hi, Wi, Ho, Wo, sh, sw,
+                       count, scale, accumulate, gin);
+    PF_LAUNCH_CHECK("upsample_bwd_kernel");
+    return PF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ loss
+// F.interpolate(logits, (Ho,Wo), bilinear, align_corners=True) -> CrossEntropyLoss(ignore_index) (bg_model.py:44,81) and
+// its gradient w.r.t. the upsampled logits, (softmax - onehot) on valid pixels (NOT yet divided by the valid count),
+// plus the accuracy counters of :82-84.  partial[block][3] = {sum nll, valid, correct} in fp64.
+template <int C>
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float *logits, int Hi, int Wi, const void *labels, int lab_i64, int Ho, int Wo,
+                                                         int ignore, float sh, float sw, float *dfull, double *partial) {
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long HWo = (long long)Ho * Wo;
+    __shared__ double sm[3 * 4];
+    double v[3] = {0.0, 0.0, 0.0};
+    if (i < HWo) {
+        const int oy = (int)(i / Wo), ox = (int)(i - (long long)oy * Wo);
+        int y0, y1, x0, x1;
+        float hy0, hy1, lx0, lx1;
+        lin_coord(oy, sh, Hi, y0, y1, hy0, hy1);
+        lin_coord(ox, sw, Wi, x0, x1, lx0, lx1);
+        const long long li = (long long)b * HWo + i;
+        const long long lab = lab_i64 ? reinterpret_cast<const long long *>(labels)[li] : (long long)reinterpret_cast<const uint8_t *>(labels)[li];
+        float z[C];
+        float mx = -INFINITY;
+        int arg = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float *p = logits + ((long long)b * C + c) * Hi * Wi;
+            const float t0 = lx0 * p[(long long)y0 * Wi + x0] + lx1 * p[(long long)y0 * Wi + x1];
+            const float t1 = lx0 * p[(long long)y1 * Wi + x0] + lx1 * p[(long long)y1 * Wi + x1];
+            z[c] = hy0 * t0 + hy1 * t1;
+            if (z[c] > mx) { mx = z[c]; arg = c; }
+        }
+        const bool valid = lab != ignore && lab >= 0 && lab < C;
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+        const float lse = mx + logf(se);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float p = expf(z[c] - lse);
+            dfull[((long long)b * C + c) * HWo + i] = valid ? (p - (c == lab ? 1.f : 0.f)) : 0.f;
+            if (valid && c == lab) v[0] = (double)(lse - z[c]);
+        }
+        if (lab != ignore) {          // :83-84: total counts labels != 255, correct compares the argmax with the label
+            v[1] = 1.0;
+            v[2] = arg == lab ? 1.0 : 0.0;
+        }
+    }
+    block_reduce_d<3>(v, sm);
+    if (threadIdx.x == 0) {
+        double *p = partial + ((long long)b * gridDim.x + blockIdx.x) * 3;
+        p[0] = v[0]; p[1] = v[1]; p[2] = v[2];
+    }
+}
+__global__ __launch_bounds__(256) void sum3_kernel(const double *partial, long long n, double *out3) {
+    __shared__ double sm[3 * 4];
+    double v[3] = {0.0, 0.0, 0.0};
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        v[0] += partial[i * 3 + 0]; v[1] += partial[i * 3 + 1]; v[2] += partial[i * 3 + 2];
+    }
+    block_reduce_d<3>(v, sm);
+    if (threadIdx.x == 0) { out3[0] = v[0]; out3[1] = v[1]; out3[2] = v[2]; }
+}
+size_t ce_partial_doubles(int B, int Ho, int Wo) { return (size_t)B * (((size_t)Ho * Wo + 255) / 256) * 3; }
+
+int launch_ce_fwd_bwd(const float *logits, int B, int C, int Hi, int Wi, const void *labels, int lab_i64, int Ho, int Wo, int ignore,
+                      float *dfull, double *partial, double *out3, hipStream_t s) {
+    const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    const dim3 grid((unsigned)(((long long)Ho * Wo + 255) / 256), B);
+    if (C == 11) hipLaunchKernelGGL((ce_fwd_bwd_kernel<11>), grid, dim3(256), 0, s, logits, Hi, Wi, labels, lab_i64, Ho, Wo, ignore, sh, sw, dfull, partial);
+    else if (C == 19) hipLaunchKernelGGL((ce_fwd_bwd_kernel<19>), grid, dim3(256), 0, s, logits, Hi, Wi, labels, lab_i64, Ho, Wo, ignore, sh, sw, dfull, partial);
+    else return fail(PF_EUNSUPPORTED, "cross entropy kernels are built for 11 or 19 classes, got %d", C);
+    hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(256), 0, s, partial, (long long)grid.x * B, out3);
+    PF_LAUNCH_CHECK("ce_fwd_bwd");
+    return PF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ optimiser
+// nn.utils.clip_grad_norm_ (train.py:207-208): coef = min(1, max_norm / (||g||_2 + 1e-6)) over the trainable elements
+constexpr int kNormBlocks = 512;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float *g, const uint8_t *trainable, long long n, double *partial) {
+    __shared__ double sm[4];
+    double v[1] = {0.0};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)kNormBlocks * 256)
+        if (trainable[i]) v[0] += (double)g[i] * (double)g[i];
+    block_reduce_d<1>(v, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = v[0];
+}
+__global__ __launch_bounds__(256) void clip_coef_kernel(const double *partial, float max_norm, float *coef_norm2 /* [2]: coef, total norm */) {
+    __shared__ double sm[4];
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < kNormBlocks; i += 256) v[0] += partial[i];
+    block_reduce_d<1>(v, sm);
+    if (threadIdx.x == 0) {
+        const double norm = sqrt(v[0]);
+        const double c = (double)max_norm / (norm + 1e-6);
+        coef_norm2[0] = max_norm > 0.f ? (float)(c < 1.0 ? c : 1.0) : 1.f;
+        coef_norm2[1] = (float)norm;
+    }
+}
+// torch.optim.SGD (train.py:138): g += wd * p;  buf = first ? g : momentum * buf + g;  p -= lr * buf
+__global__ __launch_bounds__(256) void sgd_kernel(float *theta, float *grad, float *mom, const uint8_t *trainable, long long n, float lr,
+                                                  float momentum, float wd, const float *coef, float clip_value, int first) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !trainable[i]) return;
+    float g = grad[i] * coef[0];
+    if (clip_value > 0.f) g = fminf(fmaxf(g, -clip_value), clip_value);     // clip_grad_value_ (train.py:205-206)
+    grad[i] = g;                                                            // what .grad holds after clipping
+    g += wd * theta[i];
+    const float buf = (first || momentum == 0.f) ? g : momentum * mom[i] + g;
+    mom[i] = buf;
+    theta[i] -= lr * buf;
+}
+size_t sgd_ws_bytes() { return kNormBlocks * sizeof(double) + 64; }
+
+int launch_sgd(float *theta, float *grad, float *mom, const uint8_t *trainable, long long n, float lr, float momentum, float wd, float clip_norm,
+               float clip_value, int first, void *ws, hipStream_t s) {
+    double *partial = (double *)ws;
+    float *coef = (float *)((char *)ws + kNormBlocks * sizeof(double));
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grad, trainable, n, partial);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, s, partial, clip_norm, coef);
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, theta, grad, mom, trainable, n, lr, momentum, wd, coef,
+                       clip_value, first);
+    PF_LAUNCH_CHECK("sgd");
+    return PF_OK;
+}
+
+}  // namespace pf

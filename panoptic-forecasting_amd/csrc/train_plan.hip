@@ -1,0 +1,405 @@
+// bg training step (scope row f4): forward in training mode + loss + backward over the op table, and the optimiser step.
+//
+// Replaces, for task `bg`, what the reference's training loop does per batch (training/train.py:185-222):
+//     loss_dict = model.loss(inputs, labels)      models/bg/bg_model.py:73-89  (train-mode BatchNorm, F.interpolate, CrossEntropyLoss)
+//     loss.backward()                             autograd through hardnet.py:353-387
+//     clip_grad_value_ / clip_grad_norm_ ; opt.step()  (SGD, momentum, weight decay: train.py:130-138)
+// Parameters live in ONE flat fp32 arena `theta` (layout below; the Python side maps the reference's state_dict keys onto
+// it), gradients in an arena of the same layout — so the data-parallel exchange is a single all-reduce of ~16.5 MB over
+// RCCL between pf_train_forward_backward and pf_sgd_step (the reference wraps the model in DDP, train.py:96-103).
+//
+// theta layout: for every conv op of the table, in table order:  W[cout][cin][k][k],  then
+//     with BatchNorm:  gamma[cout], beta[cout], running_mean[cout], running_var[cout]      (ConvLayer, hardnet.py:16-25)
+//     without       :  bias[cout]                                                          (finalConv, hardnet.py:325-327)
+//
+// Convolutions run on the fp32 matrix cores: forward and backward-data through the generic implicit-GEMM kernel of
+// conv_mfma.hip (weights re-packed on the device every step: forward order, or transposed + flipped per input range;
+// stride-2 backward-data = stride-1 conv over the zero-stuffed gradient), backward-weight through wgrad_partial_kernel.
+#include <cstring>
+#include <vector>
+
+#include "net_kernels.h"
+#include "pf_blob.h"
+#include "pf_prof.h"
+#include "train_kernels.h"
+
+using namespace pf;
+
+struct pf_train {
+    BlobHeader hdr;
+    std::vector<BlobTensor> tensors;
+    std::vector<BlobOp> ops;
+    std::vector<size_t> w_off, aux_off;   // per op (floats into theta); aux = gamma (BN) or bias
+    std::vector<int> bn;                  // per op: 1 = conv + BN (+ ReLU), 0 = plain conv with bias
+    size_t n_params = 0;
+    float *dev_zero = nullptr;            // 1024 zeros (bias of the BN-less generic conv launches)
+};
+
+namespace {
+
+struct TDims {
+    int h = 0, w = 0;
+};
+
+int t_propagate(const pf_train *p, int H, int W, std::vector<TDims> &d) {
+    d.assign(p->tensors.size(), TDims());
+    d[p->ops[0].src[0].tensor] = {H, W};
+    for (const BlobOp &o : p->ops) {
+        const TDims in = d[o.src[0].tensor];
+        if (in.h <= 0 || in.w <= 0) return fail(PF_EBLOB, "op reads a tensor that was never produced");
+        TDims out = in;
+        if (o.kind == OP_STEM || o.kind == OP_CONV) {
+            const int pad = o.k / 2;
+            out.h = (in.h + 2 * pad - (int)o.k) / (int)o.stride + 1;
+            out.w = (in.w + 2 * pad - (int)o.k) / (int)o.stride + 1;
+        } else if (o.kind == OP_POOL) {
+            out = {in.h / 2, in.w / 2};
+        } else if (o.kind == OP_UPSAMPLE) {
+            out = d[o.src[1].tensor];
+        }
+        if (out.h <= 0 || out.w <= 0) return fail(PF_EINVAL, "input %dx%d is too small for this network", H, W);
+        if (o.kind != OP_HEAD) d[o.dst] = out;
+    }
+    return PF_OK;
+}
+
+struct TLayout {
+    std::vector<size_t> act, grad;     // per tensor (bytes); act[input] = the dense one-hot/depth tensor
+    std::vector<size_t> ypre, stat;    // per op: pre-BN conv output, {mean[cout], invstd[cout]}
+    size_t dy = 0, wpk = 0, wpart = 0, dfull = 0, cepart = 0, bnpart = 0, sums = 0, out3 = 0, total = 0;
+    size_t grad_begin = 0, grad_end = 0;
+};
+
+TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_h, int out_w) {
+    TLayout L;
+    const size_t nt = p->tensors.size();
+    L.act.assign(nt, (size_t)-1);
+    L.grad.assign(nt, (size_t)-1);
+    L.ypre.assign(p->ops.size(), (size_t)-1);
+    L.stat.assign(p->ops.size(), (size_t)-1);
+    size_t cur = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = cur;
+        cur += align_up(bytes, 256);
+        return o;
+    };
+    auto tbytes = [&](size_t t) { return (size_t)B * p->tensors[t].channels * d[t].h * d[t].w * sizeof(float); };
+    for (size_t t = 0; t < nt; ++t)
+        if (d[t].h) L.act[t] = take(tbytes(t));
+    L.grad_begin = cur;
+    const uint32_t input = p->ops[0].src[0].tensor;
+    for (size_t t = 0; t < nt; ++t)
+        if (d[t].h && t != input) L.grad[t] = take(tbytes(t));
+    L.grad_end = cur;
+    size_t max_dy = 0, max_wpk = 0, max_wpart = 0, max_c = 16;
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const BlobOp &o = p->ops[i];
+        if (o.kind != OP_STEM && o.kind != OP_CONV) continue;
+        const TDims in = d[o.src[0].tensor], out = d[o.dst];
+        const size_t ybytes = (size_t)B * o.cout * out.h * out.w * sizeof(float);
+        if (p->bn[i]) {
+            L.ypre[i] = take(ybytes);
+            L.stat[i] = take(2 * (size_t)o.cout * sizeof(float));
+        }
+        // dy scratch: the conv-output gradient, and (stride 2) its zero-stuffed copy at the input resolution
+        size_t need = ybytes;
+        if (o.stride == 2) need += align_up((size_t)B * o.cout * in.h * in.w * sizeof(float), 256);
+        max_dy = need > max_dy ? need : max_dy;
+        const ConvTiling tf = choose_tiling((int)o.k, (int)o.stride, (int)o.cin, (int)o.cout, 0);
+        max_wpk = tf.packed_floats() > max_wpk ? tf.packed_floats() : max_wpk;
+        for (uint32_t j = 0; j < o.n_src; ++j) {
+            const ConvTiling tb = choose_tiling((int)o.k, 1, (int)o.cout, (int)o.src[j].ch, 0);
+            max_wpk = tb.packed_floats() > max_wpk ? tb.packed_floats() : max_wpk;
+        }
+        const size_t wp = wgrad_partial_floats((int)o.cout, (int)o.cin, (int)o.k, B, out.h);
+        max_wpart = wp > max_wpart ? wp : max_wpart;
+        max_c = o.cout > max_c ? o.cout : max_c;
+    }
+    L.dy = take(max_dy + 256);
+    L.wpk = take(max_wpk * sizeof(float));
+    L.wpart = take(max_wpart * sizeof(float));
+    L.dfull = take((size_t)B * p->hdr.n_cls * out_h * out_w * sizeof(float));
+    L.cepart = take(ce_partial_doubles(B, out_h, out_w) * sizeof(double));
+    L.bnpart = take(bn_partial_doubles((int)max_c) * sizeof(double));
+    L.sums = take(2 * max_c * sizeof(float));
+    L.out3 = take(4 * sizeof(double));
+    L.total = cur;
+    return L;
+}
+
+}  // namespace
+
+extern "C" int pf_train_create(const void *blob, size_t bytes, int in_ch, int n_cls, pf_train **out) {
+    if (!blob || !out) return fail(PF_EINVAL, "pf_train_create: null argument");
+    if (bytes < sizeof(BlobHeader)) return fail(PF_EBLOB, "blob shorter than its header");
+    BlobHeader h;
+    memcpy(&h, blob, sizeof(h));
+    if (memcmp(h.magic, kBlobMagic, 8) != 0 || h.version != kBlobVersion) return fail(PF_EBLOB, "bad blob magic/version");
+    if (h.total_bytes != bytes || h.tensor_off + (uint64_t)h.n_tensors * sizeof(BlobTensor) > bytes ||
+        h.op_off + (uint64_t)h.n_ops * sizeof(BlobOp) > bytes)
+        return fail(PF_EBLOB, "blob table offsets out of range");
+    if ((int)h.in_ch != in_ch || (int)h.n_cls != n_cls) return fail(PF_EINVAL, "blob is for in_ch=%u n_cls=%u", h.in_ch, h.n_cls);
+    pf_train *p = new pf_train();
+    p->hdr = h;
+    p->tensors.resize(h.n_tensors);
+    p->ops.resize(h.n_ops);
+    memcpy(p->tensors.data(), (const char *)blob + h.tensor_off, h.n_tensors * sizeof(BlobTensor));
+    memcpy(p->ops.data(), (const char *)blob + h.op_off, h.n_ops * sizeof(BlobOp));
+    p->w_off.assign(h.n_ops, 0);
+    p->aux_off.assign(h.n_ops, 0);
+    p->bn.assign(h.n_ops, 0);
+    size_t cur = 0;
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const BlobOp &o = p->ops[i];
+        bool ok = o.n_src >= 1 && o.n_src <= (uint32_t)kMaxSrc && o.dst < h.n_tensors;
+        uint32_t cin = 0;
+        for (uint32_t j = 0; ok && j < o.n_src; ++j) {
+            ok = o.src[j].tensor < h.n_tensors && o.src[j].choff + o.src[j].ch <= p->tensors[o.src[j].tensor].channels;
+            cin += o.src[j].ch;
+        }
+        if (!ok) {
+            delete p;
+            return fail(PF_EBLOB, "op %zu is inconsistent with the tensor table", i);
+        }
+        if (o.kind != OP_STEM && o.kind != OP_CONV) continue;
+        if (cin != o.cin || !((o.k == 3 && (o.stride == 1 || o.stride == 2)) || (o.k == 1 && o.stride == 1))) {
+            delete p;
+            return fail(PF_EUNSUPPORTED, "op %zu: training supports 3x3 (stride 1/2) and 1x1 convs", i);
+        }
+        // packing.py writes pad[0] = 1 + has_bn; blobs without the field: ConvLayer (conv + BN + ReLU) <=> relu flag
+        p->bn[i] = o.pad[0] ? (int)o.pad[0] - 1 : (int)(o.relu != 0);
+        p->w_off[i] = cur;
+        cur += (size_t)o.cout * o.cin * o.k * o.k;
+        p->aux_off[i] = cur;
+        cur += (size_t)o.cout * (p->bn[i] ? 4 : 1);
+    }
+    p->n_params = cur;
+    if (hipMalloc((void **)&p->dev_zero, 1024 * sizeof(float)) != hipSuccess || hipMemset(p->dev_zero, 0, 1024 * sizeof(float)) != hipSuccess) {
+        delete p;
+        return fail(PF_EHIP, "pf_train_create: device allocation failed");
+    }
+    *out = p;
+    return PF_OK;
+}
+
+extern "C" void pf_train_destroy(pf_train *p) {
+    if (!p) return;
+    if (p->dev_zero) (void)hipFree(p->dev_zero);
+    delete p;
+}
+
+extern "C" int pf_train_param_count(const pf_train *p, size_t *n_floats) {
+    if (!p || !n_floats) return fail(PF_EINVAL, "pf_train_param_count: null");
+    *n_floats = p->n_params;
+    return PF_OK;
+}
+
+extern "C" int pf_train_param_layout(const pf_train *p, int op_index, size_t *w_off, size_t *aux_off, int *has_bn) {
+    if (!p || op_index < 0 || (size_t)op_index >= p->ops.size() || !w_off || !aux_off || !has_bn) return fail(PF_EINVAL, "pf_train_param_layout: bad argument");
+    const BlobOp &o = p->ops[op_index];
+    if (o.kind != OP_STEM && o.kind != OP_CONV) return fail(PF_EINVAL, "op %d is not a convolution", op_index);
+    *w_off = p->w_off[op_index];
+    *aux_off = p->aux_off[op_index];
+    *has_bn = p->bn[op_index];
+    return PF_OK;
+}
+
+extern "C" int pf_train_workspace(const pf_train *p, int B, int H, int W, int out_h, int out_w, size_t *bytes) {
+    if (!p || !bytes || B <= 0 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) return fail(PF_EINVAL, "pf_train_workspace: bad argument");
+    std::vector<TDims> d;
+    int rc = t_propagate(p, H, W, d);
+    if (rc) return rc;
+    *bytes = t_layout(p, B, d, out_h, out_w).total;
+    return PF_OK;
+}
+
+extern "C" int pf_train_tensor_view(const pf_train *p, const char *name, int want_grad, int B, int H, int W, int out_h, int out_w,
+                                    size_t *ws_offset, int *channels, int *h, int *w) {
+    if (!p || !name || !ws_offset || !channels || !h || !w) return fail(PF_EINVAL, "pf_train_tensor_view: null");
+    std::vector<TDims> d;
+    int rc = t_propagate(p, H, W, d);
+    if (rc) return rc;
+    const TLayout L = t_layout(p, B, d, out_h, out_w);
+    for (size_t t = 0; t < p->tensors.size(); ++t)
+        if (strncmp(p->tensors[t].name, name, sizeof(p->tensors[t].name)) == 0) {
+            const size_t off = want_grad ? L.grad[t] : L.act[t];
+            if (off == (size_t)-1) return fail(PF_EINVAL, "tensor '%s' has no %s buffer", name, want_grad ? "gradient" : "activation");
+            *ws_offset = off; *channels = (int)p->tensors[t].channels; *h = d[t].h; *w = d[t].w;
+            return PF_OK;
+        }
+    return fail(PF_EINVAL, "no tensor named '%s'", name);
+}
+
+extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float *grad, int accumulate_grads, const void *seg, int seg_is_i64,
+                                         const float *depth, const uint8_t *depth_mask, float depth_mean, float depth_std, int T,
+                                         const float *x_dense, int B, int H, int W, const void *labels, int labels_i64, int out_h, int out_w,
+                                         int ignore_index, float loss_scale, float bn_momentum, float bn_eps, int update_running_stats,
+                                         double *out3, void *ws, size_t ws_bytes, void *stream) {
+    if (!p || !theta || !grad || !labels || !out3 || !ws) return fail(PF_EINVAL, "pf_train_forward_backward: null pointer argument");
+    if (!x_dense && (!seg || !depth || !depth_mask)) return fail(PF_EINVAL, "pf_train_forward_backward: pass seg+depth+depth_mask or x_dense");
+    if (B <= 0 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) return fail(PF_EINVAL, "pf_train_forward_backward: bad dims");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<TDims> d;
+    int rc = t_propagate(p, H, W, d);
+    if (rc) return rc;
+    const TLayout L = t_layout(p, B, d, out_h, out_w);
+    if (ws_bytes < L.total) return fail(PF_EWORKSPACE, "workspace %zu B < required %zu B", ws_bytes, L.total);
+    char *wsb = (char *)ws;
+    auto act = [&](uint32_t t) { return reinterpret_cast<float *>(wsb + L.act[t]); };
+    auto gradt = [&](uint32_t t) { return reinterpret_cast<float *>(wsb + L.grad[t]); };
+    const uint32_t input = p->ops[0].src[0].tensor;
+    const int in_ch = (int)p->tensors[input].channels, n_cls = (int)p->hdr.n_cls;
+    float *dy = reinterpret_cast<float *>(wsb + L.dy);
+    float *wpk = reinterpret_cast<float *>(wsb + L.wpk);
+    float *wpart = reinterpret_cast<float *>(wsb + L.wpart);
+    float *dfull = reinterpret_cast<float *>(wsb + L.dfull);
+    double *cepart = reinterpret_cast<double *>(wsb + L.cepart);
+    double *bnpart = reinterpret_cast<double *>(wsb + L.bnpart);
+    float *sums = reinterpret_cast<float *>(wsb + L.sums);
+    double *loss3 = reinterpret_cast<double *>(wsb + L.out3);
+
+    // ---- input tensor (bg_model.py:61-69)
+    if (x_dense) {
+        PF_HIP_CHECK(hipMemcpyAsync(act(input), x_dense, (size_t)B * in_ch * H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {
+        if (T * (n_cls + 1) != in_ch) return fail(PF_EINVAL, "T=%d frames x (%d classes + depth) != %d input channels", T, n_cls, in_ch);
+        if ((rc = launch_onehot_dense(seg, seg_is_i64, depth, depth_mask, depth_mean, depth_std, B, T, n_cls, H, W, act(input), s))) return rc;
+    }
+    PF_HIP_CHECK(hipMemsetAsync(wsb + L.grad_begin, 0, L.grad_end - L.grad_begin, s));
+    if (!accumulate_grads) PF_HIP_CHECK(hipMemsetAsync(grad, 0, p->n_params * sizeof(float), s));
+
+    auto conv_args = [&](const BlobOp &o, const TDims &in, const TDims &out, ConvArgs &a) {
+        memset(&a, 0, sizeof(a));
+        a.n_src = (int)o.n_src;
+        int c0 = 0;
+        for (int j = 0; j < a.n_src; ++j) {
+            a.src[j] = act(o.src[j].tensor);
+            a.src_ctotal[j] = (int)p->tensors[o.src[j].tensor].channels;
+            a.src_choff[j] = (int)o.src[j].choff;
+            a.src_cstart[j] = c0;
+            c0 += (int)o.src[j].ch;
+        }
+        for (int j = a.n_src; j <= kConvMaxSrc; ++j) a.src_cstart[j] = c0;
+        a.bias = p->dev_zero;
+        a.Cin = (int)o.cin; a.Cout = (int)o.cout;
+        a.Hin = in.h; a.Win = in.w; a.Hout = out.h; a.Wout = out.w;
+        a.zero_page = p->dev_zero;
+        a.ntiles = ((int)o.cout + 15) / 16;
+        a.src_end = a.n_src;
+    };
+
+    // ================================================================ forward (training mode)
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const BlobOp &o = p->ops[i];
+        const TDims in = d[o.src[0].tensor];
+        const TDims out = o.kind == OP_HEAD ? in : d[o.dst];
+        if (o.kind == OP_STEM || o.kind == OP_CONV) {
+            const ConvTiling t = choose_tiling((int)o.k, (int)o.stride, (int)o.cin, (int)o.cout, 0);
+            if ((rc = launch_pack_weights(theta + p->w_off[i], (int)o.cin, (int)o.cout, t, 0, 0, 0, wpk, s))) return rc;
+            ConvArgs a;
+            conv_args(o, in, out, a);
+            a.wpk = wpk;
+            a.nchunks = t.nchunks;
+            if (p->bn[i]) {
+                float *y = reinterpret_cast<float *>(wsb + L.ypre[i]);
+                a.dst = y; a.dst_ctotal = (int)o.cout; a.dst_choff = 0; a.relu = 0;
+                if ((rc = launch_conv(a, t, B, s))) return rc;
+                float *aux = theta + p->aux_off[i];
+                float *stat = reinterpret_cast<float *>(wsb + L.stat[i]);
+                if ((rc = launch_bn_forward(y, B, (int)o.cout, out.h, out.w, bn_eps, bn_momentum, aux, aux + o.cout,
+                                            update_running_stats ? aux + 2 * o.cout : nullptr, update_running_stats ? aux + 3 * o.cout : nullptr,
+                                            stat, stat + o.cout, bnpart, act(o.dst), (int)p->tensors[o.dst].channels, (int)o.dst_choff,
+                                            (int)o.relu, s)))
+                    return rc;
+            } else {
+                a.bias = theta + p->aux_off[i];
+                a.dst = act(o.dst); a.dst_ctotal = (int)p->tensors[o.dst].channels; a.dst_choff = (int)o.dst_choff; a.relu = (int)o.relu;
+                if ((rc = launch_conv(a, t, B, s))) return rc;
+            }
+        } else if (o.kind == OP_POOL) {
+            if ((rc = launch_avgpool2(act(o.src[0].tensor), act(o.dst), B * (int)o.cin, in.h, in.w, s))) return rc;
+        } else if (o.kind == OP_UPSAMPLE) {
+            if ((rc = launch_upsample(act(o.src[0].tensor), act(o.dst), B * (int)o.cin, in.h, in.w, out.h, out.w, s))) return rc;
+        } else if (o.kind == OP_HEAD) {
+            if ((rc = launch_ce_fwd_bwd(act(o.src[0].tensor), B, (int)o.cin, in.h, in.w, labels, labels_i64, out_h, out_w, ignore_index, dfull,
+                                        cepart, loss3, s)))
+                return rc;
+            PF_HIP_CHECK(hipMemcpyAsync(out3, loss3, 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+    }
+
+    // ================================================================ backward
+    for (size_t ii = p->ops.size(); ii-- > 0;) {
+        const BlobOp &o = p->ops[ii];
+        const TDims in = d[o.src[0].tensor];
+        const TDims out = o.kind == OP_HEAD ? in : d[o.dst];
+        if (o.kind == OP_HEAD) {
+            // d loss / d logits = bilinear^T (softmax - onehot) * loss_scale / n_valid   (mean over the valid pixels, bg_model.py:81)
+            if ((rc = launch_upsample_bwd(dfull, B * (int)o.cin, in.h, in.w, out_h, out_w, loss3 + 1, loss_scale, 0, gradt(o.src[0].tensor), s))) return rc;
+        } else if (o.kind == OP_POOL) {
+            if ((rc = launch_avgpool2_bwd(gradt(o.dst), B * (int)o.cin, in.h, in.w, gradt(o.src[0].tensor), s))) return rc;
+        } else if (o.kind == OP_UPSAMPLE) {
+            if ((rc = launch_upsample_bwd(gradt(o.dst), B * (int)o.cin, in.h, in.w, out.h, out.w, nullptr, 1.f, 1, gradt(o.src[0].tensor), s))) return rc;
+        } else if (o.kind == OP_STEM || o.kind == OP_CONV) {
+            const int t_ctotal = (int)p->tensors[o.dst].channels;
+            float *aux = theta + p->aux_off[ii], *gaux = grad + p->aux_off[ii];
+            if (p->bn[ii]) {
+                const float *stat = reinterpret_cast<const float *>(wsb + L.stat[ii]);
+                if ((rc = launch_bn_backward(gradt(o.dst), act(o.dst), t_ctotal, (int)o.dst_choff, reinterpret_cast<const float *>(wsb + L.ypre[ii]),
+                                             stat, stat + o.cout, aux, B, (int)o.cout, out.h, out.w, (int)o.relu, gaux, gaux + o.cout, bnpart, sums,
+                                             dy, s)))
+                    return rc;
+            } else {
+                if (o.relu) return fail(PF_EUNSUPPORTED, "training: ReLU without BatchNorm (op %zu)", ii);
+                if ((rc = launch_bias_backward(gradt(o.dst), t_ctotal, (int)o.dst_choff, B, (int)o.cout, out.h, out.w, gaux, dy, s))) return rc;
+            }
+            // dW
+            ConvArgs a;
+            conv_args(o, in, out, a);
+            if ((rc = launch_wgrad(a, (int)o.k, (int)o.stride, dy, B, wpart, grad + p->w_off[ii], s))) return rc;
+            // dX per input range (the network input needs none)
+            const float *dsrc = dy;
+            if (o.stride == 2) {
+                float *up = dy + align_up((size_t)B * o.cout * out.h * out.w * sizeof(float), 256) / sizeof(float);
+                bool needed = false;
+                for (uint32_t j = 0; j < o.n_src; ++j) needed = needed || o.src[j].tensor != input;
+                if (needed && (rc = launch_zero_stuff(dy, B * (int)o.cout, out.h, out.w, in.h, in.w, up, s))) return rc;
+                dsrc = up;
+            }
+            int c0 = 0;
+            for (uint32_t j = 0; j < o.n_src; ++j) {
+                const int ch = (int)o.src[j].ch;
+                if (o.src[j].tensor != input) {
+                    const ConvTiling tb = choose_tiling((int)o.k, 1, (int)o.cout, ch, 0);
+                    if ((rc = launch_pack_weights(theta + p->w_off[ii], (int)o.cin, (int)o.cout, tb, 1, c0, ch, wpk, s))) return rc;
+                    ConvArgs b;
+                    memset(&b, 0, sizeof(b));
+                    b.n_src = 1;
+                    b.src[0] = dsrc; b.src_ctotal[0] = (int)o.cout; b.src_choff[0] = 0; b.src_cstart[0] = 0;
+                    for (int k = 1; k <= kConvMaxSrc; ++k) b.src_cstart[k] = (int)o.cout;
+                    b.wpk = wpk; b.nchunks = tb.nchunks; b.bias = p->dev_zero; b.zero_page = p->dev_zero;
+                    b.dst = gradt(o.src[j].tensor); b.dst_ctotal = (int)p->tensors[o.src[j].tensor].channels; b.dst_choff = (int)o.src[j].choff;
+                    b.Cin = (int)o.cout; b.Cout = ch; b.Hin = in.h; b.Win = in.w; b.Hout = in.h; b.Wout = in.w;
+                    b.ntiles = (ch + 15) / 16; b.src_end = 1; b.accum = 1;
+                    if ((rc = launch_conv(b, tb, B, s))) return rc;
+                }
+                c0 += ch;
+            }
+        }
+    }
+    return PF_OK;
+}
+
+extern "C" int pf_sgd_workspace(size_t *bytes) {
+    if (!bytes) return fail(PF_EINVAL, "pf_sgd_workspace: null");
+    *bytes = sgd_ws_bytes();
+    return PF_OK;
+}
+
+extern "C" int pf_sgd_step(float *theta, float *grad, float *momentum_buf, const uint8_t *trainable, size_t n, float lr, float momentum,
+                           float weight_decay, float clip_norm, float clip_value, int first_step, void *ws, size_t ws_bytes, void *stream) {
+    if (!theta || !grad || !momentum_buf || !trainable || !ws || n == 0) return fail(PF_EINVAL, "pf_sgd_step: null argument");
+    if (ws_bytes < sgd_ws_bytes()) return fail(PF_EWORKSPACE, "pf_sgd_step: workspace %zu B < required %zu B", ws_bytes, sgd_ws_bytes());
+    return launch_sgd(theta, grad, momentum_buf, trainable, (long long)n, lr, momentum, weight_decay, clip_norm, clip_value, first_step, ws,
+                      (hipStream_t)stream);
+}

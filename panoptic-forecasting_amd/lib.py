@@ -36,6 +36,17 @@ SIGNATURES = {
     'pf_panoptic_max_ids': (_i, []),
     'pf_seg_loss_workspace': (_i, [_i, _i, _i, _c.POINTER(_sz)]),
     'pf_seg_loss': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'pf_train_create': (_i, [_vp, _sz, _i, _i, _c.POINTER(_vp)]),
+    'pf_train_destroy': (None, [_vp]),
+    'pf_train_param_count': (_i, [_vp, _c.POINTER(_sz)]),
+    'pf_train_param_layout': (_i, [_vp, _i, _c.POINTER(_sz), _c.POINTER(_sz), _c.POINTER(_i)]),
+    'pf_train_workspace': (_i, [_vp, _i, _i, _i, _i, _i, _c.POINTER(_sz)]),
+    'pf_train_forward_backward': (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _f, _f, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _f,
+                                       _f, _i, _vp, _vp, _sz, _vp]),
+    'pf_train_tensor_view': (_i, [_vp, _c.c_char_p, _i, _i, _i, _i, _i, _i, _c.POINTER(_sz), _c.POINTER(_i), _c.POINTER(_i),
+                                  _c.POINTER(_i)]),
+    'pf_sgd_workspace': (_i, [_c.POINTER(_sz)]),
+    'pf_sgd_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _sz, _vp]),
     'pf_set_option': (_i, [_c.c_char_p, _i]),
     'pf_hardnet_plan_set_option': (_i, [_vp, _c.c_char_p, _i]),
     'pf_debug_force_conv': (_i, [_i, _i, _i, _i]),

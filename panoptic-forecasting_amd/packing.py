@@ -12,7 +12,7 @@ Blob layout (little endian, all offsets from the start of the blob):
   header   64 B : magic "PFHNET02", u32 version, n_tensors, n_ops, in_ch, n_cls, pad,
                   u64 tensor_table_off, op_table_off, weights_off, total_bytes
   tensors  n_tensors x 48 B {u32 channels, u32 pad, char name[40]}
-  ops      n_ops x 128 B {u32 kind,k,stride,relu,cin,cout,n_src,dst,dst_choff,pad[3],
+  ops      n_ops x 128 B {u32 kind,k,stride,relu,cin,cout,n_src,dst,dst_choff,bn_tag (1 + has BatchNorm; convs only),pad[2],
                           {u32 tensor,choff,ch}[4], u64 w_off, u64 b_off, pad to 128}
   weights  fp32: per conv OIHW [cout][cin][k][k] then bias[cout]  (w_off/b_off in floats)
 """
@@ -91,7 +91,8 @@ def pack_blob(sd, in_ch=36, n_cls=11, prefix='model.', spec=None, params=None):
             raise ValueError('%s has %d sources (max %d)' % (op.name, len(op.srcs), MAX_SRC))
         base = o_off + OP_BYTES * i
         struct.pack_into('<12I', out, base, op.kind, op.k, op.stride, int(op.relu), op.cin, op.cout,
-                         len(op.srcs), op.dst, op.dst_choff, 0, 0, 0)
+                         len(op.srcs), op.dst, op.dst_choff,
+                         (1 + int(op.bn)) if op.kind in (arch.OP_STEM, arch.OP_CONV) else 0, 0, 0)
         for j, s in enumerate(op.srcs):
             struct.pack_into('<3I', out, base + 48 + 12 * j, s.tensor, s.choff, s.ch)
         wo, bo = w_off.get(op.name, (0, 0))

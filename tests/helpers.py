@@ -21,12 +21,17 @@ class MiniSpec:
         self.tensors.append(arch.Tensor(name, ch))
         return len(self.tensors) - 1
 
-    def conv(self, name, srcs, cout, k, stride=1, dst=None, dst_choff=0, relu=True):
+    def conv(self, name, srcs, cout, k, stride=1, dst=None, dst_choff=0, relu=True, bn=False):
         cin = sum(s.ch for s in srcs)
         if dst is None:
             dst = self.tensor(name, cout)
-        self.ops.append(arch.Op(arch.OP_CONV, name, srcs, dst, dst_choff, cin, cout, k, stride, relu, bn=False))
+        self.ops.append(arch.Op(arch.OP_CONV, name, srcs, dst, dst_choff, cin, cout, k, stride, relu, bn=bn))
         return dst
+
+    def head(self, logits_t):
+        ch = self.tensors[logits_t].channels
+        self.n_cls = ch
+        self.ops.append(arch.Op(arch.OP_HEAD, 'head', [arch.Src(logits_t, 0, ch)], logits_t, 0, ch, ch, 1, 1, False, False))
 
     def pool(self, name, src_t):
         ch = self.tensors[src_t].channels
@@ -84,3 +89,74 @@ def view_tensor(plan, ws, name, b, h, w):
                                         ctypes.byref(th), ctypes.byref(tw)), 'pf_hardnet_tensor_view')
     n = b * c.value * th.value * tw.value
     return ws[off.value:off.value + 4 * n].view(torch.float32).view(b, c.value, th.value, tw.value)
+
+
+class MiniTrain:
+    """A hand-built op table through the training entry points (pf_train_*), dense input.  ``params``: {op name: dict(w=,
+    gamma=, beta=, mean=, var=) for conv+BN ops, dict(w=, b=) for plain convs} (CPU tensors)."""
+
+    def __init__(self, spec, params):
+        L = _lib.load()
+        dummy = {op.name: (torch.zeros(op.cout, op.cin, op.k, op.k), torch.zeros(op.cout)) for op in spec.conv_ops()}
+        blob = packing.pack_blob(None, spec.in_ch, spec.n_cls, spec=spec, params=dummy)
+        self._buf = ctypes.create_string_buffer(blob, len(blob))
+        self.t = ctypes.c_void_p()
+        _lib.check(L.pf_train_create(self._buf, len(blob), spec.in_ch, spec.n_cls, ctypes.byref(self.t)), 'pf_train_create')
+        n = ctypes.c_size_t()
+        _lib.check(L.pf_train_param_count(self.t, ctypes.byref(n)), 'pf_train_param_count')
+        self.spec = spec
+        host = torch.zeros(n.value)
+        self.slots = {}
+        for i, op in enumerate(spec.ops):
+            if op.kind not in (arch.OP_STEM, arch.OP_CONV):
+                continue
+            wo, ao, bn = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_int()
+            _lib.check(L.pf_train_param_layout(self.t, i, ctypes.byref(wo), ctypes.byref(ao), ctypes.byref(bn)), 'pf_train_param_layout')
+            assert bool(bn.value) == bool(op.bn)
+            pr = params[op.name]
+            nw = op.cout * op.cin * op.k * op.k
+            host[wo.value:wo.value + nw] = pr['w'].reshape(-1)
+            self.slots[op.name + '.w'] = (wo.value, (op.cout, op.cin, op.k, op.k))
+            names = ('gamma', 'beta', 'mean', 'var') if op.bn else ('b',)
+            for j, nm in enumerate(names):
+                host[ao.value + j * op.cout:ao.value + (j + 1) * op.cout] = pr[nm]
+                self.slots[op.name + '.' + nm] = (ao.value + j * op.cout, (op.cout,))
+        self.theta = host.cuda()
+        self.grad = torch.zeros_like(self.theta)
+
+    def step(self, x, labels, loss_scale=1.0):
+        L = _lib.load()
+        b, _, h, w = x.shape
+        oh, ow = labels.shape[-2:]
+        need = ctypes.c_size_t()
+        _lib.check(L.pf_train_workspace(self.t, b, h, w, oh, ow, ctypes.byref(need)), 'pf_train_workspace')
+        self.ws = torch.zeros(need.value, dtype=torch.uint8, device='cuda')
+        self.out3 = torch.zeros(3, dtype=torch.float64, device='cuda')
+        x, labels = x.contiguous(), labels.contiguous()
+        rc = L.pf_train_forward_backward(self.t, self.theta.data_ptr(), self.grad.data_ptr(), 0, None, 0, None, None, 0.0, 1.0, 1,
+                                         x.data_ptr(), b, h, w, labels.data_ptr(), int(labels.dtype == torch.int64), oh, ow, 255,
+                                         float(loss_scale), 0.1, 1e-5, 1, self.out3.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                                         _lib.stream_ptr())
+        _lib.check(rc, 'pf_train_forward_backward')
+        torch.cuda.synchronize()
+        self.dims = (b, h, w, oh, ow)
+        return float(self.out3[0] / self.out3[1])
+
+    def param(self, name, grad=False):
+        off, shape = self.slots[name]
+        n = 1
+        for d in shape:
+            n *= d
+        return (self.grad if grad else self.theta)[off:off + n].view(shape)
+
+    def tensor(self, name, grad=False):
+        L = _lib.load()
+        off, c, th, tw = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        b = self.dims[0]
+        _lib.check(L.pf_train_tensor_view(self.t, name.encode(), int(grad), *self.dims, ctypes.byref(off), ctypes.byref(c),
+                                          ctypes.byref(th), ctypes.byref(tw)), 'pf_train_tensor_view')
+        n = b * c.value * th.value * tw.value
+        return self.ws[off.value:off.value + 4 * n].view(torch.float32).view(b, c.value, th.value, tw.value)
+
+    def close(self):
+        _lib.load().pf_train_destroy(self.t)

@@ -1,0 +1,355 @@
+"""Scope row f4 on the device: ``pf_train_forward_backward`` / ``pf_sgd_step`` (through ``bg_train.BGTrainer``) and the
+autograd drop-in (``BGModel.loss`` in training mode) against the oracle's training step and against the reference's own
+two-batch run (fixture g6_train_64x128.npz).
+
+Tolerances: kernel-level parity (every op kind of the training path, a HarDBlock-shaped mini network, float64 autograd as
+the checker) is 1e-4 relative L2 per gradient tensor, 1e-5 on the loss.  The whole 70-layer network is compared with
+bars derived from fp32's own conditioning on this problem (see ``_oracle_grads``)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hardnet_ref
+from panoptic_forecasting_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+LOSS_REL = 1e-4
+# parameters after two clipped SGD steps: (relative size of the update, ~1e-2) x (gradient conditioning, _oracle_grads)
+POST_REL = 2e-3
+
+
+def _params(**training):
+    tr = {'lr': 2e-3, 'mom': 0.9, 'wd': 1e-4, 'clip_grad_norm': 5.0}
+    tr.update(training)
+    return {'task': 'bg', 'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])]},
+            'model': {'model_type': 'bg', 'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True}, 'training': tr}
+
+
+def _sd():
+    with open(os.path.join(G, 'calib_seed1234.json')) as f:
+        return synth.make_state_dict(seed=1234, calib=json.load(f))
+
+
+def _fixture():
+    z = np.load(os.path.join(G, 'g6_train_64x128.npz'))
+    batches = []
+    for s in range(2):
+        batches.append(({'seg': torch.from_numpy(z['seg'][s]).long(), 'depth': torch.from_numpy(z['depth'][s]),
+                         'depth_mask': torch.from_numpy(z['mask'][s])}, {'seg': torch.from_numpy(z['labels'][s]).long()}))
+    return z, batches
+
+
+def _cuda(d):
+    return {k: v.cuda() for k, v in d.items()}
+
+
+def _labels(b, h, w, seed):
+    g = torch.Generator().manual_seed(4000 + seed)
+    lab = torch.randint(0, 12, (b, max(h // 8, 1), max(w // 8, 1)), generator=g)
+    lab[lab == 11] = 255
+    return torch.nn.functional.interpolate(lab[:, None].float(), size=(h, w), mode='nearest')[:, 0].long()
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-12))
+
+
+def _oracle_grads(sd, inputs, labels):
+    """(fp64 gradients, fp32 result, per-key bar).  The gradient of this 70-layer ReLU network is ill-conditioned in fp32:
+    forward round-off (1e-7 after the first layer) grows ~1.3x per layer to 3e-5..1e-4 at the output, every pre-activation
+    closer to zero than that flips its ReLU mask between two fp32 implementations, and a flipped element changes the
+    gradient by its full value — relative gradient error ~ sqrt(relative forward error).  The reference's own ATen fp32
+    gradients are 5..8 % (rel. L2) away from the float64 gradients in the encoder at this size.  So the bar per tensor
+    is set by what fp32 can deliver here: 4x the distance fp32-ATen <-> float64, floor 3e-2.  Kernel-level parity
+    (1e-4) is test_mini_network_training_step_vs_autograd."""
+    r32 = hardnet_ref.bg_train_step({k: v.clone() for k, v in sd.items()}, inputs, labels, clip_grad_norm=None, apply_update=False)
+    sd64 = {k: (v.double() if v.dtype == torch.float32 else v.clone()) for k, v in sd.items()}
+    in64 = dict(inputs)
+    in64['depth'] = inputs['depth'].double()
+    r64 = hardnet_ref.bg_train_step(sd64, in64, labels, clip_grad_norm=None, apply_update=False)
+    bars = {k: max(4 * _rel(r32['grads'][k], g), 3e-2) for k, g in r64['grads'].items()}
+    return r64['grads'], r32, bars, sd64
+
+
+@pytest.mark.parametrize('size', [(64, 128), (128, 256)])
+def test_forward_backward_vs_oracle(size):
+    from panoptic_forecasting_amd.bg_train import BGTrainer
+    h, w = size
+    sd = _sd()
+    if size == (64, 128):
+        z, batches = _fixture()
+        inputs, labels = batches[0]
+    else:
+        inputs = synth.make_bg_inputs(b=2, h=h, w=w, seed=21)
+        labels = {'seg': _labels(2, h, w, 5)}
+    tr = BGTrainer(_params())
+    tr.load_state_dict(sd)
+    out = tr.forward_backward(_cuda(inputs), _cuda(labels))
+    g64, ref, bars, sd64 = _oracle_grads(sd, inputs, labels)
+    assert abs(float(out['loss']) - float(ref['loss'])) <= LOSS_REL * abs(float(ref['loss']))
+    assert abs(float(out['accuracy']) - float(ref['accuracy'])) <= 2e-4        # an argmax near-tie may flip a pixel
+    got = tr.named_grads()
+    for k, g in g64.items():
+        assert _rel(got[k].cpu(), g) <= bars[k], (k, _rel(got[k].cpu(), g), bars[k])
+    # the last block is well conditioned at the level of the head: tight bar there
+    for k in ('model.finalConv.weight', 'model.finalConv.bias', 'model.denseBlocksUp.3.layers.3.norm.weight'):
+        assert _rel(got[k].cpu(), g64[k]) <= 2e-4, k
+    # running statistics were updated in theta (momentum 0.1, unbiased variance); sd64 holds the float64 oracle's
+    post = tr.state_dict()
+    for k in sd64:
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            assert torch.allclose(post[k].double(), sd64[k], rtol=2e-3, atol=1e-4), k
+    if size == (64, 128):      # and against the reference's own numbers (clipped by 5 / (norm + 1e-6))
+        assert abs(float(out['loss']) - z['loss'][0]) <= LOSS_REL * z['loss'][0]
+        coef = min(1.0, 5.0 / (z['grad_norm'][0] + 1e-6))
+        for name in z.files:
+            if name.startswith('grad::'):
+                assert _rel(got[name[6:]].cpu() * coef, torch.from_numpy(z[name])) <= 2 * bars[name[6:]], name
+
+
+def test_two_training_steps_vs_reference_fixture():
+    """train_step x2 with the values of configs/bg/bg_train.yaml: parameters, momentum and running statistics after the
+    second step against the reference loop's (the clip / weight decay / momentum arithmetic of pf_sgd_step included)."""
+    from panoptic_forecasting_amd.bg_train import BGTrainer
+    z, batches = _fixture()
+    tr = BGTrainer(_params())
+    tr.load_state_dict(_sd())
+    for s, (inputs, labels) in enumerate(batches):
+        out = tr.train_step(_cuda(inputs), _cuda(labels))
+        assert abs(float(out['loss']) - z['loss'][s]) <= (LOSS_REL if s == 0 else 1e-3) * z['loss'][s]
+    post = tr.state_dict()
+    keys = [str(k) for k in z['post_keys']]
+    l2 = np.array([float(post[k].double().norm()) for k in keys])
+    assert np.all(np.abs(l2 - z['post_l2']) <= POST_REL * z['post_l2'] + 1e-6)
+    for name in z.files:
+        if name.startswith('post::'):
+            ref = torch.from_numpy(z[name])
+            assert _rel(post[name[6:]], ref) <= POST_REL, name
+    assert int(post['model.base.0.norm.num_batches_tracked']) == 2
+
+
+def test_gradient_accumulation_and_loss_scale():
+    from panoptic_forecasting_amd.bg_train import BGTrainer
+    z, batches = _fixture()
+    tr = BGTrainer(_params())
+    tr.load_state_dict(_sd())
+    a_in, a_lab = (_cuda(d) for d in batches[0])
+    b_in, b_lab = (_cuda(d) for d in batches[1])
+    tr.forward_backward(a_in, a_lab, update_running_stats=False)
+    ga = tr.grad.clone()
+    tr.forward_backward(b_in, b_lab, update_running_stats=False)
+    gb = tr.grad.clone()
+    tr.forward_backward(a_in, a_lab, update_running_stats=False, loss_scale=0.5)
+    tr.forward_backward(b_in, b_lab, accumulate=True, update_running_stats=False, loss_scale=0.5)
+    assert _rel(tr.grad, 0.5 * (ga + gb)) <= 1e-5
+    # bit-reproducible: every reduction runs in a fixed order
+    tr.forward_backward(a_in, a_lab, update_running_stats=False)
+    assert torch.equal(tr.grad, ga)
+
+
+@pytest.mark.parametrize('clip', ['norm', 'value', 'none'])
+def test_sgd_step_vs_torch(clip):
+    import ctypes
+    from panoptic_forecasting_amd import lib as _lib
+    L = _lib.load()
+    n = 100003
+    g = torch.Generator().manual_seed(3)
+    theta = torch.randn(n, generator=g)
+    mask = torch.rand(n, generator=g) < 0.9
+    need = ctypes.c_size_t()
+    _lib.check(L.pf_sgd_workspace(ctypes.byref(need)), 'pf_sgd_workspace')
+    ws = torch.empty(need.value, dtype=torch.uint8, device='cuda')
+    p_ref = torch.nn.Parameter(theta[mask].clone())
+    opt = torch.optim.SGD([p_ref], lr=0.05, momentum=0.9, weight_decay=1e-2)
+    d_theta, d_mom = theta.cuda(), torch.zeros(n, device='cuda')
+    d_mask = mask.to(torch.uint8).cuda()
+    for step in range(3):
+        grad = torch.randn(n, generator=g) * 3
+        p_ref.grad = grad[mask].clone()
+        if clip == 'norm':
+            torch.nn.utils.clip_grad_norm_([p_ref], 5.0)
+        elif clip == 'value':
+            torch.nn.utils.clip_grad_value_([p_ref], 0.7)
+        opt.step()
+        d_grad = grad.cuda()
+        _lib.check(L.pf_sgd_step(d_theta.data_ptr(), d_grad.data_ptr(), d_mom.data_ptr(), d_mask.data_ptr(), n, 0.05, 0.9, 1e-2,
+                                 5.0 if clip == 'norm' else 0.0, 0.7 if clip == 'value' else 0.0, int(step == 0), ws.data_ptr(),
+                                 ws.numel(), _lib.stream_ptr()), 'pf_sgd_step')
+        assert torch.allclose(d_theta.cpu()[mask], p_ref.detach(), rtol=1e-5, atol=1e-6)
+        assert torch.equal(d_theta.cpu()[~mask], theta[~mask])            # buffers (running statistics) are not stepped
+
+
+def test_bgmodel_training_loss_is_a_drop_in_for_the_reference_loop():
+    """train.py:186-210 verbatim on the registry's model: model.train(); loss = model.loss(...)['loss']; loss.backward();
+    clip_grad_norm_; torch.optim.SGD.step() — then eval-mode predict on the updated parameters."""
+    from panoptic_forecasting_amd.registry import build_model
+    z, batches = _fixture()
+    sd = _sd()
+    m = build_model(_params())
+    m.load_state_dict(sd)
+    m.cuda()
+    model_params = [p for p in m.parameters() if p.requires_grad]
+    assert len(model_params) == len(hardnet_ref.trainable_keys(sd))
+    opt = torch.optim.SGD(model_params, lr=2e-3, weight_decay=1e-4, momentum=0.9)
+    osd = {k: v.clone() for k, v in sd.items()}
+    bufs = None
+    for s, (inputs, labels) in enumerate(batches):
+        m.train()
+        res = m.loss(_cuda(inputs), _cuda(labels))
+        loss = res['loss'].mean() / 1
+        loss.backward()
+        total = torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+        if s == 0:
+            assert abs(float(total) - z['grad_norm'][0]) <= 0.1 * z['grad_norm'][0]      # see _oracle_grads on conditioning
+            grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+            bars = _oracle_grads(sd, inputs, labels)[2]
+            for name in z.files:
+                if name.startswith('grad::'):
+                    assert _rel(grads[name[6:]].cpu(), torch.from_numpy(z[name])) <= 2 * bars[name[6:]], name
+        opt.step()
+        opt.zero_grad()
+        ref = hardnet_ref.bg_train_step(osd, inputs, labels, momentum_bufs=bufs)
+        bufs = ref['momentum_bufs']
+        assert abs(float(res['loss']) - float(ref['loss'])) <= 1e-3 * float(ref['loss'])
+    post = m.state_dict()
+    assert set(post.keys()) == set(sd.keys())
+    for name in z.files:
+        if name.startswith('post::'):
+            assert _rel(post[name[6:]].cpu(), torch.from_numpy(z[name])) <= 1e-4, name
+    # the inference plan is rebuilt from the trained parameters
+    m.eval()
+    inp = synth.make_bg_inputs(b=1, h=64, w=128, seed=3)
+    out = m.predict(_cuda(inp), None)
+    want = hardnet_ref.bg_predict({k: v.cpu() for k, v in post.items()}, inp)
+    assert (out['orig_size_logits'].cpu() - want['orig_size_logits']).abs().max() <= 1e-3
+
+
+def _mini_net():
+    """Every op kind of the training path in one small, well-conditioned network: stride-2 stem, 3x3 convs with one and
+    two input ranges, a conv writing into a slice of a wider tensor, 1x1 conv, pool, upsample + 1x1 over [up, skip],
+    plain final conv, bilinear head."""
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    from tests.helpers import MiniSpec
+    sp = MiniSpec(6)
+    S = arch.Src
+    c0 = sp.conv('c0', [S(0, 0, 6)], 16, 3, stride=2, bn=True)
+    c1 = sp.conv('c1', [S(c0, 0, 16)], 24, 3, bn=True)
+    cat = sp.tensor('cat', 28 + 10 + 12)
+    sp.conv('c2', [S(c1, 0, 24), S(c0, 0, 16)], 28, 3, dst=cat, dst_choff=10, bn=True)
+    sp.conv('c2b', [S(c1, 4, 18)], 10, 3, dst=cat, dst_choff=0, bn=True)
+    # like the last layer of a HarDBlock: three ranges, the first one a slice of the tensor it writes into
+    sp.conv('c2c', [S(cat, 0, 10), S(c1, 0, 24), S(c0, 0, 16)], 12, 3, dst=cat, dst_choff=38, bn=True)
+    c3 = sp.conv('c3', [S(cat, 0, 50)], 20, 1, bn=True)
+    p = sp.pool('p', c3)
+    c4 = sp.conv('c4', [S(p, 0, 20)], 34, 3, bn=True)
+    up = sp.upsample('up', c4, c3)
+    c5 = sp.conv('c5', [S(up, 0, 34), S(c3, 0, 20)], 22, 1, bn=True)
+    fin = sp.conv('fin', [S(c5, 0, 22), S(cat, 10, 28)], 11, 1, relu=False, bn=False)
+    sp.head(fin)
+    return sp
+
+
+def _mini_torch(sp, params, x, labels):
+    """The same op table through torch autograd (float64 checker), with gradients of every tensor retained."""
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    import torch.nn.functional as F
+    leaves = {n: {k: v.double().clone().requires_grad_(k in ('w', 'gamma', 'beta', 'b')) for k, v in pr.items()} for n, pr in params.items()}
+    parts = {}           # tensor index -> {choff: produced slice}
+    whole = {0: x.double()}
+    kept = {}
+
+    def get(src):
+        if src.tensor in whole:
+            return whole[src.tensor][:, src.choff:src.choff + src.ch]
+        pr = parts[src.tensor]
+        if src.choff in pr and pr[src.choff].shape[1] == src.ch and sum(p.shape[1] for p in pr.values()) < sp.tensors[src.tensor].channels:
+            return pr[src.choff]                       # a slice read while the tensor is still being filled
+        t = torch.cat([pr[k] for k in sorted(pr)], 1)
+        assert t.shape[1] == sp.tensors[src.tensor].channels
+        whole[src.tensor] = t
+        return t[:, src.choff:src.choff + src.ch]
+
+    logits = None
+    for op in sp.ops:
+        if op.kind in (arch.OP_STEM, arch.OP_CONV):
+            xin = torch.cat([get(s) for s in op.srcs], 1)
+            pr = leaves[op.name]
+            y = F.conv2d(xin, pr['w'], None if op.bn else pr['b'], stride=op.stride, padding=op.k // 2)
+            if op.bn:
+                y = F.batch_norm(y, pr['mean'], pr['var'], pr['gamma'], pr['beta'], training=True, momentum=0.1, eps=1e-5)
+            if op.relu:
+                y = F.relu(y)
+            if op.cout == sp.tensors[op.dst].channels:
+                y.retain_grad()
+                whole[op.dst] = y
+                kept[sp.tensors[op.dst].name] = y
+            else:
+                y.retain_grad()
+                parts.setdefault(op.dst, {})[op.dst_choff] = y
+                kept['%s@%d' % (sp.tensors[op.dst].name, op.dst_choff)] = y
+        elif op.kind == arch.OP_POOL:
+            whole[op.dst] = F.avg_pool2d(get(op.srcs[0]), 2, 2)
+            whole[op.dst].retain_grad()
+            kept[sp.tensors[op.dst].name] = whole[op.dst]
+        elif op.kind == arch.OP_UPSAMPLE:
+            like = get(op.srcs[1])
+            whole[op.dst] = F.interpolate(get(op.srcs[0]), size=like.shape[-2:], mode='bilinear', align_corners=True)
+            whole[op.dst].retain_grad()
+            kept[sp.tensors[op.dst].name] = whole[op.dst]
+        else:
+            logits = get(op.srcs[0])
+    full = F.interpolate(logits, size=labels.shape[-2:], mode='bilinear', align_corners=True)
+    loss = F.cross_entropy(full, labels.long(), ignore_index=255)
+    loss.backward()
+    return float(loss), leaves, kept
+
+
+@pytest.mark.parametrize('size', [(24, 40), (34, 70)])
+def test_mini_network_training_step_vs_autograd(size):
+    from tests.helpers import MiniTrain
+    h, w = size
+    sp = _mini_net()
+    g = torch.Generator().manual_seed(17)
+    params = {}
+    for op in sp.conv_ops():
+        pr = {'w': torch.randn(op.cout, op.cin, op.k, op.k, generator=g) * (2.0 / (op.cin * op.k * op.k)) ** 0.5}
+        if op.bn:
+            pr.update(gamma=torch.rand(op.cout, generator=g) + 0.5, beta=torch.randn(op.cout, generator=g) * 0.2,
+                      mean=torch.zeros(op.cout), var=torch.ones(op.cout))
+        else:
+            pr['b'] = torch.randn(op.cout, generator=g) * 0.1
+        params[op.name] = pr
+    x = torch.randn(3, 6, h, w, generator=g)
+    lab = torch.randint(0, 12, (3, 2 * h - 3, 2 * w + 1), generator=g)
+    lab[lab == 11] = 255
+    want_loss, leaves, kept = _mini_torch(sp, params, x, lab)
+    net = MiniTrain(sp, params)
+    got_loss = net.step(x.cuda(), lab.cuda())
+    assert abs(got_loss - want_loss) <= 1e-5 * abs(want_loss)
+    bad = []
+    for name, t in kept.items():
+        if name == 'input' or t.grad is None:
+            continue
+        tname, _, choff = name.partition('@')           # 'cat@10' = the slice of tensor 'cat' one op produced
+        sl = slice(int(choff or 0), int(choff or 0) + t.shape[1])
+        a, ga = net.tensor(tname).cpu().double()[:, sl], net.tensor(tname, grad=True).cpu().double()[:, sl]
+        if _rel(a, t.detach()) > 1e-5:
+            bad.append(('act ' + name, _rel(a, t.detach())))
+        if _rel(ga, t.grad) > 1e-4:
+            bad.append(('grad ' + name, _rel(ga, t.grad)))
+    for op in sp.conv_ops():
+        for nm in (('w', 'gamma', 'beta') if op.bn else ('w', 'b')):
+            r = _rel(net.param('%s.%s' % (op.name, nm), grad=True).cpu(), leaves[op.name][nm].grad)
+            if r > 1e-4:
+                bad.append(('d%s %s' % (nm, op.name), r))
+        if op.bn:      # running statistics (momentum 0.1, unbiased variance)
+            for nm in ('mean', 'var'):
+                r = _rel(net.param('%s.%s' % (op.name, nm)).cpu(), leaves[op.name][nm])
+                if r > 1e-5:
+                    bad.append(('running %s %s' % (nm, op.name), r))
+    net.close()
+    assert not bad, bad
