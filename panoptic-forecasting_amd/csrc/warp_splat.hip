@@ -44,8 +44,11 @@ constexpr unsigned long long kEmpty = ~0ull;
 constexpr int kThreads = 256;
 constexpr int kSrcTH = 16, kSrcTW = 64;   // source tile (pixels); 256 threads x 4 consecutive pixels
 constexpr int kDstTH = 32, kDstTW = 128;  // destination tile owned by one raster workgroup (32 KB LDS)
-constexpr int kScan = 256;                // bounding boxes tested per thread-pass
+constexpr int kScan = 256;                // bounding boxes tested per thread-pass (overflow path only)
 constexpr int kScanBatches = 8;           // passes per list fill (list holds kScan * kScanBatches tile ids)
+constexpr int kListCap = 64;              // source-tile ids per destination-tile list written by bin_kernel (typical fill 6-12)
+constexpr int kFlight = 8;                // source tiles whose projections a raster workgroup keeps in flight
+constexpr int kIdFrameShift = 20;         // list entry = (frame inside the z-buffer group) << 20 | source tile
 constexpr int kZSlots = 64;               // atomicMax slots per z-buffer group (spreads the memory-side atomics)
 
 struct SplatArgs {
@@ -57,6 +60,8 @@ struct SplatArgs {
     unsigned *zmax_part;  // [G][kZSlots]       order-preserving u32 of max(z) per z-buffer group (atomicMax, zeroed per call)
     uint8_t *inv_mark;    // [B*G][N]           1 where an invalid point lands
     uint2 *proj;          // [B][T][N]          {bits(z), x0 | y0<<13 | (x1!=x0)<<26 | (y1!=y0)<<27 | valid<<28}
+    unsigned *count;      // [B][G][dst tiles]  fill of the destination tile's list (zeroed per call; > kListCap = overflowed)
+    unsigned *lists;      // [B][G][dst tiles][kListCap]  source tiles whose valid points can reach the destination tile
     uint8_t *out_seg;
     float *out_depth;
     long long *out_r2d;
@@ -65,6 +70,7 @@ struct SplatArgs {
     int stx, sty;         // source tiles per row / column
     int dtx, dty;         // destination tiles per row / column
     long long *probe;     // PF_PROBE builds only
+    int exp;              // PF_SPLAT_EXP experiment mask (tools/bench_splat.py): timing only, results are wrong when set
 };
 
 __device__ __forceinline__ unsigned float_to_ordered(float f) {
@@ -94,6 +100,7 @@ __device__ __forceinline__ float dot4(const float *m, float a, float b, float c,
 
 struct Camera {
     float Kinv[9], E[16], Tm[16], Einv[16], K[9];
+    bool affine;   // uniform: K^-1 and K end in (0,0,1); E, T, E^-1 end in (0,0,0,1)
 };
 
 __device__ __forceinline__ void load_camera(const SplatArgs &a, int b, int t, Camera &c) {
@@ -108,6 +115,18 @@ __device__ __forceinline__ void load_camera(const SplatArgs &a, int b, int t, Ca
         c.Einv[i] = a.Einv[b * 16 + i];
         c.Tm[i] = a.Tt[((long long)b * a.T_total + t) * 16 + i];
     }
+    // combined without short-circuit: an && chain over loaded values compiles to dependent scalar-load round trips
+    int ok = 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ok &= (int)(c.Kinv[6 + i] == (i == 2 ? 1.0f : 0.0f)) & (int)(c.K[6 + i] == (i == 2 ? 1.0f : 0.0f));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float want = i == 3 ? 1.0f : 0.0f;
+        ok &= (int)(c.E[12 + i] == want) & (int)(c.Tm[12 + i] == want) & (int)(c.Einv[12 + i] == want);
+    }
+    c.affine = ok != 0;
 }
 
 struct Proj {
@@ -140,6 +159,73 @@ __device__ __forceinline__ Proj project(const Camera &c, int x, int y, float d, 
     p.y0 = (int)fminf(fmaxf(floorf(vv), 0.0f), Hf - 1.0f);
     p.y1 = (int)fminf(fmaxf(ceilf(vv), 0.0f), Hf - 1.0f);
     return p;
+}
+
+// ---- the same chain for four consecutive pixels of a row on the packed fp32 pipe, for `affine` cameras.
+// v_pk_mul_f32 / v_pk_add_f32 perform two separately rounded IEEE operations per lane per issue: same results as the
+// scalar chain at half the issues (bin_kernel is bound by the vector ALU: 256 instructions per point in the scalar form,
+// profiles/r02_a_pmc.json).  Every product and sum below is one IEEE operation per element in the order of dot3/dot4
+// (this file is built with -ffp-contract=off).  What is left out is exact:  m*1.0f == m;  with a last row (0,0,1) /
+// (0,0,0,1) the homogeneous component is (((0 + 0*a) + 0*b) + 0*c) + 1*1 == 1 whenever a, b, c are finite (0*finite =
+// +-0, +-0 + 1 = 1), and x / 1.0f == x.  If a, b or c is NOT finite the reference gets NaN there; then every component
+// downstream is non-finite too (inf or NaN times any matrix entry, zero included, is inf or NaN, and sums keep it), so
+// "e0, e1, e2 all finite" proves the shortcut was exact; anything else takes the full chain.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_dot2c(const float *m, f32x2 a, f32x2 b) {       // ((0 + m0*a) + m1*b) + m2*1
+    f32x2 acc = f32x2{0.0f, 0.0f} + f32x2{m[0], m[0]} * a;
+    acc = acc + f32x2{m[1], m[1]} * b;
+    return acc + f32x2{m[2], m[2]};
+}
+__device__ __forceinline__ f32x2 pk_dot3c(const float *m, f32x2 a, f32x2 b, f32x2 c) {   // dot4 with a trailing 1
+    f32x2 acc = f32x2{0.0f, 0.0f} + f32x2{m[0], m[0]} * a;
+    acc = acc + f32x2{m[1], m[1]} * b;
+    acc = acc + f32x2{m[2], m[2]} * c;
+    return acc + f32x2{m[3], m[3]};
+}
+__device__ __forceinline__ f32x2 pk_dot3(const float *m, f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 acc = f32x2{0.0f, 0.0f} + f32x2{m[0], m[0]} * a;
+    acc = acc + f32x2{m[1], m[1]} * b;
+    return acc + f32x2{m[2], m[2]} * c;
+}
+__device__ __forceinline__ bool finite2(f32x2 a) { return __builtin_isfinite(a.x) && __builtin_isfinite(a.y); }
+
+// :83-89 validity and :106-114 floor/ceil then clamp
+__device__ __forceinline__ Proj finish(float uu, float vv, float z, bool m, float Wf, float Hf) {
+    Proj p;
+    p.z = z;
+    const bool inb = (uu >= 0.0f) && (uu < Wf) && (vv >= 0.0f) && (vv < Hf);
+    p.valid = m && (z > 0.0f) && inb;
+    p.x0 = (int)fminf(fmaxf(floorf(uu), 0.0f), Wf - 1.0f);
+    p.x1 = (int)fminf(fmaxf(ceilf(uu), 0.0f), Wf - 1.0f);
+    p.y0 = (int)fminf(fmaxf(floorf(vv), 0.0f), Hf - 1.0f);
+    p.y1 = (int)fminf(fmaxf(ceilf(vv), 0.0f), Hf - 1.0f);
+    return p;
+}
+
+__device__ __forceinline__ bool project4_fast(const Camera &c, int x, int y, const float (&d)[4], const bool (&m)[4], float Wf, float Hf,
+                                              Proj (&p)[4]) {
+    const f32x2 v = f32x2{(float)y, (float)y};
+    const f32x2 ua = f32x2{(float)x, (float)(x + 1)}, ub = f32x2{(float)(x + 2), (float)(x + 3)};
+    const f32x2 da = f32x2{d[0], d[1]}, db = f32x2{d[2], d[3]};
+    const f32x2 r0a = pk_dot2c(c.Kinv + 0, ua, v), r0b = pk_dot2c(c.Kinv + 0, ub, v);
+    const f32x2 r1a = pk_dot2c(c.Kinv + 3, ua, v), r1b = pk_dot2c(c.Kinv + 3, ub, v);
+    const f32x2 c0a = r0a * da, c1a = r1a * da, c0b = r0b * db, c1b = r1b * db;                   // r2 == 1: c2 = d
+    f32x2 va[3], vb[3], wa[3], wb[3], ea[3], eb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { va[i] = pk_dot3c(c.E + 4 * i, c0a, c1a, da); vb[i] = pk_dot3c(c.E + 4 * i, c0b, c1b, db); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { wa[i] = pk_dot3c(c.Tm + 4 * i, va[0], va[1], va[2]); wb[i] = pk_dot3c(c.Tm + 4 * i, vb[0], vb[1], vb[2]); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ea[i] = pk_dot3c(c.Einv + 4 * i, wa[0], wa[1], wa[2]); eb[i] = pk_dot3c(c.Einv + 4 * i, wb[0], wb[1], wb[2]); }
+    if (!(finite2(ea[0]) && finite2(ea[1]) && finite2(ea[2]) && finite2(eb[0]) && finite2(eb[1]) && finite2(eb[2]))) return false;
+    // e3 == 1: px = e0, py = e1, z = e2;  q2 == z
+    const f32x2 q0a = pk_dot3(c.K + 0, ea[0], ea[1], ea[2]), q0b = pk_dot3(c.K + 0, eb[0], eb[1], eb[2]);
+    const f32x2 q1a = pk_dot3(c.K + 3, ea[0], ea[1], ea[2]), q1b = pk_dot3(c.K + 3, eb[0], eb[1], eb[2]);
+    p[0] = finish(__fdiv_rn(q0a.x, ea[2].x), __fdiv_rn(q1a.x, ea[2].x), ea[2].x, m[0], Wf, Hf);
+    p[1] = finish(__fdiv_rn(q0a.y, ea[2].y), __fdiv_rn(q1a.y, ea[2].y), ea[2].y, m[1], Wf, Hf);
+    p[2] = finish(__fdiv_rn(q0b.x, eb[2].x), __fdiv_rn(q1b.x, eb[2].x), eb[2].x, m[2], Wf, Hf);
+    p[3] = finish(__fdiv_rn(q0b.y, eb[2].y), __fdiv_rn(q1b.y, eb[2].y), eb[2].y, m[3], Wf, Hf);
+    return true;
 }
 
 // 4 consecutive pixels of a row (x multiple of 4): vector loads when the row allows it
@@ -183,10 +269,18 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
         load4(a, in_base, x, y, d, m);
         uint2 *pj = a.proj + ((long long)b * a.T + tl) * N + (long long)y * a.W + x;
         unsigned pk[8];
+        Proj p4[4];
+        if (a.exp & 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { p4[k].z = d[k]; p4[k].x0 = p4[k].x1 = min(x + k, a.W - 1); p4[k].y0 = p4[k].y1 = y; p4[k].valid = m[k]; }
+        } else if (!(cam.affine && project4_fast(cam, x, y, d, m, Wf, Hf, p4))) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p4[k] = project(cam, x + k, y, d[k], m[k], Wf, Hf);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (x + k >= a.W) break;
-            const Proj p = project(cam, x + k, y, d[k], m[k], Wf, Hf);
+            const Proj p = p4[k];
             zmax = fmaxf(zmax, p.z);   // :105 max runs over valid and invalid points alike
             pk[2 * k] = __float_as_uint(p.z);
             pk[2 * k + 1] = (unsigned)p.x0 | ((unsigned)p.y0 << 13) | ((unsigned)(p.x1 != p.x0) << 26) |
@@ -200,7 +294,7 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
             if (p.valid) {
                 bx0 = min(bx0, p.x0); by0 = min(by0, p.y0);
                 bx1 = max(bx1, p.x1); by1 = max(by1, p.y1);
-            } else {
+            } else if (!(a.exp & 1)) {
                 // every invalid point carries depth max+1 and payload 0: marking its bins is enough
                 mark[(long long)p.y0 * a.W + p.x0] = 1;
                 mark[(long long)p.y1 * a.W + p.x0] = 1;
@@ -208,7 +302,7 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
                 mark[(long long)p.y1 * a.W + p.x1] = 1;
             }
         }
-        if ((a.W & 3) == 0) {   // the raster pass re-reads these instead of re-projecting (coalesced 32 B per thread)
+        if ((a.W & 3) == 0 && !(a.exp & 16)) {   // the raster pass re-reads these instead of re-projecting (coalesced 32 B per thread)
             reinterpret_cast<uint4 *>(pj)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             reinterpret_cast<uint4 *>(pj)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
         }
@@ -228,18 +322,32 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
         bred[w][0] = bx0; bred[w][1] = by0; bred[w][2] = bx1; bred[w][3] = by1;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
 #pragma unroll
-        for (int w = 1; w < kThreads / 64; ++w) {
-            zmax = fmaxf(zmax, zred[w]);
-            bx0 = min(bx0, bred[w][0]); by0 = min(by0, bred[w][1]);
-            bx1 = max(bx1, bred[w][2]); by1 = max(by1, bred[w][3]);
-        }
+    for (int w = 0; w < kThreads / 64; ++w) {
+        zmax = fmaxf(zmax, zred[w]);
+        bx0 = min(bx0, bred[w][0]); by0 = min(by0, bred[w][1]);
+        bx1 = max(bx1, bred[w][2]); by1 = max(by1, bred[w][3]);
+    }
+    if (threadIdx.x == 0) {
         const long long ntile = (long long)a.stx * a.sty;
         // :105 the sentinel is max(z)+1 over the whole predict call (one frame's points in per_frame mode): one
         // order-independent atomicMax per source tile instead of every raster workgroup re-reducing all partials
         atomicMax(&a.zmax_part[(b * a.zgroups_per_sample + (a.per_frame ? tl : 0)) * kZSlots + ((tile + b) & (kZSlots - 1))], float_to_ordered(zmax));
         a.bbox[((long long)b * a.T + tl) * ntile + tile] = make_int4(bx0, by0, bx1, by1);
+    }
+    // register this tile with every destination tile its box touches (one global atomicAdd per pair, ~1.5 per tile): the
+    // raster workgroups then read their list instead of testing every box of the frame
+    if (bx1 >= 0) {
+        const int ndst = a.dtx * a.dty;
+        const long long dbase = ((long long)b * G + g) * ndst;
+        const unsigned id = ((unsigned)(a.per_frame ? 0 : tl) << kIdFrameShift) | (unsigned)tile;
+        const int dtx0 = bx0 / kDstTW, dty0 = by0 / kDstTH;
+        const int ntx = bx1 / kDstTW - dtx0 + 1, nt = ntx * (by1 / kDstTH - dty0 + 1);
+        for (int j = threadIdx.x; j < nt; j += kThreads) {
+            const long long dst = dbase + (dty0 + j / ntx) * a.dtx + dtx0 + j % ntx;
+            const unsigned slot = atomicAdd(&a.count[dst], 1u);
+            if (slot < (unsigned)kListCap) a.lists[dst * kListCap + slot] = id;
+        }
     }
 }
 
@@ -247,6 +355,7 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
 __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
     __shared__ unsigned long long zb[kDstTH * kDstTW];   // 16 KB
     __shared__ unsigned short list[kScan * kScanBatches];
+    __shared__ unsigned ent[kListCap];
     __shared__ int list_n;
     __shared__ float sentinel_s;
 
@@ -312,6 +421,30 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
             }
         }
     };
+    // ---- the destination tile's list (written by bin_kernel): kFlight source tiles' records in flight at a time
+    const int ndst = a.dtx * a.dty;
+    const long long dslot = ((long long)b * G + g) * ndst + dtile;
+    const unsigned cnt = a.count[dslot];
+    if (cnt <= (unsigned)kListCap) {
+        if (threadIdx.x < cnt) ent[threadIdx.x] = a.lists[dslot * kListCap + threadIdx.x];
+        __syncthreads();
+        for (int li = 0; li < (int)cnt; li += kFlight) {
+            unsigned pk[kFlight][8];
+            int xs[kFlight], ys[kFlight];
+            unsigned long long eb[kFlight];
+#pragma unroll
+            for (int j = 0; j < kFlight; ++j) {
+                const unsigned e = li + j < (int)cnt ? ent[li + j] : 0u;
+                const int tt = (int)(e >> kIdFrameShift), st = li + j < (int)cnt ? (int)(e & ((1u << kIdFrameShift) - 1u)) : -1;
+                const int tl = a.per_frame ? g : tt;
+                eb[j] = (unsigned long long)tt * N;
+                load4(a.proj + ((long long)b * a.T + tl) * N, st, pk[j], xs[j], ys[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < kFlight; ++j) splat4(pk[j], xs[j], ys[j], eb[j]);
+        }
+    } else {
+    // the list overflowed: test every box of the group's frames (the path every call took before the lists existed)
     for (int tt = 0; tt < Tg; ++tt) {
         const int tl = a.per_frame ? g : tt;     // local frame index
         const int4 *boxes = a.bbox + ((long long)b * a.T + tl) * ntile;
@@ -342,6 +475,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
                 for (int j = 0; j < 4; ++j) splat4(pk[j], xs[j], ys[j], ebase);
             }
         }
+    }
     }
     __syncthreads();
     RPROBE(1);
@@ -409,7 +543,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
 }
 
 struct SplatLayout {
-    size_t bbox_off, zmax_off, mark_off, mark_bytes, proj_off, total;
+    size_t bbox_off, zmax_off, count_off, mark_off, mark_bytes, proj_off, lists_off, total;
     int stx, sty, dtx, dty;
 };
 
@@ -420,10 +554,14 @@ static SplatLayout splat_layout(int B, int T, int H, int W, int per_frame) {
     const size_t ntile = (size_t)L.stx * L.sty, N = (size_t)H * W;
     L.bbox_off = 0;
     L.zmax_off = align_up(L.bbox_off + (size_t)B * T * ntile * sizeof(int4), 256);
-    L.mark_off = align_up(L.zmax_off + (size_t)B * T * kZSlots * sizeof(unsigned), 256);   // zmax slots sit right before the marks: one memset
-    L.mark_bytes = (size_t)B * (per_frame ? T : 1) * N;
+    // zmax slots, list counters and marks are contiguous: one memset per call
+    const size_t ndst = (size_t)L.dtx * L.dty, G = per_frame ? T : 1;
+    L.count_off = align_up(L.zmax_off + (size_t)B * T * kZSlots * sizeof(unsigned), 256);
+    L.mark_off = align_up(L.count_off + B * G * ndst * sizeof(unsigned), 256);
+    L.mark_bytes = (size_t)B * G * N;
     L.proj_off = align_up(L.mark_off + L.mark_bytes, 256);
-    L.total = align_up(L.proj_off + (size_t)B * T * N * sizeof(uint2), 256);
+    L.lists_off = align_up(L.proj_off + (size_t)B * T * N * sizeof(uint2), 256);
+    L.total = align_up(L.lists_off + B * G * ndst * kListCap * sizeof(unsigned), 256);
     return L;
 }
 
@@ -434,8 +572,8 @@ extern "C" int pf_warp_splat_workspace(int B, int T, int H, int W, int per_frame
         return pf::fail(PF_EINVAL, "pf_warp_splat_workspace: bad dims B=%d T=%d H=%d W=%d", B, T, H, W);
     if (4ll * T * H * W >= (1ll << 32))
         return pf::fail(PF_EUNSUPPORTED, "pf_warp_splat: 4*T*H*W must be < 2^32 (element index packs in 32 bits)");
-    if (H > 8192 || W > 8192)
-        return pf::fail(PF_EUNSUPPORTED, "pf_warp_splat: H and W must be <= 8192 (13-bit bin coordinates)");
+    if (H > 8192 || W > 8192 || T >= 4096)
+        return pf::fail(PF_EUNSUPPORTED, "pf_warp_splat: H and W must be <= 8192 (13-bit bin coordinates) and T < 4096");
     *bytes = pf::splat_layout(B, T, H, W, per_frame & PF_SPLAT_PER_FRAME).total;
     return PF_OK;
 }
@@ -466,6 +604,8 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     a.zmax_part = (unsigned *)((char *)ws + L.zmax_off);
     a.inv_mark = (uint8_t *)ws + L.mark_off;
     a.proj = (uint2 *)((char *)ws + L.proj_off);
+    a.count = (unsigned *)((char *)ws + L.count_off);
+    a.lists = (unsigned *)((char *)ws + L.lists_off);
     a.out_seg = out_seg; a.out_depth = out_depth; a.out_r2d = (long long *)out_result2d;
     a.B = B; a.T_total = T_total; a.t_first = t_first; a.T = T; a.H = H; a.W = W; a.C = seg_channels;
     a.per_frame = (per_frame & PF_SPLAT_PER_FRAME) ? 1 : 0;
@@ -475,6 +615,8 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
 #if PF_PROBE
     a.probe = getenv("PF_PROBE") ? pf::probe_buffer() : nullptr;
 #endif
+    static const int exp_mask = getenv("PF_SPLAT_EXP") ? atoi(getenv("PF_SPLAT_EXP")) : 0;
+    a.exp = exp_mask;
     hipStream_t s = (hipStream_t)stream;
     const int G = a.per_frame ? T : 1;
 
