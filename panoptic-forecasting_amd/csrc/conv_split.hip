@@ -1,4 +1,5 @@
-// 3x3/s1 convolution with fp32 operands SPLIT into bf16 terms on the bf16 matrix pipe of gfx950 (opt-in).
+// 3x3/s1 convolution with fp32 operands SPLIT into bf16 terms on the bf16 matrix pipe of gfx950 (the default for the layers the tuned
+// table gives it; plan option split_bf16 = 0 keeps everything on the fp32 matrix instructions).
 //
 // fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at the fp32 vector rate and shares its budget with the VALU: ~135 TF/s is
 // the ceiling of conv_dma.hip.  v_mfma_f32_16x16x32_bf16 is 16x faster.  Every fp32 value x is split exactly into

@@ -10,14 +10,20 @@
 // (profiles/r01_a_first_path_kernel_stats.txt).  This version is a two-pass binning rasteriser:
 //
 //   bin_kernel     one workgroup per 16x64 SOURCE tile: exact-order fp32 projection (this file is built with
-//                  -ffp-contract=off; every product/sum rounded separately, IEEE divides), stored as 8 B per
-//                  point {bits(z), packed bins}; block max(z) partial; the bounding box of the destination bins
-//                  its VALID points reach; a byte mark per bin reached by an INVALID point (plain stores of the
-//                  constant 1 - no atomics needed); optional result2d.
-//   raster_kernel  one workgroup per 32x128 DESTINATION tile: scans the bounding boxes, re-reads the stored
-//                  projections (8 B/point) of only the source tiles that can reach it, and resolves "min depth,
-//                  ties -> lowest element index" with 64-bit ds_min on a packed key in a 32 KB LDS z-buffer it
-//                  alone owns; then writes seg/depth for its pixels.  The z-buffer never exists in HBM.
+//                  -ffp-contract=off; every product/sum rounded separately, IEEE divides) — four pixels per lane in
+//                  lockstep on the packed fp32 pipe with exact shortcuts for affine cameras (project4_fast), the full
+//                  scalar chain otherwise — stored as 8 B per point {bits(z), packed bins}; block max(z) partial; the
+//                  bounding box of the destination bins its VALID points reach; a byte mark per bin reached by an
+//                  INVALID point (plain stores of the constant 1 - no atomics needed); optional result2d.  The tile then
+//                  appends its id to the list of every destination tile its box touches (one global atomicAdd per pair).
+//   raster_kernel  one workgroup per 32x128 DESTINATION tile: reads its list (kFlight source tiles' 32-B-per-lane records in
+//                  flight at a time; a list that overflowed kListCap falls back to testing every box of the frame), and
+//                  resolves "min depth, ties -> lowest element index" with 64-bit ds_min on a packed key in a 32 KB LDS
+//                  z-buffer it alone owns; then writes seg/depth for its pixels.  The z-buffer never exists in HBM.
+//                  List order is arbitrary (atomic appends); min() does not care: the output is deterministic.
+//
+// Measured bounds and the variants that were tried and dropped (re-projecting in the raster pass instead of the 8 B/point
+// round trip, software-pipelined multi-tile workgroups): profiles/r02_experiments.md.
 //
 // Packed key (valid points have z > 0, so raw fp32 bits are monotone as unsigned):
 //     [ bits(z) : 32 | e : 32 ],  e = r*P + t*N + n  (corner replica r, P = T*N)   — pc_transform_model.py:112
@@ -70,7 +76,6 @@ struct SplatArgs {
     int stx, sty;         // source tiles per row / column
     int dtx, dty;         // destination tiles per row / column
     long long *probe;     // PF_PROBE builds only
-    int exp;              // PF_SPLAT_EXP experiment mask (tools/bench_splat.py): timing only, results are wrong when set
 };
 
 __device__ __forceinline__ unsigned float_to_ordered(float f) {
@@ -270,10 +275,7 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
         uint2 *pj = a.proj + ((long long)b * a.T + tl) * N + (long long)y * a.W + x;
         unsigned pk[8];
         Proj p4[4];
-        if (a.exp & 2) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { p4[k].z = d[k]; p4[k].x0 = p4[k].x1 = min(x + k, a.W - 1); p4[k].y0 = p4[k].y1 = y; p4[k].valid = m[k]; }
-        } else if (!(cam.affine && project4_fast(cam, x, y, d, m, Wf, Hf, p4))) {
+        if (!(cam.affine && project4_fast(cam, x, y, d, m, Wf, Hf, p4))) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) p4[k] = project(cam, x + k, y, d[k], m[k], Wf, Hf);
         }
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
             if (p.valid) {
                 bx0 = min(bx0, p.x0); by0 = min(by0, p.y0);
                 bx1 = max(bx1, p.x1); by1 = max(by1, p.y1);
-            } else if (!(a.exp & 1)) {
+            } else {
                 // every invalid point carries depth max+1 and payload 0: marking its bins is enough
                 mark[(long long)p.y0 * a.W + p.x0] = 1;
                 mark[(long long)p.y1 * a.W + p.x0] = 1;
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
                 mark[(long long)p.y1 * a.W + p.x1] = 1;
             }
         }
-        if ((a.W & 3) == 0 && !(a.exp & 16)) {   // the raster pass re-reads these instead of re-projecting (coalesced 32 B per thread)
+        if ((a.W & 3) == 0) {   // the raster pass re-reads these instead of re-projecting (coalesced 32 B per thread)
             reinterpret_cast<uint4 *>(pj)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             reinterpret_cast<uint4 *>(pj)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
         }
@@ -615,8 +617,6 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
 #if PF_PROBE
     a.probe = getenv("PF_PROBE") ? pf::probe_buffer() : nullptr;
 #endif
-    static const int exp_mask = getenv("PF_SPLAT_EXP") ? atoi(getenv("PF_SPLAT_EXP")) : 0;
-    a.exp = exp_mask;
     hipStream_t s = (hipStream_t)stream;
     const int G = a.per_frame ? T : 1;
 
