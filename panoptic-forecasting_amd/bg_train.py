@@ -213,9 +213,8 @@ class BGTrainer:
 
     def all_reduce_grads(self):
         """Data-parallel exchange: ONE all-reduce of the flat gradient (RCCL over xGMI; DDP-style average)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
-            self.grad.div_(dist.get_world_size())
+        from . import dist as pfdist
+        pfdist.all_reduce_mean_(self.grad)
 
     def optimizer_step(self, lr=None):
         L = _lib.load()

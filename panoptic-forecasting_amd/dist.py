@@ -62,3 +62,13 @@ def max_over_ranks(x, device):
     t = torch.tensor([float(x)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_reduce_mean_(flat):
+    """Data-parallel gradient exchange of the bg training step: ONE sum all-reduce of the flat gradient arena (16.5 MB
+    for FC-HarDNet-70) and a division by the world size — what DistributedDataParallel does bucket by bucket in the
+    reference (``training/train.py:96-103``).  In place; identity for a single process."""
+    if is_dist():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+    return flat

@@ -353,3 +353,27 @@ def test_mini_network_training_step_vs_autograd(size):
                     bad.append(('running %s %s' % (nm, op.name), r))
     net.close()
     assert not bad, bad
+
+
+def test_train_driver_runs_resumes_and_writes_reference_checkpoints(tmp_path):
+    """train_bg.py with the reference's flags on synthetic crops: two epochs, then --continue_training for a third; the
+    files of training/train.py:269-281 appear and the checkpoint loads into the registry's model with strict keys."""
+    from panoptic_forecasting_amd import train_bg
+    from panoptic_forecasting_amd.registry import build_model
+    wd = str(tmp_path / 'exp')
+    cfg = tmp_path / 'cfg.yaml'
+    cfg.write_text('task: bg\nmodel:\n  model_type: bg\n  num_inputs: 3\n  use_depth_inps: true\n  convert2onehot: true\n'
+                   'data:\n  crop_size: 64\ntraining:\n  batch_size: 2\n  num_epochs: 2\n  lr: 2.0e-3\n  mom: 0.9\n  wd: 1.0e-4\n'
+                   '  clip_grad_norm: 5.0\n  lr_decay_type: step\n  lr_decay_factor: 0.1\n  lr_decay_steps: 100\n')
+    train_bg.main(['--config_file', str(cfg), '--working_dir', wd, '--synthetic', '4'])
+    for name in ('config.yaml', 'model_checkpoint', 'best_model', 'training_checkpoint'):
+        assert os.path.exists(os.path.join(wd, name)), name
+    st = torch.load(os.path.join(wd, 'training_checkpoint'))
+    assert st['epoch'] == 3 and st['step'] == 4          # 2 epochs x 2 batches
+    train_bg.main(['--continue_training', '--working_dir', wd, '--synthetic', '4', '--extra_args', 'training.num_epochs', '3'])
+    st = torch.load(os.path.join(wd, 'training_checkpoint'))
+    assert st['epoch'] == 4 and st['step'] == 6
+    sd = torch.load(os.path.join(wd, 'model_checkpoint'))
+    m = build_model(_params())
+    m.load_state_dict(sd, strict=True)
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Timing of one bg training step (scope row f4) on the configuration of configs/bg/bg_train.yaml: batch 8, 800x800 crops,
+3 input frames; per-kernel hipEvent times of pf_train_forward_backward + pf_sgd_step.
+
+    python tools/bench_train.py [--batch 8] [--size 800] [--steps 3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from panoptic_forecasting_amd import lib as pflib, synth  # noqa: E402
+from panoptic_forecasting_amd.bg_train import BGTrainer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--size', type=int, default=800)
+    ap.add_argument('--steps', type=int, default=3)
+    a = ap.parse_args()
+    params = {'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])]},
+              'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True},
+              'training': {'lr': 2e-3, 'mom': 0.9, 'wd': 1e-4, 'clip_grad_norm': 5.0}}
+    tr = BGTrainer(params)
+    tr.load_state_dict(synth.make_state_dict(seed=1234))
+    inp = {k: v.cuda() for k, v in synth.make_bg_inputs(b=a.batch, h=a.size, w=a.size, seed=1).items()}
+    inp['seg'] = inp['seg'].to(torch.uint8)
+    lab = {'seg': torch.randint(0, 11, (a.batch, a.size, a.size), dtype=torch.uint8, device='cuda')}
+    tr.train_step(inp, lab)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(a.steps):
+        out = tr.train_step(inp, lab)
+    torch.cuda.synchronize()
+    ms = (time.time() - t0) / a.steps * 1e3
+    pflib.profile(True)
+    tr.train_step(inp, lab)
+    torch.cuda.synchronize()
+    recs = pflib.profile_results()
+    pflib.profile(False)
+    top = sorted(recs, key=lambda r: -r['ms'])[:8]
+    print(json.dumps({'ms_per_step': ms, 'samples_per_s': a.batch / ms * 1e3, 'batch': a.batch, 'size': a.size, 'loss': float(out['loss']),
+                      'workspace_GB': tr._ws.numel() / 1e9,
+                      'profiled_kernels': {r['label'][:60]: round(r['ms'], 2) for r in top}}))
+
+
+if __name__ == '__main__':
+    main()
