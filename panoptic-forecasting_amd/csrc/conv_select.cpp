@@ -28,8 +28,18 @@ size_t wave_lds_bytes(int ks, int mh, int nt, int wk) {
 
 ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B, int need, int use_tuned) {
     if (stride != 1) return ConvChoice{1, 0, 0, 0};           // conv_dma, shape by its cost model
+    // The table was measured at B = 1, 2, 4, 8, 16 (a layer without a row at one of those: the heuristics below won
+    // there).  Any other batch size takes the decision of the nearest measured one (in ratio; the larger on a tie): the
+    // choice depends on how many tiles the launch has, which moves slowly with B.
+    int Bt = B;
+    if (use_tuned && B != 1 && B != 2 && B != 4 && B != 8 && B != 16) {
+        const int measured[5] = {1, 2, 4, 8, 16};
+        Bt = 16;
+        for (int m : measured)
+            if (m >= B) { Bt = (m > 1 && (long)B * B < (long)m * (m / 2)) ? m / 2 : m; break; }
+    }
     for (const Tuned &t : kTuned)
-        if (use_tuned && t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == B &&
+        if (use_tuned && t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == Bt &&
             (!(need & 2) || t.c.kind != 2 || t.c.p0 != 1))
             return t.c;
     // Untuned shape.  Large stride-1 3x3 layers go to the bf16-split kernel: on every measured shape with >= 64x128
