@@ -257,21 +257,23 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
     const int t = a.t_first + tl;
     const int ty0 = (tile / a.stx) * kSrcTH, tx0 = (tile % a.stx) * kSrcTW;
     const long long N = (long long)a.H * a.W;
+    const long long in_base = ((long long)b * a.T_total + t) * N;
+    const int y = ty0 + (threadIdx.x >> 4), x = tx0 + (threadIdx.x & 15) * 4;
+    // the pixel loads go out BEFORE the 66 camera scalars are fetched: two independent round trips in flight together (a
+    // one-tile workgroup lives ~9 us, most of it dependent latency: profiles/r02_experiments.md)
+    float d[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    bool m[4] = {false, false, false, false};
+    if (y < a.H && x < a.W) load4(a, in_base, x, y, d, m);
     Camera cam;
     load_camera(a, b, t, cam);
-    const long long in_base = ((long long)b * a.T_total + t) * N;
     const int g = a.per_frame ? tl : 0, G = a.per_frame ? a.T : 1;
     uint8_t *mark = a.inv_mark + ((long long)b * G + g) * N;
     long long *r2d = a.out_r2d ? a.out_r2d + ((long long)b * a.T + tl) * N * 2 : nullptr;
     const float Wf = (float)a.W, Hf = (float)a.H;
 
-    const int y = ty0 + (threadIdx.x >> 4), x = tx0 + (threadIdx.x & 15) * 4;
     float zmax = -INFINITY;
     int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
     if (y < a.H && x < a.W) {
-        float d[4];
-        bool m[4];
-        load4(a, in_base, x, y, d, m);
         uint2 *pj = a.proj + ((long long)b * a.T + tl) * N + (long long)y * a.W + x;
         unsigned pk[8];
         Proj p4[4];
@@ -509,12 +511,15 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
             e -= e >= Pu ? Pu : 0u;
             src[k] = key[k] != kEmpty ? seg_base + (long long)e : seg_base;     // always a readable address
         }
+        if ((a.W & 3) == 0) {
+            const uchar4 mv = *reinterpret_cast<const uchar4 *>(mark + n0);
+            mk[0] = mv.x; mk[1] = mv.y; mk[2] = mv.z; mk[3] = mv.w;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool in = x + k < a.W;
-            mk[k] = in ? mark[n0 + k] : (uint8_t)0;
-            sg[k] = C == 1 ? a.seg[src[k]] : (uint8_t)0;
+            for (int k = 0; k < 4; ++k) mk[k] = x + k < a.W ? mark[n0 + k] : (uint8_t)0;
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sg[k] = C == 1 ? a.seg[src[k]] : (uint8_t)0;
         float dep[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
