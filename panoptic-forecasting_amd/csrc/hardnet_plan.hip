@@ -21,6 +21,8 @@ struct ConvPlan {
     size_t bias_off = 0;  // floats (padded to 16*n_tiles)
     size_t raw_off = 0;   // folded OIHW copy (stem only)
     size_t dep_off = 0;   // stem only: depth-channel columns [tap][t][16]
+    size_t oh_off = 0;    // stem only: one-hot rows [tap][t][n_cls + 1][16] with a zero row per group
+    bool has_oh = false;
     size_t tiled_off = 0; // per-cout-tile packing for the DMA fast path
     int tiled_chunks = 0;
     size_t rem_off = 0;   // conv_dma vector-ALU cout weights (3x3/s1 convs, rem_count trailing couts), else 0
@@ -280,6 +282,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             StemArgs a = *stem;
             a.w = p->dev_weights + p->conv[i].raw_off;
             a.wdep = p->dev_weights + p->conv[i].dep_off;
+            a.woh = p->conv[i].has_oh ? p->dev_weights + p->conv[i].oh_off : nullptr;
             a.probe = getenv("PF_PROBE") ? probe_buffer() : nullptr;
             a.dbg_plane_pad = getenv("PF_DBG_PLANE_PAD") ? atoi(getenv("PF_DBG_PLANE_PAD")) : 0;
             a.bias = p->dev_weights + p->conv[i].bias_off;
@@ -497,6 +500,14 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
                     for (int t = 0; t < T; ++t)
                         for (int co = 0; co < 16; ++co)
                             host.push_back(wts[o.w_off + ((size_t)co * o.cin + T * h.n_cls + t) * ks2 + tap]);
+                host.resize(align_up(host.size(), 16), 0.f);
+                c.oh_off = host.size();
+                c.has_oh = true;
+                for (int tap = 0; tap < ks2; ++tap)
+                    for (int t = 0; t < T; ++t)
+                        for (int r = 0; r <= (int)h.n_cls; ++r)
+                            for (int co = 0; co < 16; ++co)
+                                host.push_back(r < (int)h.n_cls ? wts[o.w_off + ((size_t)co * o.cin + t * h.n_cls + r) * ks2 + tap] : 0.f);
             }
         }
         host.resize(align_up(host.size(), 64), 0.f);

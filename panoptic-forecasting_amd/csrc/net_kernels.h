@@ -12,6 +12,7 @@ struct StemArgs {
     const uint8_t *mask;   // [B,T,H,W] (ignored with PF_HOP_DEPTH_U16)
     const float *w;        // folded OIHW [16][T*(n_cls+1)][3][3]
     const float *wdep;     // depth-channel columns re-packed [tap][t][16] (uniform 64-B rows for scalar loads)
+    const float *woh;      // one-hot rows re-packed [tap][t][n_cls + 1][16], last row of each group zero (nullable)
     const float *bias;     // [16]
     const uint8_t *lut;    // [256] id -> trainId (device)
     float *dst;            // [B,16,Hout,Wout]

@@ -179,6 +179,118 @@ __global__ __launch_bounds__(256) void stem_onehot_batched_kernel(StemArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stem, third form.  The batched kernel above was bound by the vector ALU (SQ counters, profiles/r02_a_pmc.json: 2270
+// instructions per output pixel, 300 M wave-instructions per 16 frames = 485 us of issue time in a 573 us kernel), and a
+// third of those instructions were not arithmetic: 64-bit address arithmetic for each of the 54 loads of a lane, a divergent
+// branch per (tap, frame) around the one-hot row, and every workgroup re-gathering its 20 KB of weights from the OIHW array
+// 4 bytes at a time.  Here
+//   * the one-hot rows arrive pre-packed [tap][t][n_cls + 1][16] (plan creation; the last row of each group is zero) and are
+//     copied to LDS with 16-B loads; a label outside 0..n_cls-1 (or a tap outside the image) selects the zero row: no branch;
+//   * loads use one uniform base per tensor + a 32-bit lane offset;
+//   * accumulation is on register pairs (v_pk_add_f32 for the one-hot rows, v_pk_fma_f32 with scalar weight pairs for depth).
+// Same operations on the same values in the same order as the kernels above: outputs are bit-identical.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+constexpr int kStemRow = 16;   // floats per one-hot weight row in LDS (20 = conflict-free for any label mix; measured no faster: warped label maps are coherent)
+template <int T, bool SEG64, bool HOP_D, bool HOP_LUT>
+__global__ __launch_bounds__(256) void stem_onehot_v3_kernel(StemArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [tap][t][n_cls + 1][kStemRow]
+    __shared__ uint8_t lut[256];
+    const int rows_per = a.n_cls + 1;
+    {
+        const f32x4v *src = reinterpret_cast<const f32x4v *>(a.woh);
+        f32x4v *dst = reinterpret_cast<f32x4v *>(wl);
+        // (kStemRow = 20 would pad the rows so that lanes picking different rows never share a bank group)
+        for (int e = threadIdx.x; e < 9 * T * rows_per * 4; e += 256) dst[(e >> 2) * (kStemRow / 4) + (e & 3)] = src[e];
+    }
+    lut[threadIdx.x] = HOP_LUT ? a.lut[threadIdx.x] : (uint8_t)threadIdx.x;
+    __syncthreads();
+
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (ox >= a.Wout || oy >= a.Hout) return;
+    const unsigned N = (unsigned)a.H * (unsigned)a.W;
+    constexpr bool hop_d = HOP_D;
+    // uniform bases of this sample; lane offsets in elements (T*N < 2^32 is checked at launch)
+    const uint8_t *seg8 = reinterpret_cast<const uint8_t *>(a.seg) + (size_t)b * T * N;
+    const long long *seg64 = reinterpret_cast<const long long *>(a.seg) + (size_t)b * T * N;
+    const float *depth = a.depth + (size_t)b * T * N;
+    const uint8_t *mask = a.mask ? a.mask + (size_t)b * T * N : nullptr;
+    // One (tap) per iteration of a ROLLED loop, the loads of the next three taps in flight (registers rotate).  Fully
+    // unrolled, hipcc issues all 216 LDS row reads of the straight-line code first and spills them (512 registers +
+    // scratch; scheduling fences do not stop it); the rolled loop holds 24 reads.
+    struct Tap { int lab[T]; float dep[T]; uint8_t msk[T]; bool ok; };
+    auto issue = [&](int tap, Tap &p) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+        p.ok = tap < 9 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const unsigned pix = p.ok ? (unsigned)iy * (unsigned)a.W + (unsigned)ix : 0u;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const unsigned idx = (unsigned)t * N + pix;
+            p.lab[t] = SEG64 ? (int)seg64[idx] : (int)seg8[idx];
+            p.dep[t] = depth[idx];
+            p.msk[t] = hop_d ? (uint8_t)0 : mask[idx];
+        }
+    };
+    f32x2v acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x2v{a.bias[2 * i], a.bias[2 * i + 1]};
+    const float mean_ = a.depth_mean, std_ = a.depth_std;
+    Tap c0, c1, c2, c3;
+    issue(0, c0);
+    issue(1, c1);
+    issue(2, c2);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        issue(tap + 3 < 9 ? tap + 3 : 8, c3);
+        const float *wrow = wl + tap * T * rows_per * kStemRow;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            int cls = c0.lab[t];
+            if (HOP_LUT) cls = lut[cls & 255];
+            // labels >= n_cls contribute nothing (bg_model.py:54-57): they, and taps outside the image, read the zero row
+            const int r = (c0.ok && (unsigned)cls < (unsigned)a.n_cls) ? cls : a.n_cls;
+            const f32x4v *row = reinterpret_cast<const f32x4v *>(wrow + (t * rows_per + r) * kStemRow);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4v w4 = row[q];
+                acc[2 * q] += f32x2v{w4[0], w4[1]};
+                acc[2 * q + 1] += f32x2v{w4[2], w4[3]};
+            }
+            float d = c0.dep[t], m;
+            if (hop_d) {
+                const float q = rintf(fminf(fmaxf(d + 1.f, 0.f), 255.f) * 256.f);  // export :119-124
+                d = q / 256.f - 1.f;                                                // load bg_dataset.py:225
+                const bool mk = d > 0.f;
+                d = mk ? fminf(fmaxf(d, a.min_depth), a.max_depth) : -1.f;           // :227-228,:166-170
+                m = mk ? 1.f : 0.f;
+            } else {
+                m = c0.msk[t] ? 1.f : 0.f;
+            }
+            const float dn = c0.ok ? ((d - mean_) / std_) * m : 0.f;                 // (bg_model.py:50-51,66-67)
+            const float *wd = a.wdep + (tap * T + t) * 16;                           // uniform: scalar loads, SGPR-pair operands
+            const f32x2v dn2 = f32x2v{dn, dn};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_elementwise_fma(f32x2v{wd[2 * i], wd[2 * i + 1]}, dn2, acc[i]);
+        }
+        // the LDS row reads stay inside their iteration (hipcc otherwise rotates the loop and carries 12 rows = 48 registers
+        // across the back edge: one wave per SIMD less); their ~100 cycles are hidden by the other waves
+        __builtin_amdgcn_sched_barrier(0);
+        c0 = c1;
+        c1 = c2;
+        c2 = c3;
+    }
+    const size_t op = (size_t)a.Hout * a.Wout;
+    float *o = a.dst + (size_t)b * 16 * op + (size_t)oy * a.Wout + ox;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        o[(2 * i) * op] = fmaxf(acc[i].x, 0.f);
+        o[(2 * i + 1) * op] = fmaxf(acc[i].y, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void avgpool2_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                        int planes, int Hin, int Win, int Hout, int Wout) {
     const size_t total = (size_t)planes * Hout * Wout;
@@ -499,13 +611,24 @@ int launch_stem(const StemArgs &a, hipStream_t s) {
     const double ipx = (double)a.B * a.T * a.H * a.W, opx = (double)a.B * a.Hout * a.Wout;
     static const bool generic = getenv("PF_STEM_GENERIC") != nullptr;   // A/B switch for profiling
     const bool batched = a.T == 3 && a.wdep && !generic;
+    static const bool no_v3 = getenv("PF_STEM_BATCHED") != nullptr;       // A/B switch: the previous form
+    const bool v3 = batched && a.woh && !no_v3 && (unsigned long long)a.T * a.H * a.W < (1ull << 32);
     const char *label = !batched ? "pf::stem_onehot_kernel(pf::StemArgs)"
+                        : v3 ? "pf::stem_onehot_v3_kernel(pf::StemArgs)"
                         : a.seg_is_i64 ? "void pf::stem_onehot_batched_kernel<3, true>(pf::StemArgs)"
                                        : "void pf::stem_onehot_batched_kernel<3, false>(pf::StemArgs)";
     ProfScope ps(s, label, 2.0 * opx * 16 * a.T * (a.n_cls + 1) * 9,
                  ipx * ((a.seg_is_i64 ? 8 : 1) + 4 + ((a.hop & PF_HOP_DEPTH_U16) ? 0 : 1)) + opx * 16 * 4);
     const dim3 grid((a.Wout + 63) / 64, (a.Hout + 3) / 4, a.B);
-    if (batched) {
+    if (v3) {
+        const size_t lds3 = (size_t)9 * a.T * (a.n_cls + 1) * kStemRow * sizeof(float);
+        const int variant = (a.seg_is_i64 ? 4 : 0) | ((a.hop & PF_HOP_DEPTH_U16) ? 2 : 0) | ((a.hop & PF_HOP_TRAINID_LUT) ? 1 : 0);
+#define PF_STEM3(V, S64, HD, HL) \
+        if (variant == V) hipLaunchKernelGGL((stem_onehot_v3_kernel<3, S64, HD, HL>), grid, dim3(256), lds3, s, a);
+        PF_STEM3(0, false, false, false) PF_STEM3(1, false, false, true) PF_STEM3(2, false, true, false) PF_STEM3(3, false, true, true)
+        PF_STEM3(4, true, false, false) PF_STEM3(5, true, false, true) PF_STEM3(6, true, true, false) PF_STEM3(7, true, true, true)
+#undef PF_STEM3
+    } else if (batched) {
         if (a.seg_is_i64) hipLaunchKernelGGL((stem_onehot_batched_kernel<3, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((stem_onehot_batched_kernel<3, false>), grid, dim3(256), lds, s, a);
     } else {
