@@ -140,6 +140,15 @@ struct Proj {
     bool valid;
 };
 
+// :106-114 `.floor().long()` / `.ceil().long()` then clamp(0, hi).  Clamping in float first keeps the conversion in range;
+// a value the reference's float -> int64 cast cannot represent (NaN, +-inf, |f| >= 2^63: x86 returns INT64_MIN, which the
+// clamp turns into 0) gives 0 here too, so that bins of points with non-finite projections (invalid, but they still mark
+// bins and appear in result2d) agree with the reference run on x86.
+__device__ __forceinline__ int to_bin(float f, float hi) {
+    const float c = fminf(fmaxf(f, 0.0f), hi);
+    return (f < 9223372036854775808.0f) ? (int)c : 0;
+}
+
 // pc_transform_model.py:54-114 for one pixel.  Used by BOTH kernels so they agree bit for bit.
 __device__ __forceinline__ Proj project(const Camera &c, int x, int y, float d, bool m, float Wf, float Hf) {
     const float u = (float)x, v = (float)y;
@@ -159,10 +168,10 @@ __device__ __forceinline__ Proj project(const Camera &c, int x, int y, float d, 
     const bool inb = (uu >= 0.0f) && (uu < Wf) && (vv >= 0.0f) && (vv < Hf);                          // :83-86
     p.valid = m && (z > 0.0f) && inb;                                                                 // :87-89
     // :106-114 floor/ceil then clamp (clamping in float first keeps the int conversion in range)
-    p.x0 = (int)fminf(fmaxf(floorf(uu), 0.0f), Wf - 1.0f);
-    p.x1 = (int)fminf(fmaxf(ceilf(uu), 0.0f), Wf - 1.0f);
-    p.y0 = (int)fminf(fmaxf(floorf(vv), 0.0f), Hf - 1.0f);
-    p.y1 = (int)fminf(fmaxf(ceilf(vv), 0.0f), Hf - 1.0f);
+    p.x0 = to_bin(floorf(uu), Wf - 1.0f);
+    p.x1 = to_bin(ceilf(uu), Wf - 1.0f);
+    p.y0 = to_bin(floorf(vv), Hf - 1.0f);
+    p.y1 = to_bin(ceilf(vv), Hf - 1.0f);
     return p;
 }
 
@@ -200,10 +209,10 @@ __device__ __forceinline__ Proj finish(float uu, float vv, float z, bool m, floa
     p.z = z;
     const bool inb = (uu >= 0.0f) && (uu < Wf) && (vv >= 0.0f) && (vv < Hf);
     p.valid = m && (z > 0.0f) && inb;
-    p.x0 = (int)fminf(fmaxf(floorf(uu), 0.0f), Wf - 1.0f);
-    p.x1 = (int)fminf(fmaxf(ceilf(uu), 0.0f), Wf - 1.0f);
-    p.y0 = (int)fminf(fmaxf(floorf(vv), 0.0f), Hf - 1.0f);
-    p.y1 = (int)fminf(fmaxf(ceilf(vv), 0.0f), Hf - 1.0f);
+    p.x0 = to_bin(floorf(uu), Wf - 1.0f);
+    p.x1 = to_bin(ceilf(uu), Wf - 1.0f);
+    p.y0 = to_bin(floorf(vv), Hf - 1.0f);
+    p.y1 = to_bin(ceilf(vv), Hf - 1.0f);
     return p;
 }
 

@@ -117,3 +117,40 @@ def test_full_size_properties():
     o = _model(2, False).predict(ident, None)
     # identity ego-motion: every pixel lands within one pixel of itself; the nearest of <=4 candidates wins
     assert (o['depth'] > 0).float().mean() > 0.99
+
+
+@pytest.mark.parametrize('case', ['non_affine_camera', 'huge_depth', 'list_overflow'])
+def test_paths_beside_the_fast_one_match_oracle(case):
+    """bin_kernel takes the packed shortcut chain only for affine cameras and finite intermediates, and the raster kernel
+    reads per-tile lists unless one overflowed.  The other branches against the C oracle, bit for bit:
+      non_affine_camera  last rows of K / E that are not (0,0,1) / (0,0,0,1): every point on the full scalar chain;
+      huge_depth         finite depths around 1e37..3e38 scattered in the maps: intermediates overflow to inf (and inf - inf =
+                         NaN in later sums), so those lanes leave the shortcut; both sides clamp the resulting coordinates
+                         with fmaxf/fminf before the integer conversion, which is defined for NaN and inf;
+      list_overflow      depth planes that alternate between 2 m and 80 m per pixel at a large ego translation: every
+                         source tile's box covers a wide band, destination lists exceed their 64 entries and the kernel falls
+                         back to testing all boxes."""
+    from oracle import warp_splat as oracle
+    from panoptic_forecasting_amd import synth
+    if case == 'list_overflow':
+        inp = synth.make_inputs(b=1, h=512, w=1024, seed=5, gap_len=9, depth_mode='uniform')
+        g = torch.Generator().manual_seed(1)
+        near = torch.rand(inp['depth'].shape, generator=g) < 0.5
+        inp['depth'] = torch.where(near, torch.full_like(inp['depth'], 2.0), torch.full_like(inp['depth'], 80.0))
+        inp['target_T'][:, :, 0, 3] += 1.5          # metres sideways: 1700 px of parallax at 2 m, 40 px at 80 m
+    else:
+        inp = synth.make_inputs(b=2, h=128, w=256, seed=21, gap_len=3, depth_mode='uniform')
+    if case == 'non_affine_camera':
+        inp['intrinsics'][:, 2, 0] = 1e-5
+        inp['extrinsics'][:, 3, 2] = 1e-3
+    if case == 'huge_depth':
+        g = torch.Generator().manual_seed(2)
+        pick = torch.rand(inp['depth'].shape, generator=g) < 0.02
+        big = torch.empty(inp['depth'].shape).uniform_(1e37, 3e38, generator=g)
+        inp['depth'] = torch.where(pick, big, inp['depth'])
+    for ind in (None, 1):
+        ref = oracle.predict(inp, only_this_ind=ind)
+        out = _model(ind, False).predict({k: v.cuda() for k, v in inp.items()}, None)
+        assert torch.equal(out['result2d'].cpu(), ref['result2d']), (case, ind)
+        assert torch.equal(out['seg'].cpu(), ref['seg']), (case, ind)
+        assert torch.equal(out['depth'].cpu().view(torch.int32), ref['depth'].view(torch.int32)), (case, ind)
