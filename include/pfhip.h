@@ -245,6 +245,13 @@ int pf_sgd_step(float *theta, float *grad, float *momentum_buf, const uint8_t *t
  * "base.4.out") lives inside the workspace for this (B,H,W): byte offset, channels, height, width. */
 int pf_hardnet_tensor_view(const pf_plan *plan, const char *name, int B, int H, int W,
                            size_t *ws_offset, int *channels, int *h, int *w);
+/* Copy tensor `name` of the LAST forward of this plan out of its workspace as fp32 NCHW [B,channels,h,w].  Intermediate
+ * tensors may live in the packed-pair layout of conv_s4.hip (plan option "packed_acts", on by default): two bf16 terms
+ * hi = bf16(x), mid = bf16(x - hi) per element in [B][2][ceil(C/4)][H][W][4] order - this call undoes it. */
+int pf_hardnet_tensor_read(const pf_plan *plan, const char *name, int B, int H, int W, const void *ws, float *dst, void *stream);
+/* fp32 NCHW <-> packed-pair layout (dst of pf_s4_pack: 16 * B * ceil(C/4) * H * W bytes); tests and tensor taps */
+int pf_s4_pack(const float *src, void *dst, int B, int C, int H, int W, void *stream);
+int pf_s4_unpack(const void *src, float *dst, int B, int C, int H, int W, void *stream);
 /* Dense-equivalent FLOPs of one forward at (H,W) per sample (2*Cout*Hout*Wout*Cin*k*k summed). */
 int pf_hardnet_flops(const pf_plan *plan, int H, int W, double *flops);
 

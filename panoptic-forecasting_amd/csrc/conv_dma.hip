@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int co = (tile0 + n) * 16 + (lane & 15);
-            if (co >= a.Cout) continue;
+            if (epi_skip(a, co)) continue;
 #pragma unroll
             for (int m = 0; m < C::MP; ++m) {
                 const int mt = wm * C::MP + m;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int co = (tile0 + n) * 16 + (lane_e & 15);
-                if (co >= a.Cout) continue;
+                if (epi_skip(a, co)) continue;
                 const lds_float *chan = res_lds + (n * 16 + (lane_e & 15)) * rw.cs;
                 const f32x4 top = epi_finish(a, b, co, oy, ox, acc[m][n], biasv[n], has_res, chan, &t0);
                 if (!a.pool) epi_store(a, b, co, oy, ox, top);

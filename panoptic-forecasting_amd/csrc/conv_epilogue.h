@@ -122,7 +122,86 @@ __device__ __forceinline__ epi_f32x4 epi_finish(const ConvArgs &a, int b, int co
     return v;
 }
 
+// ---- S4 stores (ConvArgs::dst_fmt == 1) ---------------------------------------------------------------------------
+// The D fragment gives a quad of lanes (same lane >> 2) 4 consecutive output channels x 4 consecutive pixels.  A 4x4
+// transpose inside the quad (two butterfly steps of DPP quad_perm moves) turns that into "lane k = pixel ox + k, 4
+// consecutive channels" = one 8-B unit of the packed layout per term.  EVERY lane of a quad must arrive here: callers
+// skip fragments with epi_skip(), which keeps lanes whose channel is past Cout (they contribute zeros) in S4 mode.
+__device__ __forceinline__ bool epi_skip(const ConvArgs &a, int co) { return co >= a.Cout && !a.dst_fmt; }
+
+__device__ __forceinline__ float quad_swap1(float x) {   // value of lane ^ 1
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_swap2(float x) {   // value of lane ^ 2
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));
+}
+// lane k holds row k of a 4x4 matrix -> lane k holds column k
+__device__ __forceinline__ epi_f32x4 quad_transpose(epi_f32x4 v) {
+    const int k = threadIdx.x & 3;
+    const bool hi2 = (k & 2) != 0, hi1 = (k & 1) != 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float lo = v[r], up = v[r + 2];
+        const float got = quad_swap2(hi2 ? lo : up);
+        v[r] = hi2 ? got : lo;
+        v[r + 2] = hi2 ? up : got;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+        const float lo = v[r], up = v[r + 1];
+        const float got = quad_swap1(hi1 ? lo : up);
+        v[r] = hi1 ? got : lo;
+        v[r + 1] = hi1 ? up : got;
+    }
+    return v;
+}
+
+typedef __bf16 epi_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 epi_bf16x4 __attribute__((ext_vector_type(4)));
+
+// c = 4 consecutive channels (buffer channels chb .. chb+3, chb even) of the pixel at element offset `pix` of an h x w plane
+__device__ __forceinline__ void s4_store_unit(const ConvArgs &a, int b, int chb, size_t plane_px, size_t pix, epi_f32x4 c) {
+    epi_bf16x4 hi, mid;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        hi[r] = (__bf16)c[r];
+        mid[r] = (__bf16)(c[r] - (float)hi[r]);
+    }
+    const size_t term = (size_t)a.dst_c4 * plane_px * 8;                      // bytes between the hi and the mid block
+    char *base = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8;
+    const bool ok0 = chb < a.dst_limit, ok1 = chb + 2 < a.dst_limit;
+    if ((chb & 3) == 0) {
+        char *p = base + (size_t)(chb >> 2) * plane_px * 8;
+        if (ok1) {
+            *reinterpret_cast<epi_bf16x4 *>(p) = hi;
+            *reinterpret_cast<epi_bf16x4 *>(p + term) = mid;
+        } else if (ok0) {
+            *reinterpret_cast<epi_bf16x2 *>(p) = epi_bf16x2{hi[0], hi[1]};
+            *reinterpret_cast<epi_bf16x2 *>(p + term) = epi_bf16x2{mid[0], mid[1]};
+        }
+    } else {   // the range starts in the middle of a group: upper half of one group, lower half of the next
+        char *p = base + (size_t)(chb >> 2) * plane_px * 8 + 4;
+        if (ok0) {
+            *reinterpret_cast<epi_bf16x2 *>(p) = epi_bf16x2{hi[0], hi[1]};
+            *reinterpret_cast<epi_bf16x2 *>(p + term) = epi_bf16x2{mid[0], mid[1]};
+        }
+        p += plane_px * 8 - 4;
+        if (ok1) {
+            *reinterpret_cast<epi_bf16x2 *>(p) = epi_bf16x2{hi[2], hi[3]};
+            *reinterpret_cast<epi_bf16x2 *>(p + term) = epi_bf16x2{mid[2], mid[3]};
+        }
+    }
+}
+
 __device__ __forceinline__ void epi_store(const ConvArgs &a, int b, int co, int oy, int ox, epi_f32x4 v) {
+    if (a.dst_fmt) {
+        if (co >= a.Cout) v = epi_f32x4{0.f, 0.f, 0.f, 0.f};
+        const epi_f32x4 c = quad_transpose(v);
+        const int k = threadIdx.x & 3;
+        if (ox + k < a.Wout)
+            s4_store_unit(a, b, a.dst_choff + (co & ~3), (size_t)a.Hout * a.Wout, (size_t)oy * a.Wout + ox + k, c);
+        return;
+    }
     float *p = a.dst + ((size_t)b * a.dst_ctotal + a.dst_choff + co) * ((size_t)a.Hout * a.Wout) + (size_t)oy * a.Wout + ox;
     if ((a.Wout & 3) == 0 && ox + 3 < a.Wout) {
         *reinterpret_cast<epi_f32x4 *>(p) = v;
@@ -136,10 +215,18 @@ __device__ __forceinline__ void epi_store(const ConvArgs &a, int b, int co, int 
 // rows oy (even) and oy+1 of the conv output -> row oy/2 of the pooled tensor [.., Hout/2, Wout/2]
 __device__ __forceinline__ void epi_store_pooled(const ConvArgs &a, int b, int co, int oy, int ox, epi_f32x4 top, epi_f32x4 bot) {
     const int Hp = a.Hout >> 1, Wp = a.Wout >> 1, py = oy >> 1, px = ox >> 1;
-    if (py >= Hp) return;
-    float *p = a.dst + ((size_t)b * a.dst_ctotal + a.dst_choff + co) * ((size_t)Hp * Wp) + (size_t)py * Wp + px;
     const float p0 = (((top[0] + top[1]) + bot[0]) + bot[1]) * 0.25f;   // summation order of avgpool2_kernel
     const float p1 = (((top[2] + top[3]) + bot[2]) + bot[3]) * 0.25f;
+    if (a.dst_fmt) {
+        const bool live = co < a.Cout;
+        const epi_f32x4 c = quad_transpose(epi_f32x4{live ? p0 : 0.f, live ? p1 : 0.f, 0.f, 0.f});
+        const int k = threadIdx.x & 3;
+        if (py < Hp && k < 2 && px + k < Wp)
+            s4_store_unit(a, b, a.dst_choff + (co & ~3), (size_t)Hp * Wp, (size_t)py * Wp + px + k, c);
+        return;
+    }
+    if (py >= Hp) return;
+    float *p = a.dst + ((size_t)b * a.dst_ctotal + a.dst_choff + co) * ((size_t)Hp * Wp) + (size_t)py * Wp + px;
     if ((Wp & 1) == 0 && px + 1 < Wp) {
         *reinterpret_cast<epi_f32x2 *>(p) = epi_f32x2{p0, p1};
     } else {

@@ -41,6 +41,19 @@ struct ConvArgs {
     int chunk_begin, chunk_end;  // = src_chunk0[src_begin], src_chunk0[src_end] (filled at launch)
     long long *probe;        // PF_PROBE builds only: in-kernel timestamps of workgroup 0 / wave 0 (else nullptr)
     int accum;               // generic kernel (conv_mfma.hip) only: dst += result (gradient accumulation of the training path)
+    // ---- packed-pair ("S4") activation layout, conv_s4.hip: a tensor of C channels is stored as
+    //      [B][2 terms: hi, mid][C4 = ceil(C/4)][H][W][4] bf16 with x ~= hi + mid, hi = bf16(x), mid = bf16(x - hi): the same
+    //      4 B per element as fp32 and exactly the two terms the bf16-split kernels feed the matrix pipe with
+    int dst_fmt;             // 0: fp32 NCHW, 1: S4 (epi_store / epi_store_pooled of conv_epilogue.h)
+    int dst_c4;              // channel groups of the dst tensor
+    int dst_limit;           // S4: stores cover buffer channels [dst_choff, dst_limit) = dst_choff + Cout, rounded up to a
+                             // whole group when this conv also zero-fills the tail of its last group
+    int src_fmt;             // 1: every source is S4 (conv_s4 kernels only)
+    int src_c4[kConvMaxSrc];      // channel groups of each source tensor
+    int src_g0[kConvMaxSrc];      // first group a range touches = src_choff / 4
+    int src_gn[kConvMaxSrc];      // number of groups it touches
+    int src_ent0[kConvMaxSrc + 1];// first K entry of each range ("group entries": one group of one range; padded per range to
+                                  // whole rounds when the conv was packed with pad_sources)
 };
 
 // Tiling choice for one conv (depends on shape only; fixed at plan time for the weight packing).
@@ -112,9 +125,23 @@ size_t split1_packed_floats(const int *src_ch, int n_src, int cout);
 void pack_conv_weights_split1(const float *w_oihw, int cin, int cout, const int *src_ch, int n_src, float *out);
 int launch_conv_split1(const ConvArgs &a, int nt, int B, hipStream_t stream);
 
+// S4 path (conv_s4.hip; stride 1, W % 4 == 0): every source in the packed-pair layout, tiles arrive by LDS-DMA, no split
+// phase.  K order = the group entries of the ranges in order, two entries (8 channels) per 3x3 round, eight (32 channels)
+// per 1x1 round; weights of channels a range does not own inside its first/last group are zero.
+struct S4Range { int choff, ch; };   // a source range in the channel numbering of its tensor
+// pad_sources: every range padded to whole rounds (convs that may be launched one range at a time)
+int s4_entries(const S4Range *r, int n_src, int ks, int pad_sources);
+int s4_rounds(const S4Range *r, int n_src, int ks, int pad_sources);
+size_t s4_packed_floats(const S4Range *r, int n_src, int cout, int ks, int pad_sources);
+void pack_conv_weights_s4(const float *w_oihw, int cin, int cout, int ks, const S4Range *r, int n_src, int pad_sources, float *out);
+int launch_conv_s4(const ConvArgs &a, int ks, int nt, int wide, int B, hipStream_t stream);
+// layout conversion (tests, tensor taps): fp32 NCHW <-> S4
+int launch_s4_pack(const float *src, void *dst, int B, int C, int H, int W, hipStream_t stream);
+int launch_s4_unpack(const void *src, float *dst, int B, int C, int H, int W, hipStream_t stream);
+
 // Kernel/shape choice for one stride-1 conv (conv_select.cpp): kind 1 = conv_dma (p0 = WM, p1 = NT),
 // kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK), kind 3 = conv_valu (p0 = rows per wave),
-// kind 4 = conv_split (p0 = NT, p1 = 1: 8x64-pixel tiles).
+// kind 4 = conv_split (p0 = NT, p1 = 1: 8x64-pixel tiles), kind 5 = conv_s4 (same parameters; S4 sources).
 struct ConvChoice {
     int kind, p0, p1, p2;
 };

@@ -1,0 +1,589 @@
+// Convolutions on activations stored PRE-SPLIT ("S4" layout, conv_mfma.h): the bf16-split scheme of conv_split.hip without its
+// memory side.
+//
+// conv_split.hip reads fp32 NCHW, and every consumer of a tensor splits it again: per round of 8 channels a thread holds 32
+// staging registers, spends 15-20 % of the round on conversions + 8 ds_write_b128 and needs two barriers because the
+// activation buffer cannot be overwritten while it is read (profiles/r02_experiments.md: the memory side and the matrix
+// side of a 91->28 layer need 285 and 318 us alone and 406 us together).  Here the PRODUCER's epilogue writes
+//     [B][2 terms: hi, mid][C4 = ceil(C/4)][H][W][4 channels] bf16       hi = bf16(x), mid = bf16(x - hi)
+// - the same 4 B per element as fp32 and exactly what these consumers feed the matrix pipe with, so nothing is lost for
+// them - and a consumer's halo tile arrives by LDS-DMA (buffer_load_dwordx4 ... lds, 16 B = 2 pixels x 4 channels of one
+// term; out-of-image pieces carry an out-of-range offset and land as zeros = the convolution's padding): no staging
+// registers, no conversion, no LDS stores, double-buffered stages with ONE barrier per round.
+//
+// Channel groups of 4 (not 8): FC-HarDNet's tensors have 10/18/28/46 channels; a range is read as the groups it touches
+// (weights of channels it does not own inside its first/last group are zero), so 10 channels cost 12, not 16.  A block's
+// concatenated output tensor is one buffer: layers write their slice (4-B granularity: all offsets are even) and whoever
+// reads the whole block reads no padding at all.
+//
+// 3x3: GEMM view as in conv_split.hip (M = 16 pixels of a row, N = 16 couts, K = 32 = 4 lane groups x 8 values), a lane's 8
+// K-values = the 4 channels of TWO group entries for one tap: two ds_read_b64 per term.  A round = 2 entries = 8 channels =
+// 3 instructions of 4 tap slots.  The 9 taps are laid out so that the two lane groups one ds_read_b64 pass serves
+// (lanes 0-31 / 32-63) read the same tile row, or the same addresses: conflict-free for any row pitch -
+//     instr 0: (0,0) (0,1) | (1,0) (1,1)     instr 1: (2,0) (2,1) | (0,2) --     instr 2: (1,2) -- | (2,2) --
+// (-- = zero-weight slot reading its neighbour's addresses).  Wave w DMAs plane (term = w >> 1, entry = w & 1) of a stage.
+// 1x1: K = 32 = 8 group entries per instruction and round; 8x32-pixel tiles, the fused epilogue stages of conv_epilogue.h.
+#include <cstring>
+#include <vector>
+
+#include "conv_epilogue.h"
+#include "pf_prof.h"
+
+namespace pf {
+
+typedef float s4_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 s4_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 s4_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *s4_lds_ptr_t;
+[[maybe_unused]] constexpr unsigned kS4Oob = 0x80000000u;
+
+__device__ __forceinline__ s4_bf16x8 s4_join(s4_bf16x4 lo, s4_bf16x4 hi) {
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// group entry e of the conv's K order -> (source tensor frame base, byte offset of the hi plane of its group); all scalar
+__device__ __forceinline__ void s4_entry(const ConvArgs &a, int e, int b, size_t plane_bytes, const char *&base, unsigned &goff,
+                                         unsigned &term_stride) {
+    const float *sp = a.src[0];
+    int c4 = a.src_c4[0], g0 = a.src_g0[0], gn = a.src_gn[0], e0 = 0;
+#pragma unroll
+    for (int k = 1; k < kConvMaxSrc; ++k) {
+        const bool take = k < a.n_src && e >= a.src_ent0[k];
+        sp = take ? a.src[k] : sp;
+        c4 = take ? a.src_c4[k] : c4;
+        g0 = take ? a.src_g0[k] : g0;
+        gn = take ? a.src_gn[k] : gn;
+        e0 = take ? a.src_ent0[k] : e0;
+    }
+    // entries past the groups of their range (round padding) have zero weights: they re-read the range's last group
+    base = reinterpret_cast<const char *>(sp) + (size_t)b * 2 * c4 * plane_bytes;
+    goff = (unsigned)(g0 + min(e - e0, gn - 1)) * (unsigned)plane_bytes;
+    term_stride = (unsigned)c4 * (unsigned)plane_bytes;
+}
+
+template <int NT, int TW_>
+struct S4Cfg {
+    static constexpr int TW = TW_, TH = 8, MTR = TW / 16, MP = 2 * MTR;   // 4 waves x MP M-tiles = 8 rows x TW pixels
+    static constexpr int IW = TW + 4, IH = TH + 2;                        // halo tile, 2-pixel apron left/right (16-B pieces)
+    static constexpr int ROWP = IW / 2, PIECES = IH * ROWP;               // 16-B pieces per (term, entry) plane
+    static constexpr int NDMA = (PIECES + 63) / 64;                       // DMA instructions per plane (one wave per plane)
+    static constexpr int PLANE = NDMA * 64 * 16;                          // bytes
+    static constexpr int ABUF = 4 * PLANE;                                // [term][entry] per stage
+    static constexpr int WBUF = NT * 3 * 2 * 64 * 16;                     // [nt][instr][term][lane][8 bf16]
+    static constexpr int WPIECES = WBUF / 16, NITW = (WPIECES + 255) / 256;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)ABUF + 2 * (size_t)WBUF;
+};
+
+template <int NT, int TW_>
+__global__ __launch_bounds__(256) void conv_s4_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using C = S4Cfg<NT, TW_>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntl = a.tilesX * a.tilesY;   // XCD-aware tile order (see conv_split.hip)
+    const int tid_lin = (ntl & 7) == 0 ? (int)(blockIdx.x & 7) * (ntl >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int tileY = tid_lin / a.tilesX, tileX = tid_lin - tileY * a.tilesX;
+    const int tile0 = blockIdx.y * NT, b = blockIdx.z;
+    const int iy0 = tileY * C::TH - 1, ix0 = tileX * C::TW - 2;
+    const size_t plane_bytes = (size_t)a.Hin * a.Win * 8;
+    auto abuf = [&](int i) { return smem_raw + i * C::ABUF; };
+    auto wbuf = [&](int i) { return smem_raw + 2 * C::ABUF + i * C::WBUF; };
+
+    s4_f32x4 acc[C::MP][NT];
+#pragma unroll
+    for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = s4_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this lane's pieces of the plane its wave fetches: byte offset inside a group plane, or out of range
+    unsigned poff[C::NDMA];
+#pragma unroll
+    for (int j = 0; j < C::NDMA; ++j) {
+        const int p = j * 64 + lane, row = p / C::ROWP, cp = p - row * C::ROWP;
+        const int gy = iy0 + row, gx = ix0 + 2 * cp;
+        poff[j] = (p < C::PIECES && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? (unsigned)(gy * a.Win + gx) * 8u : kS4Oob;
+    }
+    unsigned woff[C::NITW];
+#pragma unroll
+    for (int it = 0; it < C::NITW; ++it) {
+        const int p = it * 256 + tid, n = p / (3 * 2 * 64);
+        woff[it] = (p < C::WPIECES && tile0 + n < a.ntiles) ? (unsigned)((tile0 + n) * a.nchunks * (3 * 2 * 64) + (p - n * (3 * 2 * 64))) * 16u : kS4Oob;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wpk, 0, 0x7FFFFFFF, 0x00020000);
+
+    // A-fragment byte offsets inside a plane for instruction s (M-tile part added as an immediate): the lane group picks the tap
+    int aoff[3];
+    {
+        const int g = lane >> 4;
+        const int ky[3] = {g >> 1, g < 2 ? 2 : 0, g < 2 ? 1 : 2};
+        const int kx[3] = {g & 1, g < 2 ? g : 2, 2};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) aoff[s] = ((wave * 2 + ky[s]) * C::IW + (lane & 15) + kx[s] + 1) * 8;
+    }
+
+    float biasv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) biasv[n] = epi_bias(a, (tile0 + n) * 16 + (lane & 15));
+
+    const int cb = a.chunk_begin, nrounds = a.chunk_end - cb;
+    auto issue_round = [&](int r, int stage) {
+        // activations: wave w fetches plane (term = w >> 1, entry = 2 (cb + r) + (w & 1))
+        const int e = 2 * (cb + r) + (wave & 1);
+        const char *base;
+        unsigned goff, tstride;
+        s4_entry(a, e, b, plane_bytes, base, goff, tstride);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7FFFFFFF, 0x00020000);
+        const unsigned soff = goff + (unsigned)(wave >> 1) * tstride;
+        unsigned char *dst = abuf(stage) + wave * C::PLANE;
+#pragma unroll
+        for (int j = 0; j < C::NDMA; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (s4_lds_ptr_t)(dst + j * 1024), 16, poff[j], soff, 0, 0);
+        unsigned char *wdst = wbuf(stage);
+#pragma unroll
+        for (int it = 0; it < C::NITW; ++it)
+            if (it * 256 + tid < C::WPIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (s4_lds_ptr_t)(wdst + (it * 256 + wave * 64) * 16), 16, woff[it],
+                                                         (unsigned)(cb + r) * (3 * 2 * 64 * 16), 0, 0);
+    };
+
+    if (nrounds > 0) issue_round(0, 0);
+    for (int round = 0; round < nrounds; ++round) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
+        __syncthreads();                                    // everyone's have, and everyone is done reading the other stage
+        if (round + 1 < nrounds) issue_round(round + 1, (round + 1) & 1);
+        const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
+        constexpr int HALVES = C::MP / 4, UNITS = 3 * HALVES;
+        s4_bf16x8 fa_h[2][4], fa_m[2][4], fb_h[2][NT], fb_m[2][NT];
+        auto fetch = [&](int u, int set) {
+            const int s = u / HALVES, m0 = (u % HALVES) * 4;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                fb_h[set][n] = *reinterpret_cast<const s4_bf16x8 *>(wb + (((n * 3 + s) * 2 + 0) * 64 + lane) * 16);
+                fb_m[set][n] = *reinterpret_cast<const s4_bf16x8 *>(wb + (((n * 3 + s) * 2 + 1) * 64 + lane) * 16);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int mm = m0 + m, mo = ((mm / C::MTR) * C::IW + (mm % C::MTR) * 16) * 8;
+                const unsigned char *p = ab + aoff[s] + mo;
+                fa_h[set][m] = s4_join(*reinterpret_cast<const s4_bf16x4 *>(p), *reinterpret_cast<const s4_bf16x4 *>(p + C::PLANE));
+                fa_m[set][m] = s4_join(*reinterpret_cast<const s4_bf16x4 *>(p + 2 * C::PLANE), *reinterpret_cast<const s4_bf16x4 *>(p + 3 * C::PLANE));
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int set = u & 1, m0 = (u % HALVES) * 4;
+            if (u + 1 < UNITS) fetch(u + 1, set ^ 1);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_m[set][m], fb_h[set][n], acc[m0 + m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[set][m], fb_m[set][n], acc[m0 + m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[set][m], fb_h[set][n], acc[m0 + m][n], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias + ReLU; fp32 NCHW float4 stores or S4 units (conv_epilogue.h)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = (tile0 + n) * 16 + (lane & 15);
+        if (epi_skip(a, co)) continue;
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m) {
+            const int mt = wave * C::MP + m;
+            const int oy = tileY * C::TH + mt / C::MTR;
+            const int ox = tileX * C::TW + (mt % C::MTR) * 16 + (lane >> 4) * 4;
+            if (oy >= a.Hout || ox >= a.Wout) continue;
+            s4_f32x4 v = acc[m][n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] += biasv[n];
+                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            epi_store(a, b, co, oy, ox, v);
+        }
+    }
+#endif
+}
+
+template <int NT, int TW_>
+static int launch_s4_cfg(const ConvArgs &a0, int B, hipStream_t s) {
+    using C = S4Cfg<NT, TW_>;
+    ConvArgs a = a0;
+    a.tilesX = (a.Wout + C::TW - 1) / C::TW;
+    a.tilesY = (a.Hout + C::TH - 1) / C::TH;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s4_kernel<NT, TW_>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_set = true;
+    }
+    char label[96];
+    snprintf(label, sizeof(label), "void pf::conv_s4_kernel<%d, %d>(pf::ConvArgs)", NT, TW_);
+    const double px = (double)B * a.Hout * a.Wout;
+    ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * 9,
+                 4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * 9));
+    hipLaunchKernelGGL((conv_s4_kernel<NT, TW_>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(256), C::LDS_BYTES, s, a);
+    PF_LAUNCH_CHECK("conv_s4_kernel");
+    return PF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1x1: one round = 8 group entries (32 channels) of an 8x32-pixel tile; stage = [term][entry 8][256 pixels][4 ch], planes
+// 2112 B apart (2 planes = 128 B mod 256: the lane groups g, g+1 of a ds_read_b64 pass, which read entries 2g and 2g+2,
+// hit disjoint banks).  Wave w fetches the planes (term = w >> 1, entries 4 (w & 1) .. +3), two DMA instructions each.
+template <int NT>
+struct S41Cfg {
+    static constexpr int TW = 32, TH = 8, MTR = 2, MP = 4, NPIX = TH * TW;
+    static constexpr int PLANE = NPIX * 8 + 64;                     // bytes
+    static constexpr int ABUF = 2 * 8 * PLANE;                      // [term][entry]
+    static constexpr int WBUF = NT * 2 * 64 * 16;                   // [nt][term][lane][8 bf16]
+    static constexpr int MAIN = 2 * ABUF + 2 * WBUF;
+    static constexpr int WPIECES = WBUF / 16, NITW = (WPIECES + 255) / 256;
+};
+
+template <int NT, int EPI>
+__global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using C = S41Cfg<NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tileY = blockIdx.x / a.tilesX, tileX = blockIdx.x - tileY * a.tilesX;
+    const int tile0 = blockIdx.y * NT, b = blockIdx.z;
+    const size_t plane_bytes = (size_t)a.Hin * a.Win * 8;
+    auto abuf = [&](int i) { return smem_raw + i * C::ABUF; };
+    auto wbuf = [&](int i) { return smem_raw + 2 * C::ABUF + i * C::WBUF; };
+
+    s4_f32x4 acc[C::MP][NT];
+#pragma unroll
+    for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = s4_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    unsigned poff[2];   // pieces j*64 + lane of a 256-pixel plane: row = piece / 16, pixel pair = piece % 16
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = j * 64 + lane, row = p >> 4, cp = p & 15;
+        const int gy = tileY * C::TH + row, gx = tileX * C::TW + 2 * cp;
+        poff[j] = (gy < a.Hin && gx < a.Win) ? (unsigned)(gy * a.Win + gx) * 8u : kS4Oob;
+    }
+    int aoff[C::MP];   // entry pair of the lane group (2g, 2g+1) + the lane's pixel
+#pragma unroll
+    for (int m = 0; m < C::MP; ++m) {
+        const int mt = wave * C::MP + m, ty = mt / C::MTR, tx0 = (mt % C::MTR) * 16;
+        aoff[m] = (lane >> 4) * 2 * C::PLANE + (ty * C::TW + tx0 + (lane & 15)) * 8;
+    }
+    unsigned woff[C::NITW];
+#pragma unroll
+    for (int it = 0; it < C::NITW; ++it) {
+        const int p = it * 256 + tid, n = p / (2 * 64);
+        woff[it] = (p < C::WPIECES && tile0 + n < a.ntiles) ? (unsigned)((tile0 + n) * a.nchunks * (2 * 64) + (p - n * (2 * 64))) * 16u : kS4Oob;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wpk, 0, 0x7FFFFFFF, 0x00020000);
+
+    float biasv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) biasv[n] = epi_bias(a, (tile0 + n) * 16 + (lane & 15));
+
+    const int cb = a.chunk_begin, nrounds = a.chunk_end - cb;
+    auto issue_round = [&](int r, int stage) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int slot = 4 * (wave & 1) + q;
+            const int e = 8 * (cb + r) + slot;
+            const char *base;
+            unsigned goff, tstride;
+            s4_entry(a, e, b, plane_bytes, base, goff, tstride);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7FFFFFFF, 0x00020000);
+            const unsigned soff = goff + (unsigned)(wave >> 1) * tstride;
+            unsigned char *dst = abuf(stage) + ((wave >> 1) * 8 + slot) * C::PLANE;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (s4_lds_ptr_t)(dst + j * 1024), 16, poff[j], soff, 0, 0);
+        }
+        unsigned char *wdst = wbuf(stage);
+#pragma unroll
+        for (int it = 0; it < C::NITW; ++it)
+            if (it * 256 + tid < C::WPIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (s4_lds_ptr_t)(wdst + (it * 256 + wave * 64) * 16), 16, woff[it],
+                                                         (unsigned)(cb + r) * (2 * 64 * 16), 0, 0);
+    };
+
+    if (nrounds > 0) issue_round(0, 0);
+    for (int round = 0; round < nrounds; ++round) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (round + 1 < nrounds) issue_round(round + 1, (round + 1) & 1);
+        const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
+        s4_bf16x8 bh[NT], bm[NT], ah[C::MP], am[C::MP];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            bh[n] = *reinterpret_cast<const s4_bf16x8 *>(wb + ((n * 2 + 0) * 64 + lane) * 16);
+            bm[n] = *reinterpret_cast<const s4_bf16x8 *>(wb + ((n * 2 + 1) * 64 + lane) * 16);
+        }
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m) {
+            const unsigned char *p = ab + aoff[m];
+            ah[m] = s4_join(*reinterpret_cast<const s4_bf16x4 *>(p), *reinterpret_cast<const s4_bf16x4 *>(p + C::PLANE));
+            am[m] = s4_join(*reinterpret_cast<const s4_bf16x4 *>(p + 8 * C::PLANE), *reinterpret_cast<const s4_bf16x4 *>(p + 9 * C::PLANE));
+        }
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bm[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+    }
+
+    if (EPI == 0) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = (tile0 + n) * 16 + (lane & 15);
+            if (epi_skip(a, co)) continue;
+#pragma unroll
+            for (int m = 0; m < C::MP; ++m) {
+                const int mt = wave * C::MP + m;
+                const int oy = tileY * C::TH + mt / C::MTR;
+                const int ox = tileX * C::TW + (mt % C::MTR) * 16 + (lane >> 4) * 4;
+                if (oy >= a.Hout || ox >= a.Wout) continue;
+                s4_f32x4 v = acc[m][n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] += biasv[n];
+                    if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                }
+                epi_store(a, b, co, oy, ox, v);
+            }
+        }
+    } else {
+        // fused stages (conv_epilogue.h), as in conv_split1_kernel: residual window of this tile -> LDS (the stages are free
+        // once every wave has left the main loop), then pixel-group outer / channel inner
+        ResWin rw = ResWin();
+        const lds_float *res_lds = nullptr;
+        const bool has_res = a.res && a.res_lds_off >= 0;
+        if (has_res) {
+            __syncthreads();
+            rw = res_window(a, tileY * C::TH, C::TH, tileX * C::TW, C::TW);
+            res_stage(a, rw, b, tile0 * 16, NT * 16, (lds_float *)(reinterpret_cast<float *>(smem_raw) + a.res_lds_off), tid, 256);
+            res_lds = (const lds_float *)(reinterpret_cast<float *>(smem_raw) + a.res_lds_off);
+            __syncthreads();
+        }
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m) {
+            const int mt = wave * C::MP + m;
+            const int oy = tileY * C::TH + mt / C::MTR;
+            const int ox = tileX * C::TW + (mt % C::MTR) * 16 + (lane_e >> 4) * 4;
+            if (oy >= a.Hout || ox >= a.Wout) continue;
+            const bool pool_top = a.pool && ((m / C::MTR) & 1) == 0 && m + C::MTR < C::MP && oy + 1 < a.Hout;
+            if (a.pool && !pool_top) continue;
+            ResTaps t0, t1;
+            if (has_res) {
+                t0 = res_taps(a, rw, oy, ox);
+                if (pool_top) t1 = res_taps(a, rw, oy + 1, ox);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = (tile0 + n) * 16 + (lane_e & 15);
+                if (epi_skip(a, co)) continue;
+                const lds_float *chan = res_lds + (n * 16 + (lane_e & 15)) * rw.cs;
+                const s4_f32x4 top = epi_finish(a, b, co, oy, ox, acc[m][n], biasv[n], has_res, chan, &t0);
+                if (!a.pool) epi_store(a, b, co, oy, ox, top);
+                else epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, acc[(m + C::MTR) % C::MP][n], biasv[n], has_res, chan, &t1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#endif
+}
+
+template <int NT, int EPI>
+static int launch_s41_cfg(const ConvArgs &a0, int B, hipStream_t s) {
+    using C = S41Cfg<NT>;
+    ConvArgs a = a0;
+    a.tilesX = (a.Wout + C::TW - 1) / C::TW;
+    a.tilesY = (a.Hout + C::TH - 1) / C::TH;
+    size_t lds = C::MAIN;
+    a.res_lds_off = -1;
+    if (a.res) {
+        const size_t need = (size_t)NT * 16 * res_chan_stride(res_extent(C::TH, a.res_sh), res_extent(C::TW, a.res_sw)) * sizeof(float);
+        if (need > 64 * 1024) return fail(PF_EUNSUPPORTED, "conv_s4 1x1: residual window of %zu B does not fit LDS", need);
+        a.res_lds_off = 0;
+        if (need > lds) lds = need;
+    }
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s4_1x1_kernel<NT, EPI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    char label[112];
+    snprintf(label, sizeof(label), "void pf::conv_s4_1x1_kernel<%d, %d>(pf::ConvArgs)", NT, EPI);
+    if (a.res) strncat(label, " +res", sizeof(label) - strlen(label) - 1);
+    if (a.pool) strncat(label, " +pool", sizeof(label) - strlen(label) - 1);
+    if (a.no_bias) strncat(label, " lowres-half", sizeof(label) - strlen(label) - 1);
+    const double px = (double)B * a.Hout * a.Wout;
+    ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin, 4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin));
+    hipLaunchKernelGGL((conv_s4_1x1_kernel<NT, EPI>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(256), lds, s, a);
+    PF_LAUNCH_CHECK("conv_s4_1x1_kernel");
+    return PF_OK;
+}
+
+// a.wpk = pack_conv_weights_s4() output, a.nchunks = s4_rounds(), a.src_fmt = 1 (sources in the S4 layout, a.src_c4 /
+// src_g0 / src_ent0 filled), a.chunk_begin/chunk_end = the rounds to run.
+// ks = 3: nt = cout tiles per workgroup (1..3), wide = 8x64-pixel tiles.  ks = 1: nt = 1..4.
+int launch_conv_s4(const ConvArgs &a, int ks, int nt, int wide, int B, hipStream_t s) {
+    if (!a.src_fmt) return fail(PF_EINVAL, "conv_s4: sources are not in the S4 layout");
+    if ((a.Wout & 3) != 0 || a.Hin != a.Hout || a.Win != a.Wout) return fail(PF_EUNSUPPORTED, "conv_s4: stride 1, width % 4 == 0 only");
+    nt = nt < 1 ? 1 : (nt > a.ntiles ? a.ntiles : nt);
+    if (ks == 3) {
+        if (a.pool || a.res || a.no_bias) return fail(PF_EUNSUPPORTED, "conv_s4 3x3: no fused epilogue stages");
+        if (wide) {
+            if (nt == 1) return launch_s4_cfg<1, 64>(a, B, s);
+            if (nt == 2) return launch_s4_cfg<2, 64>(a, B, s);
+            return launch_s4_cfg<3, 32>(a, B, s);   // 3 cout tiles: the 8x64 stages would leave one workgroup per CU
+        }
+        if (nt == 1) return launch_s4_cfg<1, 32>(a, B, s);
+        if (nt == 2) return launch_s4_cfg<2, 32>(a, B, s);
+        return launch_s4_cfg<3, 32>(a, B, s);
+    }
+    nt = nt > 4 ? 4 : nt;
+    const bool fused = a.pool || a.res || a.no_bias;
+#define PF_S41(NT_) \
+    if (nt == NT_) return fused ? launch_s41_cfg<NT_, 1>(a, B, s) : launch_s41_cfg<NT_, 0>(a, B, s);
+    PF_S41(1) PF_S41(2) PF_S41(3) PF_S41(4)
+#undef PF_S41
+    return PF_EUNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------ host side: weights
+static unsigned short s4_bf16_rne(float x) {
+    unsigned u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static float s4_bf16_f32(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// group entries of range j; with pad_sources every range is padded to whole rounds (convs that may run one range at a
+// time: the two halves of a commuted upsample + 1x1, hardnet_plan.hip)
+static int s4_range_groups(const S4Range &r) { return (r.choff + r.ch + 3) / 4 - r.choff / 4; }
+int s4_entries(const S4Range *r, int n_src, int ks, int pad_sources) {
+    const int per = ks == 3 ? 2 : 8;
+    int n = 0;
+    for (int j = 0; j < n_src; ++j) n += pad_sources ? (s4_range_groups(r[j]) + per - 1) / per * per : s4_range_groups(r[j]);
+    return n;
+}
+int s4_rounds(const S4Range *r, int n_src, int ks, int pad_sources) {
+    const int per = ks == 3 ? 2 : 8;
+    return (s4_entries(r, n_src, ks, pad_sources) + per - 1) / per;
+}
+size_t s4_packed_floats(const S4Range *r, int n_src, int cout, int ks, int pad_sources) {
+    return (size_t)((cout + 15) / 16) * s4_rounds(r, n_src, ks, pad_sources) * (ks == 3 ? 3 : 1) * 2 * 64 * 4;
+}
+
+// 3x3: [tile][round][instr 3][term 2][lane 64][8 bf16]; 1x1: [tile][round][term 2][lane 64][8 bf16]; lane = (cout n = lane & 15,
+// group g = lane >> 4), the lane's 8 values = 4 channels of two group entries
+void pack_conv_weights_s4(const float *w, int cin, int cout, int ks, const S4Range *r, int n_src, int pad_sources, float *out_f) {
+    unsigned short *out = reinterpret_cast<unsigned short *>(out_f);
+    // entry -> (first conv input channel of the group's channel 0, may be negative; valid channel window)
+    std::vector<int> ent_c0, ent_lo, ent_hi;
+    const int per = ks == 3 ? 2 : 8;
+    int c0 = 0;
+    for (int j = 0; j < n_src; ++j) {
+        const int g0 = r[j].choff / 4, g1 = (r[j].choff + r[j].ch + 3) / 4;
+        for (int g = g0; g < g1; ++g) {
+            ent_c0.push_back(c0 + 4 * g - r[j].choff);
+            ent_lo.push_back(c0);
+            ent_hi.push_back(c0 + r[j].ch);
+        }
+        while (pad_sources && ent_c0.size() % per != 0) {   // padding entry: no valid channel
+            ent_c0.push_back(0);
+            ent_lo.push_back(0);
+            ent_hi.push_back(0);
+        }
+        c0 += r[j].ch;
+    }
+    const int n_ent = (int)ent_c0.size(), rounds = (n_ent + per - 1) / per, ntiles = (cout + 15) / 16;
+    // tap of (instr, lane group); -1 = zero slot
+    static const int tap3[3][4] = {{0, 1, 3, 4}, {6, 7, 2, -1}, {5, -1, 8, -1}};
+    size_t o = 0;
+    for (int t = 0; t < ntiles; ++t)
+        for (int rd = 0; rd < rounds; ++rd)
+            for (int s = 0; s < (ks == 3 ? 3 : 1); ++s)
+                for (int term = 0; term < 2; ++term)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = t * 16 + (lane & 15), g = lane >> 4;
+                            const int ent = ks == 3 ? rd * 2 + e / 4 : rd * 8 + g * 2 + e / 4;
+                            const int tap = ks == 3 ? tap3[s][g] : 0;
+                            float v = 0.f;
+                            if (co < cout && tap >= 0 && ent < n_ent) {
+                                const int ci = ent_c0[ent] + (e & 3);
+                                if (ci >= ent_lo[ent] && ci < ent_hi[ent]) v = w[((size_t)co * cin + ci) * ks * ks + tap];
+                            }
+                            const unsigned short hi = s4_bf16_rne(v);
+                            out[o++] = term == 0 ? hi : s4_bf16_rne(v - s4_bf16_f32(hi));
+                        }
+}
+
+// ------------------------------------------------------------------------------------------------ layout conversion
+__global__ void s4_pack_kernel(const float *src, unsigned short *dst, int B, int C, int H, int W) {
+    const size_t hw = (size_t)H * W, c4 = (C + 3) / 4, n = (size_t)B * c4 * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t px = i % hw, g = (i / hw) % c4, b = i / (hw * c4);
+        for (int r = 0; r < 4; ++r) {
+            const int c = (int)g * 4 + r;
+            const float x = c < C ? src[((size_t)b * C + c) * hw + px] : 0.f;
+            const __bf16 h = (__bf16)x;
+            const __bf16 m = (__bf16)(x - (float)h);
+            dst[(((b * 2 + 0) * c4 + g) * hw + px) * 4 + r] = __builtin_bit_cast(unsigned short, h);
+            dst[(((b * 2 + 1) * c4 + g) * hw + px) * 4 + r] = __builtin_bit_cast(unsigned short, m);
+        }
+    }
+}
+__global__ void s4_unpack_kernel(const unsigned short *src, float *dst, int B, int C, int H, int W) {
+    const size_t hw = (size_t)H * W, c4 = (C + 3) / 4, n = (size_t)B * C * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t px = i % hw, c = (i / hw) % C, b = i / (hw * C);
+        const size_t at = ((c / 4) * hw + px) * 4 + (c & 3);
+        const unsigned h = src[(b * 2 + 0) * c4 * hw * 4 + at], m = src[(b * 2 + 1) * c4 * hw * 4 + at];
+        dst[i] = __uint_as_float(h << 16) + __uint_as_float(m << 16);
+    }
+}
+int launch_s4_pack(const float *src, void *dst, int B, int C, int H, int W, hipStream_t s) {
+    hipLaunchKernelGGL(s4_pack_kernel, dim3(1024), dim3(256), 0, s, src, (unsigned short *)dst, B, C, H, W);
+    PF_LAUNCH_CHECK("s4_pack_kernel");
+    return PF_OK;
+}
+int launch_s4_unpack(const void *src, float *dst, int B, int C, int H, int W, hipStream_t s) {
+    hipLaunchKernelGGL(s4_unpack_kernel, dim3(1024), dim3(256), 0, s, (const unsigned short *)src, dst, B, C, H, W);
+    PF_LAUNCH_CHECK("s4_unpack_kernel");
+    return PF_OK;
+}
+
+}  // namespace pf

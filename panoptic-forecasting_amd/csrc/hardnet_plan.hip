@@ -8,7 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "conv_mfma.h"
+#include "conv_epilogue.h"
 #include "net_kernels.h"
 #include "pf_blob.h"
 #include "pf_prof.h"
@@ -34,6 +34,9 @@ struct ConvPlan {
     size_t split_off = 0; // bf16 hi/mid fragments for the bf16-split path (3x3/s1), else 0
     int split_chunks = 0;
     bool has_split = false;
+    size_t s4_off = 0;    // conv_s4.hip packing (stride-1 3x3 and 1x1), else 0
+    int s4_rounds = 0;
+    bool has_s4 = false, s4_pad = false;   // s4_pad: ranges padded to whole rounds (the conv may run one range at a time)
 };
 
 struct pf_plan {
@@ -49,10 +52,13 @@ struct pf_plan {
     // (pf_set_option) when the plan is created and read only by forwards of this plan
     int opt_fuse_pool = 1, opt_fuse_upsample = 1, opt_valu_rem = 1, opt_split_bf16 = 1, opt_use_tuned = 1;
     int opt_table_batch = 0;   // > 0: per-layer kernel choice as if the batch were this (batch-invariant numerics)
+    int opt_packed_acts = 1;   // tensors whose producers and consumers all support it live in the S4 layout (conv_s4.hip)
+    // formats of the last forward (pf_hardnet_tensor_read): 1 = S4
+    mutable std::vector<uint8_t> last_fmt;
 };
 
 namespace pf {
-int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_split_bf16 = 1;
+int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_split_bf16 = 1, g_opt_packed_acts = 1;
 extern int g_opt_use_tuned;
 }
 
@@ -63,6 +69,7 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "use_tuned_table")) g_opt_use_tuned = value;
     else if (!strcmp(name, "valu_remainder")) g_opt_valu_rem = value;
     else if (!strcmp(name, "split_bf16")) g_opt_split_bf16 = value;
+    else if (!strcmp(name, "packed_acts")) g_opt_packed_acts = value;
     else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);
     return PF_OK;
 }
@@ -74,6 +81,7 @@ extern "C" int pf_hardnet_plan_set_option(pf_plan *p, const char *name, int valu
     else if (!strcmp(name, "use_tuned_table")) p->opt_use_tuned = value;
     else if (!strcmp(name, "valu_remainder")) p->opt_valu_rem = value;
     else if (!strcmp(name, "split_bf16")) p->opt_split_bf16 = value;
+    else if (!strcmp(name, "packed_acts")) p->opt_packed_acts = value;
     else if (!strcmp(name, "table_batch")) p->opt_table_batch = value < 0 ? 0 : value;
     else return fail(PF_EINVAL, "pf_hardnet_plan_set_option: unknown option '%s'", name);
     return PF_OK;
@@ -132,7 +140,8 @@ int layout(const pf_plan *p, int B, const std::vector<Dims> &d, std::vector<size
     for (size_t t = 0; t < p->tensors.size(); ++t) {
         if (t == input || d[t].h == 0) continue;
         off[t] = cur;
-        cur += align_up((size_t)B * p->tensors[t].channels * d[t].h * d[t].w * sizeof(float), 256);
+        // channels padded to whole groups of 4: the same region holds the tensor as fp32 NCHW or in the S4 layout
+        cur += align_up((size_t)B * ((p->tensors[t].channels + 3) / 4 * 4) * d[t].h * d[t].w * sizeof(float), 256);
     }
     total = cur ? cur : 256;
     return PF_OK;
@@ -156,12 +165,37 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
     static const bool tag_ops = getenv("PF_PROFILE_OPS") != nullptr;
     const bool fuse = p->opt_fuse_pool != 0;      // option "fuse_pool"
 
-    auto fill_conv_args = [&](const BlobOp &o, size_t i, const Dims &in, const Dims &out, ConvArgs &a) {
+    // ---- tensor formats.  The op loop below runs twice: a dry pass records every launch (which tensors it reads and
+    // writes, whether its kernel can read / write the S4 layout of conv_s4.hip), the formats are then decided - a tensor is
+    // S4 iff every launch that reads it reads all its inputs as S4 and every launch that writes it can write S4 - and
+    // the second pass enqueues.
+    struct ConvRec {
+        uint32_t src_t[kConvMaxSrc], dst_t;
+        int sb, se;            // ranges it accumulates
+        bool can_read, can_write;   // can_write: whatever it reads; can_write_s4: only when it reads S4 itself
+        bool can_write_s4;
+        int dst_limit;         // S4 stores: first buffer channel this launch must NOT write (conv_mfma.h)
+        int nt, wide;          // conv_s4 shape if it reads S4
+    };
+    const size_t nT = p->tensors.size();
+    std::vector<ConvRec> recs;
+    std::vector<uint8_t> fmt(nT, 0), cand(nT, 1);
+    std::vector<std::vector<uint8_t>> written(nT);
+    for (size_t t = 0; t < nT; ++t) written[t].assign(p->tensors[t].channels + 8, 0);
+    const bool s4_allowed = p->opt_packed_acts && p->opt_split_bf16 && (g_conv_force.kind == 0 || g_conv_force.kind == 5);
+    bool dry = true;
+    size_t rec_i = 0;
+    struct ConvMeta {
+        uint32_t src_t[kConvMaxSrc], dst_t;
+    };
+
+    auto fill_conv_args = [&](const BlobOp &o, size_t i, const Dims &in, const Dims &out, ConvArgs &a, ConvMeta &mt) {
         memset(&a, 0, sizeof(a));
         a.n_src = (int)o.n_src;
         int c0 = 0;
         for (int j = 0; j < a.n_src; ++j) {
             a.src[j] = tptr(o.src[j].tensor);
+            mt.src_t[j] = o.src[j].tensor;
             a.src_ctotal[j] = (int)p->tensors[o.src[j].tensor].channels;
             a.src_choff[j] = (int)o.src[j].choff;
             a.src_cstart[j] = c0;
@@ -170,6 +204,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         for (int j = a.n_src; j <= kConvMaxSrc; ++j) a.src_cstart[j] = c0;
         a.bias = p->dev_weights + p->conv[i].bias_off;
         a.dst = tptr(o.dst);
+        mt.dst_t = o.dst;
         a.dst_ctotal = (int)p->tensors[o.dst].channels;
         a.dst_choff = (int)o.dst_choff;
         a.Cin = (int)o.cin; a.Cout = (int)o.cout;
@@ -183,24 +218,88 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         a.probe = probe_on ? probe_buffer() : nullptr;
     };
     // need: bit 1 = even tile rows (pooling epilogue), bit 2 = fused stage (not available on the generic path)
-    auto launch_conv_op = [&](const BlobOp &o, size_t i, ConvArgs &a, int need) -> int {
-        if ((a.Win & 3) != 0) {
+    auto launch_conv_op = [&](const BlobOp &o, size_t i, ConvArgs &a, const ConvMeta &mt, int need) -> int {
+        const bool generic = (a.Win & 3) != 0;
+        ConvChoice ch{0, 0, 0, 0};
+        if (!generic) {
+            ch = choose_conv((int)o.k, (int)o.stride, a.Cin, a.Cout, a.Hout, a.Wout, p->opt_table_batch > 0 ? p->opt_table_batch : B, need,
+                             p->opt_use_tuned);
+            if (g_conv_force.kind == 2 && o.stride == 1) {
+                ch = g_conv_force;
+                if ((need & 2) && ch.p0 == 1) ch.p0 = 2;
+            }
+            if (g_conv_force.kind == 1) ch = g_conv_force;
+            if (g_conv_force.kind == 3 && p->conv[i].has_valu && !need) ch = g_conv_force;
+            if (g_conv_force.kind == 4 && p->conv[i].has_split && (!need || o.k == 1)) ch = g_conv_force;
+            if (ch.kind == 4 && (!p->conv[i].has_split || (need && o.k != 1) || !p->opt_split_bf16)) ch = ConvChoice{1, 0, 0, 0};
+            if (ch.kind == 3 && (!p->conv[i].has_valu || need)) ch = ConvChoice{1, 0, 0, 0};
+            // pf_debug_force_conv(5, ..): launches that cannot read S4 (fp32 sources) still have to be able to WRITE it
+            if (g_conv_force.kind == 5) ch = ConvChoice{1, 0, 0, 0};
+        }
+        if (dry) {
+            ConvRec r;
+            memset(&r, 0, sizeof(r));
+            memcpy(r.src_t, mt.src_t, sizeof(r.src_t));
+            r.dst_t = mt.dst_t;
+            r.sb = a.src_begin;
+            r.se = a.src_end;
+            // reads S4: the layers the table gives to the bf16-split kernels (same tile parameters), big 1x1 convs, or all
+            // eligible convs under pf_debug_force_conv(5, nt, wide)
+            const bool forced = g_conv_force.kind == 5;
+            const long px = (long)B * a.Hout * a.Wout;
+            bool want = ch.kind == 4 || (o.k == 1 && px >= 131072 && ch.kind == 1) || forced;
+            r.nt = forced ? g_conv_force.p0 : (ch.kind == 4 ? ch.p0 : 2);
+            r.wide = forced ? g_conv_force.p1 : (ch.kind == 4 ? ch.p1 : 0);
+            if (o.k == 1 && r.nt > 3) r.nt = a.ntiles == 4 ? 2 : 3;   // conv_s4 1x1: 4 cout tiles leave one workgroup per CU
+            bool res_fits = true;
+            if (a.res) {
+                const int nt1 = r.nt < 1 ? 1 : (r.nt > a.ntiles ? a.ntiles : r.nt);
+                res_fits = (size_t)nt1 * 16 * res_chan_stride(res_extent(8, a.res_sh), res_extent(32, a.res_sw)) * sizeof(float) <= 64 * 1024;
+            }
+            r.can_read = s4_allowed && !generic && o.stride == 1 && o.kind == OP_CONV && p->conv[i].has_s4 && (need == 0 || o.k == 1) && want &&
+                         res_fits && ((a.src_begin == 0 && a.src_end == a.n_src) || p->conv[i].s4_pad);
+            r.can_write_s4 = s4_allowed && !generic && (a.dst_choff & 1) == 0;
+            r.can_write = r.can_write_s4 && (ch.kind == 1 || ch.kind == 4);
+            // channel bookkeeping of the destination: zero-fill the tail of the last group unless its owner wrote it already
+            std::vector<uint8_t> &wr = written[mt.dst_t];
+            const int lo = a.dst_choff, hi = a.dst_choff + a.Cout;
+            if ((lo & 3) == 2 && !wr[lo - 2]) cand[mt.dst_t] = 0;   // would expose an unwritten half group to readers of this range
+            r.dst_limit = ((hi & 3) != 0 && !wr[hi]) ? (hi + 3) / 4 * 4 : hi;
+            for (int c = lo; c < hi; ++c) wr[c] = 1;
+            recs.push_back(r);
+            return PF_OK;
+        }
+        const ConvRec &rec = recs[rec_i++];
+        a.dst_fmt = fmt[rec.dst_t];
+        a.dst_c4 = (a.dst_ctotal + 3) / 4;
+        a.dst_limit = rec.dst_limit;
+        bool read_s4 = rec.can_read;
+        for (int j = rec.sb; j < rec.se; ++j) read_s4 = read_s4 && fmt[rec.src_t[j]];
+        if (read_s4) {
+            const int per = o.k == 3 ? 2 : 8;
+            int e = 0;
+            for (int j = 0; j < a.n_src; ++j) {
+                const int ch0 = a.src_choff[j], chn = a.src_cstart[j + 1] - a.src_cstart[j];
+                a.src_c4[j] = (a.src_ctotal[j] + 3) / 4;
+                a.src_g0[j] = ch0 / 4;
+                a.src_gn[j] = (ch0 + chn + 3) / 4 - ch0 / 4;
+                a.src_ent0[j] = e;
+                e += p->conv[i].s4_pad ? (a.src_gn[j] + per - 1) / per * per : a.src_gn[j];
+            }
+            for (int j = a.n_src; j <= kConvMaxSrc; ++j) a.src_ent0[j] = e;
+            a.src_fmt = 1;
+            a.wpk = p->dev_weights + p->conv[i].s4_off;
+            a.nchunks = p->conv[i].s4_rounds;
+            a.chunk_begin = a.src_ent0[a.src_begin] / per;
+            a.chunk_end = (a.src_ent0[a.src_end] + per - 1) / per;
+            return launch_conv_s4(a, (int)o.k, rec.nt, rec.wide, B, s);
+        }
+        if (generic) {
             if (need) return fail(PF_EUNSUPPORTED, "fused conv on a width that is not a multiple of 4");
             a.wpk = p->dev_weights + p->conv[i].wpk_off;
             a.nchunks = p->conv[i].tiling.nchunks;
             return launch_conv(a, p->conv[i].tiling, B, s);
         }
-        ConvChoice ch = choose_conv((int)o.k, (int)o.stride, a.Cin, a.Cout, a.Hout, a.Wout, p->opt_table_batch > 0 ? p->opt_table_batch : B, need,
-                                    p->opt_use_tuned);
-        if (g_conv_force.kind == 2 && o.stride == 1) {
-            ch = g_conv_force;
-            if ((need & 2) && ch.p0 == 1) ch.p0 = 2;
-        }
-        if (g_conv_force.kind == 1) ch = g_conv_force;
-        if (g_conv_force.kind == 3 && p->conv[i].has_valu && !need) ch = g_conv_force;
-        if (g_conv_force.kind == 4 && p->conv[i].has_split && (!need || o.k == 1)) ch = g_conv_force;
-        if (ch.kind == 4 && (!p->conv[i].has_split || (need && o.k != 1) || !p->opt_split_bf16)) ch = ConvChoice{1, 0, 0, 0};
-        if (ch.kind == 3 && (!p->conv[i].has_valu || need)) ch = ConvChoice{1, 0, 0, 0};
         int rc = PF_EUNSUPPORTED;
         auto set_chunks = [&](int kc) {
             a.src_chunk0[0] = 0;
@@ -238,7 +337,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             // the trailing rem_count output channels of a big image go to the vector ALU instead of an MFMA tile
             // (conv_dma WM=4 shapes only: forced or cost-model-chosen WM is checked inside, which falls back)
             a.rem = 0;
-            if (p->opt_valu_rem && p->conv[i].rem_off && !need && a.src_begin == 0 && a.src_end == a.n_src &&
+            if (p->opt_valu_rem && p->conv[i].rem_off && !need && !a.dst_fmt && a.src_begin == 0 && a.src_end == a.n_src &&
                 (ch.p0 == 0 || ch.p0 == 4)) {
                 a.rem = p->conv[i].rem_count;
                 a.wrem = p->dev_weights + p->conv[i].rem_off;
@@ -265,20 +364,29 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
     };
 
     static const bool sync_ops = getenv("PF_SYNC_OPS") != nullptr;   // debugging: localise a faulting launch
+    cand[input] = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+    dry = pass == 0;
     for (size_t i = 0; i < p->ops.size(); ++i) {
-        if (sync_ops) {
+        if (sync_ops && !dry) {
             const hipError_t e = hipStreamSynchronize(s);
             fprintf(stderr, "[pf] before op %zu (%s): %s\n", i, p->tensors[p->ops[i].dst].name, hipGetErrorString(e));
         }
         const BlobOp &o = p->ops[i];
         const Dims in = d[o.src[0].tensor];
         const Dims out = o.kind == OP_HEAD ? in : d[o.dst];
-        if (tag_ops && prof_enabled()) {
+        if (tag_ops && prof_enabled() && !dry) {
             char tag[96];
             snprintf(tag, sizeof(tag), "%02zu %s %u->%u %dx%d", i, p->tensors[o.dst].name, o.cin, o.cout, out.h, out.w);
             prof_set_tag(tag);
         }
+        // ops executed by kernels that only know fp32 NCHW pin their tensors to it
+        auto pin_fp32 = [&](const BlobOp &op) {
+            for (uint32_t j = 0; j < op.n_src; ++j) cand[op.src[j].tensor] = 0;
+            cand[op.dst] = 0;
+        };
         if (o.kind == OP_STEM && stem) {
+            if (dry) { pin_fp32(o); continue; }
             StemArgs a = *stem;
             a.w = p->dev_weights + p->conv[i].raw_off;
             a.wdep = p->dev_weights + p->conv[i].dep_off;
@@ -305,26 +413,33 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                 p->readers[o.dst] == 1 && out.h >= 2 && out.w >= 2)
                 pool = &p->ops[i + 1];
             ConvArgs a;
-            fill_conv_args(o, i, in, out, a);
+            ConvMeta mt;
+            fill_conv_args(o, i, in, out, a, mt);
             if (pool) {
                 a.pool = 1;
                 a.dst = tptr(pool->dst);
+                mt.dst_t = pool->dst;
                 a.dst_ctotal = (int)p->tensors[pool->dst].channels;
             }
-            if ((rc = launch_conv_op(o, i, a, pool ? 2 : 0))) return rc;
+            if ((rc = launch_conv_op(o, i, a, mt, pool ? 2 : 0))) return rc;
             if (pool) ++i;   // the pool op is done
         } else if (o.kind == OP_POOL) {
+            if (dry) { pin_fp32(o); continue; }
             if ((rc = launch_avgpool2(tptr(o.src[0].tensor), tptr(o.dst), B * (int)o.cin, in.h, in.w, s))) return rc;
         } else if (o.kind == OP_UPSAMPLE && can_commute_upsample(i, in, out)) {
             // TransitionUp + 1x1 conv over cat([up(x), skip])  ==  W_skip*skip + up(W_x*x)   (conv_epilogue.h)
             const BlobOp &n = p->ops[i + 1];
             const Dims hi = out;   // = size of the skip tensor
             ConvArgs lo;
-            fill_conv_args(n, i + 1, in, in, lo);
+            ConvMeta lo_mt;
+            fill_conv_args(n, i + 1, in, in, lo, lo_mt);
             lo.src[0] = tptr(o.src[0].tensor);                 // x at the low resolution
+            lo_mt.src_t[0] = o.src[0].tensor;
             lo.src_ctotal[0] = (int)p->tensors[o.src[0].tensor].channels;
             lo.src_choff[0] = (int)o.src[0].choff;
             lo.dst = tptr(o.dst);                              // scratch: the slot of the (never built) upsampled tensor
+            lo_mt.dst_t = o.dst;
+            if (dry) cand[o.dst] = 0;                          // sampled as an fp32 residual by the other half
             lo.dst_ctotal = (int)n.cout;
             lo.dst_choff = 0;
             lo.relu = 0;
@@ -333,17 +448,18 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             lo.src_begin = 0;
             lo.src_end = 1;
             auto tag_half = [&](const char *half, int cin, const Dims &dd) {
-                if (!(tag_ops && prof_enabled())) return;
+                if (!(tag_ops && prof_enabled()) || dry) return;
                 char tag[96];
                 snprintf(tag, sizeof(tag), "%02zu%c %s.%s %d->%u %dx%d", i + 1, half[0] == 'l' ? 'a' : 'b', p->tensors[n.dst].name,
                          half, cin, n.cout, dd.h, dd.w);
                 prof_set_tag(tag);
             };
             tag_half("lo", lo.Cin, in);
-            if ((rc = launch_conv_op(n, i + 1, lo, 4))) return rc;
-            if (sync_ops) fprintf(stderr, "[pf]   low-resolution half: %s\n", hipGetErrorString(hipStreamSynchronize(s)));
+            if ((rc = launch_conv_op(n, i + 1, lo, lo_mt, 4))) return rc;
+            if (sync_ops && !dry) fprintf(stderr, "[pf]   low-resolution half: %s\n", hipGetErrorString(hipStreamSynchronize(s)));
             ConvArgs hi_a;
-            fill_conv_args(n, i + 1, hi, hi, hi_a);
+            ConvMeta hi_mt;
+            fill_conv_args(n, i + 1, hi, hi, hi_a, hi_mt);
             hi_a.Cin = (int)n.src[1].ch;
             hi_a.src_begin = 1;
             hi_a.src_end = 2;
@@ -355,12 +471,14 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             hi_a.Wres = in.w;
             hi_a.res_sh = hi.h > 1 ? (float)(in.h - 1) / (float)(hi.h - 1) : 0.f;
             hi_a.res_sw = hi.w > 1 ? (float)(in.w - 1) / (float)(hi.w - 1) : 0.f;
-            if ((rc = launch_conv_op(n, i + 1, hi_a, 4))) return rc;
+            if ((rc = launch_conv_op(n, i + 1, hi_a, hi_mt, 4))) return rc;
             ++i;   // the 1x1 conv is done
         } else if (o.kind == OP_UPSAMPLE) {
+            if (dry) { pin_fp32(o); continue; }
             if ((rc = launch_upsample(tptr(o.src[0].tensor), tptr(o.dst), B * (int)o.cin, in.h, in.w, out.h, out.w, s)))
                 return rc;
         } else if (o.kind == OP_HEAD) {
+            if (dry) { pin_fp32(o); continue; }
             HeadArgs a;
             a.logits = tptr(o.src[0].tensor);
             a.out_seg = out_seg; a.out_logits = out_logits; a.out_is_i64 = out_seg_is_i64;
@@ -370,6 +488,29 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                                             hipMemcpyDeviceToDevice, s));
             if ((rc = launch_head(a, s))) return rc;
         }
+    }
+    if (dry) {
+        // fixpoint: a launch reads S4 only if ALL the ranges it accumulates are S4; a tensor stays S4 only while all its
+        // readers do and all its writers can
+        if (!s4_allowed) std::fill(cand.begin(), cand.end(), 0);
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (const ConvRec &r : recs) {
+                bool all = r.can_read;
+                for (int j = r.sb; j < r.se; ++j) all = all && cand[r.src_t[j]];
+                if (!all)
+                    for (int j = r.sb; j < r.se; ++j)
+                        if (cand[r.src_t[j]]) { cand[r.src_t[j]] = 0; changed = true; }
+                if (!(r.can_write || (all && r.can_write_s4)) && cand[r.dst_t]) { cand[r.dst_t] = 0; changed = true; }
+            }
+        }
+        // a tensor nobody reads as S4 (network outputs tapped by the caller) stays fp32
+        std::vector<uint8_t> read_s4(nT, 0);
+        for (const ConvRec &r : recs)
+            for (int j = r.sb; j < r.se; ++j) read_s4[r.src_t[j]] = 1;
+        for (size_t t = 0; t < nT; ++t) fmt[t] = cand[t] && read_s4[t];
+        p->last_fmt = fmt;
+    }
     }
     if (tag_ops) prof_set_tag(nullptr);
     return PF_OK;
@@ -392,7 +533,7 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
         return fail(PF_EINVAL, "blob is for in_ch=%u n_cls=%u, caller asked for %d/%d", h.in_ch, h.n_cls, in_ch, n_cls);
     pf_plan *p = new pf_plan();
     p->opt_fuse_pool = g_opt_fuse_pool; p->opt_fuse_upsample = g_opt_fuse_upsample; p->opt_valu_rem = g_opt_valu_rem;
-    p->opt_split_bf16 = g_opt_split_bf16; p->opt_use_tuned = g_opt_use_tuned;
+    p->opt_split_bf16 = g_opt_split_bf16; p->opt_use_tuned = g_opt_use_tuned; p->opt_packed_acts = g_opt_packed_acts;
     p->hdr = h;
     p->tensors.resize(h.n_tensors);
     p->ops.resize(h.n_ops);
@@ -473,6 +614,23 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
             c.has_split = true;
             host.resize(host.size() + split1_packed_floats(src_ch, (int)o.n_src, (int)o.cout));
             pack_conv_weights_split1(wts + o.w_off, (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, host.data() + c.split_off);
+        }
+        if (o.stride == 1 && o.kind == OP_CONV) {
+            S4Range rg[kMaxSrc];
+            bool even = true;
+            for (uint32_t j = 0; j < o.n_src; ++j) {
+                rg[j] = S4Range{(int)o.src[j].choff, (int)o.src[j].ch};
+                even = even && (o.src[j].choff & 1) == 0;
+            }
+            if (even) {
+                c.s4_pad = o.k == 1 && o.n_src == 2;
+                host.resize(align_up(host.size(), 16), 0.f);
+                c.s4_off = host.size();
+                c.s4_rounds = s4_rounds(rg, (int)o.n_src, (int)o.k, c.s4_pad);
+                c.has_s4 = true;
+                host.resize(host.size() + s4_packed_floats(rg, (int)o.n_src, (int)o.cout, (int)o.k, c.s4_pad));
+                pack_conv_weights_s4(wts + o.w_off, (int)o.cin, (int)o.cout, (int)o.k, rg, (int)o.n_src, c.s4_pad, host.data() + c.s4_off);
+            }
         }
         if (o.k == 3 && o.stride == 1 && conv_valu_supports((int)o.cout)) {
             host.resize(align_up(host.size(), 16), 0.f);
@@ -600,6 +758,30 @@ extern "C" int pf_hardnet_tensor_view(const pf_plan *p, const char *name, int B,
         }
     }
     return fail(PF_EINVAL, "no tensor named '%s'", name);
+}
+
+extern "C" int pf_hardnet_tensor_read(const pf_plan *p, const char *name, int B, int H, int W, const void *ws, float *dst,
+                                      void *stream) {
+    if (!p || !name || !ws || !dst) return fail(PF_EINVAL, "pf_hardnet_tensor_read: null");
+    size_t off;
+    int c, h, w;
+    int rc = pf_hardnet_tensor_view(p, name, B, H, W, &off, &c, &h, &w);
+    if (rc) return rc;
+    size_t t = 0;
+    while (strncmp(p->tensors[t].name, name, sizeof(p->tensors[t].name)) != 0) ++t;
+    const char *src = (const char *)ws + off;
+    if (t < p->last_fmt.size() && p->last_fmt[t]) return launch_s4_unpack(src, dst, B, c, h, w, (hipStream_t)stream);
+    PF_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)B * c * h * w * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PF_OK;
+}
+
+extern "C" int pf_s4_pack(const float *src, void *dst, int B, int C, int H, int W, void *stream) {
+    if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(PF_EINVAL, "pf_s4_pack: bad argument");
+    return launch_s4_pack(src, dst, B, C, H, W, (hipStream_t)stream);
+}
+extern "C" int pf_s4_unpack(const void *src, float *dst, int B, int C, int H, int W, void *stream) {
+    if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(PF_EINVAL, "pf_s4_unpack: bad argument");
+    return launch_s4_unpack(src, dst, B, C, H, W, (hipStream_t)stream);
 }
 
 extern "C" int pf_hardnet_flops(const pf_plan *p, int H, int W, double *flops) {

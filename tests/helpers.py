@@ -87,8 +87,12 @@ def view_tensor(plan, ws, name, b, h, w):
     off, c, th, tw = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     _lib.check(L.pf_hardnet_tensor_view(plan, name.encode(), b, h, w, ctypes.byref(off), ctypes.byref(c),
                                         ctypes.byref(th), ctypes.byref(tw)), 'pf_hardnet_tensor_view')
-    n = b * c.value * th.value * tw.value
-    return ws[off.value:off.value + 4 * n].view(torch.float32).view(b, c.value, th.value, tw.value)
+    out = torch.empty(b, c.value, th.value, tw.value, dtype=torch.float32, device=ws.device)
+    # fp32 copy of the tensor whatever layout the last forward kept it in (packed-pair tensors: hi + mid)
+    _lib.check(L.pf_hardnet_tensor_read(plan, name.encode(), b, h, w, ws.data_ptr(), out.data_ptr(), _lib.stream_ptr()),
+               'pf_hardnet_tensor_read')
+    torch.cuda.synchronize()
+    return out
 
 
 class MiniTrain:

@@ -321,3 +321,121 @@ def test_split_bf16_fused_pool_and_commuted_upsample(h, w, b, nt, fuse_upsample,
     assert (net.tensor('c3').cpu() - r3).abs().max() <= _tol_split(r3)
     assert (net.tensor('c4').cpu() - r4).abs().max() <= 2 * _tol_split(r4)
     net.close()
+
+
+# ---- packed-pair ("S4") activation layout: conv_s4.hip ---------------------------------------------------------------
+def test_s4_layout_round_trip():
+    """pf_s4_pack / pf_s4_unpack: [B][2][ceil(C/4)][H][W][4] bf16, hi = bf16(x) (round to nearest even), mid = bf16(x - hi)."""
+    import ctypes
+    from panoptic_forecasting_amd import lib as pflib
+    L = pflib.load()
+    g = torch.Generator().manual_seed(3)
+    b, c, h, w = 2, 10, 6, 8
+    x = (torch.randn(b, c, h, w, generator=g) * torch.exp(3 * torch.randn(b, c, 1, 1, generator=g))).cuda()
+    c4 = (c + 3) // 4
+    packed = torch.zeros(b, 2, c4, h, w, 4, dtype=torch.bfloat16, device='cuda')
+    pflib.check(L.pf_s4_pack(x.data_ptr(), packed.data_ptr(), b, c, h, w, pflib.stream_ptr()), 'pf_s4_pack')
+    back = torch.empty_like(x)
+    pflib.check(L.pf_s4_unpack(packed.data_ptr(), back.data_ptr(), b, c, h, w, pflib.stream_ptr()), 'pf_s4_unpack')
+    torch.cuda.synchronize()
+    xp = torch.zeros(b, c4 * 4, h, w, device='cuda')
+    xp[:, :c] = x
+    hi = xp.to(torch.bfloat16)
+    mid = (xp - hi.float()).to(torch.bfloat16)
+    want = torch.stack([hi, mid], 1).view(b, 2, c4, 4, h, w).permute(0, 1, 2, 4, 5, 3).contiguous()
+    assert torch.equal(packed.view(torch.int16), want.view(torch.int16))
+    assert torch.equal(back, hi.float()[:, :c] + mid.float()[:, :c])
+    assert ((back - x).abs() <= 2.0 ** -16 * x.abs()).all()
+
+
+def _block_net(g, cin0):
+    """A HarDBlock-shaped little network (hardnet.py:220-240 wiring: slots of a concatenated output tensor at channel offsets
+    0 / 10 / 20, an own tensor for the even layer), a pooled transition, a commuted upsample and a final conv."""
+    from helpers import MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    S = arch.Src
+    spec = MiniSpec(cin0)
+    t0 = spec.conv('t0', [S(0, 0, cin0)], 20, 3)
+    out = spec.tensor('out', 48)
+    spec.conv('L1', [S(t0, 0, 20)], 10, 3, dst=out, dst_choff=0)
+    l2 = spec.conv('L2', [S(out, 0, 10), S(t0, 0, 20)], 18, 3)
+    spec.conv('L3', [S(l2, 0, 18)], 10, 3, dst=out, dst_choff=10)
+    spec.conv('L4', [S(out, 10, 10), S(l2, 0, 18), S(t0, 0, 20)], 28, 3, dst=out, dst_choff=20)
+    c5 = spec.conv('c5', [S(out, 0, 48)], 24, 1)
+    p = spec.pool('p', c5)
+    c6 = spec.conv('c6', [S(p, 0, 24)], 40, 3)
+    up = spec.upsample('up', c6, out)
+    c7 = spec.conv('c7', [S(up, 0, 40), S(out, 0, 48)], 37, 1)
+    spec.conv('c8', [S(c7, 0, 37)], 11, 3, relu=False)
+    shapes = [('t0', cin0, 20, 3), ('L1', 20, 10, 3), ('L2', 30, 18, 3), ('L3', 18, 10, 3), ('L4', 48, 28, 3), ('c5', 48, 24, 1),
+              ('c6', 24, 40, 3), ('c7', 88, 37, 1), ('c8', 37, 11, 3)]
+    P = {n: (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5, torch.randn(co, generator=g)) for n, ci, co, k in shapes}
+    return spec, P
+
+
+def _block_ref(x, P, h, w):
+    D = {k: (v[0].double(), v[1].double()) for k, v in P.items()}
+    x = x.double()
+    t0 = F.relu(F.conv2d(x, *D['t0'], padding=1))
+    l1 = F.relu(F.conv2d(t0, *D['L1'], padding=1))
+    l2 = F.relu(F.conv2d(torch.cat([l1, t0], 1), *D['L2'], padding=1))
+    l3 = F.relu(F.conv2d(l2, *D['L3'], padding=1))
+    l4 = F.relu(F.conv2d(torch.cat([l3, l2, t0], 1), *D['L4'], padding=1))
+    out = torch.cat([l1, l3, l4], 1)
+    p = F.avg_pool2d(F.relu(F.conv2d(out, *D['c5'])), 2, 2)
+    c6 = F.relu(F.conv2d(p, *D['c6'], padding=1))
+    c7 = F.relu(F.conv2d(torch.cat([F.interpolate(c6, size=(h, w), mode='bilinear', align_corners=True), out], 1), *D['c7']))
+    c8 = F.conv2d(c7, *D['c8'], padding=1)
+    return {'t0': t0, 'L2': l2, 'out': out, 'p': p, 'c6': c6, 'c7': c7, 'c8': c8}
+
+
+@pytest.mark.parametrize('nt,wide', [(1, 0), (2, 0), (3, 0), (1, 1), (2, 1)])
+@pytest.mark.parametrize('h,w,b', [(16, 64, 2), (24, 40, 1), (34, 136, 1)])
+def test_packed_activation_block(h, w, b, nt, wide, force_conv):
+    """Every tensor between the first and the last conv lives in the packed-pair layout; the S4 3x3 kernel (LDS-DMA halo
+    tiles, slots of a shared output tensor at offsets that are not multiples of 4, zero-filled group tails) and the S4 1x1
+    kernel (plain, pooled, low-resolution half, upsampled residual) against float64 torch.  Tolerance per layer as for
+    conv_split (2e-4 (1 + max|ref|)), 3x that after the chain of 6."""
+    from helpers import MiniNet
+    from panoptic_forecasting_amd import lib as pflib
+    g = torch.Generator().manual_seed(h * 3 + w + nt)
+    x = torch.randn(b, 12, h, w, generator=g) * torch.exp(torch.randn(b, 12, 1, 1, generator=g))
+    spec, P = _block_net(g, 12)
+    force_conv(5, nt, wide, 0)
+    pflib.profile(True)
+    net = MiniNet(spec, P).run(x.cuda())
+    labels = [r['label'] for r in pflib.profile_results()]
+    pflib.profile(False)
+    assert sum('conv_s4_kernel' in l for l in labels) >= 1, labels
+    for tag in ('+pool', '+res', 'lowres-half'):
+        assert any('conv_s4_1x1_kernel' in l and tag in l for l in labels), (tag, labels)
+    ref = _block_ref(x, P, h, w)
+    for name, scale in [('t0', 1), ('L2', 1), ('out', 2), ('p', 2), ('c6', 3), ('c7', 3), ('c8', 3)]:
+        r = ref[name].float()
+        err = (net.tensor(name).cpu() - r).abs().max().item()
+        assert err <= scale * _tol_split(r), (name, err, _tol_split(r))
+    net.close()
+
+
+def test_packed_activations_off_is_fp32_layout(force_conv):
+    """pf_set_option('packed_acts', 0): the same network, no S4 kernel launched, same results within the split tolerance."""
+    from helpers import MiniNet
+    from panoptic_forecasting_amd import lib as pflib
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 12, 16, 64, generator=g)
+    spec, P = _block_net(g, 12)
+    L = pflib.load()
+    pflib.check(L.pf_set_option(b'packed_acts', 0), 'pf_set_option')
+    try:
+        pflib.profile(True)
+        net = MiniNet(spec, P).run(x.cuda())
+        labels = [r['label'] for r in pflib.profile_results()]
+        pflib.profile(False)
+    finally:
+        pflib.check(L.pf_set_option(b'packed_acts', 1), 'pf_set_option')
+    assert not any('conv_s4' in l for l in labels), labels
+    ref = _block_ref(x, P, 16, 64)
+    for name in ('out', 'c7', 'c8'):
+        r = ref[name].float()
+        assert (net.tensor(name).cpu() - r).abs().max().item() <= 3 * _tol_split(r)
+    net.close()
