@@ -35,6 +35,8 @@ struct ConvArgs {
     int res_ctotal, res_choff, Hres, Wres;
     float res_sh, res_sw;    // (Hres-1)/(Hout-1), (Wres-1)/(Wout-1)
     int res_lds_off;         // float offset of the staged residual window in the kernel's LDS, or -1: sample from memory
+    int res_rows, res_cols;  // conv_s4 1x1: fixed window size per channel (upper bounds of what a tile touches)
+    unsigned res_magic_cs, res_magic_cols;   // ... and 2^32 / d + 1 of its channel stride and its columns (lane index -> element)
     const float *wrem;       // conv_dma remainder path: weights of the last `rem` couts, [chunk][kgroup][tap][RV][4 ch]
     int rem;                 // > 0: couts handled on the vector ALU; ntiles then counts FULL 16-cout tiles only
     int src_begin, src_end;      // input ranges to accumulate (whole conv: 0, n_src)
@@ -147,6 +149,7 @@ struct ConvChoice {
 };
 // need: bit 1 = even tile rows if conv_wave is chosen (pooling epilogue)
 ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B, int need = 0, int use_tuned = 1);
+bool choose_s4(int ks, int cin, int cout, int hout, int wout, int B, ConvChoice *out);   // conv_s4 table row, if any
 long long *probe_buffer();
 // tuning hook (pf_debug_force_conv): kind 0 = automatic
 extern ConvChoice g_conv_force;

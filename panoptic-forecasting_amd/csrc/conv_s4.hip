@@ -29,6 +29,15 @@
 #include "conv_epilogue.h"
 #include "pf_prof.h"
 
+#ifndef PF_PROBE
+#define PF_PROBE 0
+#endif
+#if PF_PROBE   // shader-clock stamps of one workgroup in the middle of the grid (tools/probe_s4.py)
+#define S4_PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2 && a.probe && (i) < 60) a.probe[i] = clock64(); } while (0)
+#else
+#define S4_PROBE(i) do { } while (0)
+#endif
+
 namespace pf {
 
 typedef float s4_f32x4 __attribute__((ext_vector_type(4)));
@@ -42,7 +51,7 @@ __device__ __forceinline__ s4_bf16x8 s4_join(s4_bf16x4 lo, s4_bf16x4 hi) {
 }
 
 // group entry e of the conv's K order -> (source tensor frame base, byte offset of the hi plane of its group); all scalar
-__device__ __forceinline__ void s4_entry(const ConvArgs &a, int e, int b, size_t plane_bytes, const char *&base, unsigned &goff,
+__device__ __forceinline__ bool s4_entry(const ConvArgs &a, int e, int b, size_t plane_bytes, const char *&base, unsigned &goff,
                                          unsigned &term_stride) {
     const float *sp = a.src[0];
     int c4 = a.src_c4[0], g0 = a.src_g0[0], gn = a.src_gn[0], e0 = 0;
@@ -55,10 +64,12 @@ __device__ __forceinline__ void s4_entry(const ConvArgs &a, int e, int b, size_t
         gn = take ? a.src_gn[k] : gn;
         e0 = take ? a.src_ent0[k] : e0;
     }
-    // entries past the groups of their range (round padding) have zero weights: they re-read the range's last group
+    // entries past the groups of their range (round padding) have zero weights; the caller fetches nothing for them
+    // (out-of-range pieces land as zeros), the address stays inside the tensor anyway
     base = reinterpret_cast<const char *>(sp) + (size_t)b * 2 * c4 * plane_bytes;
     goff = (unsigned)(g0 + min(e - e0, gn - 1)) * (unsigned)plane_bytes;
     term_stride = (unsigned)c4 * (unsigned)plane_bytes;
+    return e - e0 < gn;
 }
 
 template <int NT, int TW_>
@@ -122,38 +133,56 @@ __global__ __launch_bounds__(256) void conv_s4_kernel(ConvArgs a) {
         for (int s = 0; s < 3; ++s) aoff[s] = ((wave * 2 + ky[s]) * C::IW + (lane & 15) + kx[s] + 1) * 8;
     }
 
-    float biasv[NT];
+    // operand roles are swapped with respect to conv_split.hip (weights = A, pixels = B): the D fragment of lane (g, i) is
+    // couts 4g .. 4g+3 of pixel i = one 8-B unit of the packed layout per term, no cross-lane traffic in the epilogue
+    s4_f32x4 bias4[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) biasv[n] = epi_bias(a, (tile0 + n) * 16 + (lane & 15));
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[n][r] = epi_bias(a, (tile0 + n) * 16 + (lane >> 4) * 4 + r);
 
     const int cb = a.chunk_begin, nrounds = a.chunk_end - cb;
-    auto issue_round = [&](int r, int stage) {
+    // The DMA instructions of the next stage are issued in UNITS parts between the matrix units of the current one (a part =
+    // one activation piece + its share of the weight pieces): issued in one block they cost the wave ~1000 clocks per
+    // round in which it feeds no MFMA (tools/probe_s4.py).
+    constexpr int HALVES = C::MP / 4, UNITS = 3 * HALVES;
+    static_assert(C::NDMA == UNITS, "one activation DMA instruction per matrix unit");
+    __amdgpu_buffer_rsrc_t ars;
+    unsigned asoff = 0;
+    bool areal = true;
+    auto prepare_round = [&](int r) {
         // activations: wave w fetches plane (term = w >> 1, entry = 2 (cb + r) + (w & 1))
-        const int e = 2 * (cb + r) + (wave & 1);
         const char *base;
         unsigned goff, tstride;
-        s4_entry(a, e, b, plane_bytes, base, goff, tstride);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7FFFFFFF, 0x00020000);
-        const unsigned soff = goff + (unsigned)(wave >> 1) * tstride;
-        unsigned char *dst = abuf(stage) + wave * C::PLANE;
-#pragma unroll
-        for (int j = 0; j < C::NDMA; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (s4_lds_ptr_t)(dst + j * 1024), 16, poff[j], soff, 0, 0);
+        areal = s4_entry(a, 2 * (cb + r) + (wave & 1), b, plane_bytes, base, goff, tstride);
+        ars = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7FFFFFFF, 0x00020000);
+        asoff = goff + (unsigned)(wave >> 1) * tstride;
+    };
+    auto issue_part = [&](int r, int stage, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (s4_lds_ptr_t)(abuf(stage) + wave * C::PLANE + j * 1024), 16,
+                                                 areal ? poff[j] : kS4Oob, asoff, 0, 0);
         unsigned char *wdst = wbuf(stage);
 #pragma unroll
-        for (int it = 0; it < C::NITW; ++it)
+        for (int it = j; it < C::NITW; it += UNITS)
             if (it * 256 + tid < C::WPIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (s4_lds_ptr_t)(wdst + (it * 256 + wave * 64) * 16), 16, woff[it],
                                                          (unsigned)(cb + r) * (3 * 2 * 64 * 16), 0, 0);
     };
 
-    if (nrounds > 0) issue_round(0, 0);
+    if (nrounds > 0) {
+        prepare_round(0);
+#pragma unroll
+        for (int j = 0; j < UNITS; ++j) issue_part(0, 0, j);
+    }
     for (int round = 0; round < nrounds; ++round) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
+        S4_PROBE(round * 4 + 0);
         __syncthreads();                                    // everyone's have, and everyone is done reading the other stage
-        if (round + 1 < nrounds) issue_round(round + 1, (round + 1) & 1);
+        S4_PROBE(round * 4 + 1);
+        const bool more = round + 1 < nrounds;
+        if (more) prepare_round(round + 1);
+        S4_PROBE(round * 4 + 2);
         const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
-        constexpr int HALVES = C::MP / 4, UNITS = 3 * HALVES;
         s4_bf16x8 fa_h[2][4], fa_m[2][4], fb_h[2][NT], fb_m[2][NT];
         auto fetch = [&](int u, int set) {
             const int s = u / HALVES, m0 = (u % HALVES) * 4;
@@ -179,40 +208,84 @@ __global__ __launch_bounds__(256) void conv_s4_kernel(ConvArgs a) {
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_m[set][m], fb_h[set][n], acc[m0 + m][n], 0, 0, 0);
+                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_h[set][n], fa_m[set][m], acc[m0 + m][n], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[set][m], fb_m[set][n], acc[m0 + m][n], 0, 0, 0);
+                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_m[set][n], fa_h[set][m], acc[m0 + m][n], 0, 0, 0);
+            if (more) issue_part(round + 1, (round + 1) & 1, u);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[set][m], fb_h[set][n], acc[m0 + m][n], 0, 0, 0);
+                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_h[set][n], fa_h[set][m], acc[m0 + m][n], 0, 0, 0);
         }
+        S4_PROBE(round * 4 + 3);
     }
+    S4_PROBE(58);
 
-    // ---- epilogue: bias + ReLU; fp32 NCHW float4 stores or S4 units (conv_epilogue.h)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int co = (tile0 + n) * 16 + (lane & 15);
-        if (epi_skip(a, co)) continue;
+    // ---- epilogue: bias + ReLU; lane (g, i) = couts 4g..4g+3 of pixel i: one packed unit per term, or 4 fp32 NCHW elements
+    {
+        const int g = lane >> 4, px = lane & 15;
+        const size_t hw = (size_t)a.Hout * a.Wout;
+        const size_t term = (size_t)a.dst_c4 * hw * 8;
+        const bool mis = (a.dst_choff & 2) != 0;   // the range starts in the middle of a group (uniform)
 #pragma unroll
         for (int m = 0; m < C::MP; ++m) {
             const int mt = wave * C::MP + m;
             const int oy = tileY * C::TH + mt / C::MTR;
-            const int ox = tileX * C::TW + (mt % C::MTR) * 16 + (lane >> 4) * 4;
+            const int ox = tileX * C::TW + (mt % C::MTR) * 16 + px;
             if (oy >= a.Hout || ox >= a.Wout) continue;
-            s4_f32x4 v = acc[m][n];
+            const size_t pix = (size_t)oy * a.Wout + ox;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] += biasv[n];
-                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+            for (int n = 0; n < NT; ++n) {
+                const int co = (tile0 + n) * 16 + 4 * g;
+                if (co >= a.Cout + 2) continue;                      // nothing of this unit is stored (limit <= Cout + 2)
+                s4_f32x4 v = acc[m][n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] += bias4[n][r];
+                    if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (a.dst_fmt) {
+                    s4_bf16x4 hi, mid;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        hi[r] = (__bf16)v[r];
+                        mid[r] = (__bf16)(v[r] - (float)hi[r]);
+                    }
+                    const int chb = a.dst_choff + co;
+                    const bool ok0 = chb < a.dst_limit, ok1 = chb + 2 < a.dst_limit;
+                    char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
+                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                    if (!mis) {
+                        if (ok1) {
+                            *reinterpret_cast<s4_bf16x4 *>(p) = hi;
+                            *reinterpret_cast<s4_bf16x4 *>(p + term) = mid;
+                        } else if (ok0) {
+                            *reinterpret_cast<bf2 *>(p) = bf2{hi[0], hi[1]};
+                            *reinterpret_cast<bf2 *>(p + term) = bf2{mid[0], mid[1]};
+                        }
+                    } else {   // upper half of one group, lower half of the next
+                        if (ok0) {
+                            *reinterpret_cast<bf2 *>(p + 4) = bf2{hi[0], hi[1]};
+                            *reinterpret_cast<bf2 *>(p + 4 + term) = bf2{mid[0], mid[1]};
+                        }
+                        if (ok1) {
+                            *reinterpret_cast<bf2 *>(p + hw * 8) = bf2{hi[2], hi[3]};
+                            *reinterpret_cast<bf2 *>(p + hw * 8 + term) = bf2{mid[2], mid[3]};
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < a.Cout) a.dst[((size_t)b * a.dst_ctotal + a.dst_choff + co + r) * hw + pix] = v[r];
+                }
             }
-            epi_store(a, b, co, oy, ox, v);
         }
     }
+    S4_PROBE(59);
 #endif
 }
 
@@ -239,18 +312,25 @@ static int launch_s4_cfg(const ConvArgs &a0, int B, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 1x1: one round = 8 group entries (32 channels) of an 8x32-pixel tile; stage = [term][entry 8][256 pixels][4 ch], planes
-// 2112 B apart (2 planes = 128 B mod 256: the lane groups g, g+1 of a ds_read_b64 pass, which read entries 2g and 2g+2,
-// hit disjoint banks).  Wave w fetches the planes (term = w >> 1, entries 4 (w & 1) .. +3), two DMA instructions each.
+// 1x1: a streaming kernel (these layers are bound by their bytes: 2*Cin*Cout flops per pixel against 4*(Cin+Cout) bytes).
+// One round = 8 group entries (32 channels); lane group g of an instruction supplies entries 2g and 2g+1.  The activation
+// fragments come STRAIGHT from memory into registers - in the packed layout a 16-B load is [2 pixels][4 channels] of one
+// term, which is the K-slice two M-tiles need (M-tile A = the even pixels of a 32-pixel row segment, M-tile B = the odd
+// ones; 16 lanes x 16 B = 256 B contiguous per plane) - so there is no activation staging, and the only barrier per round
+// is the one of the weight stages (LDS-DMA, double-buffered).  A wave owns rows 2w, 2w+1 of an 8x32-pixel tile and all NT
+// cout tiles.  The D fragments of tiles A and B interleave to 8 consecutive pixels per lane, i.e. two of the 4-pixel
+// fragments conv_epilogue.h works on (bias, upsampled residual, ReLU, 2x2 pool, fp32 or packed stores).
+// The residual window of the tile (commuted upsample, conv_epilogue.h) is prefetched by 4-B LDS-DMA before the main loop.
 template <int NT>
 struct S41Cfg {
-    static constexpr int TW = 32, TH = 8, MTR = 2, MP = 4, NPIX = TH * TW;
-    static constexpr int PLANE = NPIX * 8 + 64;                     // bytes
-    static constexpr int ABUF = 2 * 8 * PLANE;                      // [term][entry]
+    static constexpr int TW = 32, TH = 8, MP = 4;
     static constexpr int WBUF = NT * 2 * 64 * 16;                   // [nt][term][lane][8 bf16]
-    static constexpr int MAIN = 2 * ABUF + 2 * WBUF;
+    static constexpr int MAIN = 2 * WBUF;
     static constexpr int WPIECES = WBUF / 16, NITW = (WPIECES + 255) / 256;
 };
+
+typedef unsigned s4_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned s4_u32x2 __attribute__((ext_vector_type(2)));
 
 template <int NT, int EPI>
 __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
@@ -262,27 +342,23 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
     const int tileY = blockIdx.x / a.tilesX, tileX = blockIdx.x - tileY * a.tilesX;
     const int tile0 = blockIdx.y * NT, b = blockIdx.z;
     const size_t plane_bytes = (size_t)a.Hin * a.Win * 8;
-    auto abuf = [&](int i) { return smem_raw + i * C::ABUF; };
-    auto wbuf = [&](int i) { return smem_raw + 2 * C::ABUF + i * C::WBUF; };
+    auto wbuf = [&](int i) { return smem_raw + i * C::WBUF; };
+    const int g = lane >> 4;
 
     s4_f32x4 acc[C::MP][NT];
 #pragma unroll
     for (int m = 0; m < C::MP; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = s4_f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool has_res = EPI == 1 && a.res && a.res_lds_off >= 0;
+    ResWin rw = ResWin();
 
-    unsigned poff[2];   // pieces j*64 + lane of a 256-pixel plane: row = piece / 16, pixel pair = piece % 16
+    // this lane's pixel pair in rows 2w, 2w+1: byte offset inside a group plane, or -1
+    int poff[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = j * 64 + lane, row = p >> 4, cp = p & 15;
-        const int gy = tileY * C::TH + row, gx = tileX * C::TW + 2 * cp;
-        poff[j] = (gy < a.Hin && gx < a.Win) ? (unsigned)(gy * a.Win + gx) * 8u : kS4Oob;
-    }
-    int aoff[C::MP];   // entry pair of the lane group (2g, 2g+1) + the lane's pixel
-#pragma unroll
-    for (int m = 0; m < C::MP; ++m) {
-        const int mt = wave * C::MP + m, ty = mt / C::MTR, tx0 = (mt % C::MTR) * 16;
-        aoff[m] = (lane >> 4) * 2 * C::PLANE + (ty * C::TW + tx0 + (lane & 15)) * 8;
+    for (int rr = 0; rr < 2; ++rr) {
+        const int gy = tileY * C::TH + 2 * wave + rr, gx = tileX * C::TW + 2 * (lane & 15);
+        poff[rr] = (gy < a.Hin && gx < a.Win) ? (gy * a.Win + gx) * 8 : -1;
     }
     unsigned woff[C::NITW];
 #pragma unroll
@@ -292,27 +368,43 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
     }
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wpk, 0, 0x7FFFFFFF, 0x00020000);
 
-    float biasv[NT];
+    // operand roles swapped (weights = A, pixels = B): lane (g, i) ends up with couts 4g..4g+3 of the pixel pair (2i, 2i+1)
+    s4_f32x4 bias4[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) biasv[n] = epi_bias(a, (tile0 + n) * 16 + (lane & 15));
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[n][r] = epi_bias(a, (tile0 + n) * 16 + g * 4 + r);
 
     const int cb = a.chunk_begin, nrounds = a.chunk_end - cb;
-    auto issue_round = [&](int r, int stage) {
+    // fragments of one round: [row][entry of the pair][term], each 16 B = 2 pixels x 4 channels
+    auto load_round = [&](int r, s4_u32x4 (&x)[2][2][2]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int slot = 4 * (wave & 1) + q;
-            const int e = 8 * (cb + r) + slot;
-            const char *base;
-            unsigned goff, tstride;
-            s4_entry(a, e, b, plane_bytes, base, goff, tstride);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7FFFFFFF, 0x00020000);
-            const unsigned soff = goff + (unsigned)(wave >> 1) * tstride;
-            unsigned char *dst = abuf(stage) + ((wave >> 1) * 8 + slot) * C::PLANE;
+        for (int h = 0; h < 2; ++h) {
+            const int e = 8 * (cb + r) + 2 * g + h;   // per lane group
+            const float *sp = a.src[0];
+            int c4 = a.src_c4[0], g0 = a.src_g0[0], gn = a.src_gn[0], e0 = 0;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (s4_lds_ptr_t)(dst + j * 1024), 16, poff[j], soff, 0, 0);
+            for (int k = 1; k < kConvMaxSrc; ++k) {
+                const bool take = k < a.n_src && e >= a.src_ent0[k];
+                sp = take ? a.src[k] : sp;
+                c4 = take ? a.src_c4[k] : c4;
+                g0 = take ? a.src_g0[k] : g0;
+                gn = take ? a.src_gn[k] : gn;
+                e0 = take ? a.src_ent0[k] : e0;
+            }
+            const bool real = e - e0 < gn;   // padding entries (zero weights) read the zero page
+            const char *hi = reinterpret_cast<const char *>(sp) + ((size_t)b * 2 * c4 + (g0 + min(e - e0, gn - 1))) * plane_bytes;
+            const size_t tstride = (size_t)c4 * plane_bytes;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const bool ok = real && poff[rr] >= 0;
+                const char *p = ok ? hi + poff[rr] : reinterpret_cast<const char *>(a.zero_page);
+                x[rr][h][0] = *reinterpret_cast<const s4_u32x4 *>(p);
+                x[rr][h][1] = *reinterpret_cast<const s4_u32x4 *>(ok ? p + tstride : p);
+            }
         }
-        unsigned char *wdst = wbuf(stage);
+    };
+    auto load_weights = [&](int r, unsigned char *wdst) {
 #pragma unroll
         for (int it = 0; it < C::NITW; ++it)
             if (it * 256 + tid < C::WPIECES)
@@ -320,94 +412,210 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
                                                          (unsigned)(cb + r) * (2 * 64 * 16), 0, 0);
     };
 
-    if (nrounds > 0) issue_round(0, 0);
+    s4_u32x4 cur[2][2][2], nxt[2][2][2];
+    if (nrounds > 0) {
+        load_weights(0, wbuf(0));
+        load_round(0, cur);
+    }
+    // residual window -> LDS, asynchronously, behind the first round's loads (fixed-size window of res_rows x res_cols per
+    // channel, edge-clamped)
+    if (has_res) {
+        rw = res_window(a, tileY * C::TH, C::TH, tileX * C::TW, C::TW);
+        rw.rows = a.res_rows;
+        rw.cols = a.res_cols;
+        rw.cs = res_chan_stride(a.res_rows, a.res_cols);
+        const unsigned per = (unsigned)(rw.rows * rw.cols), total = (unsigned)(NT * 16 * rw.cs);
+        const size_t rplane = (size_t)a.Hres * a.Wres;
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.res + ((size_t)b * a.res_ctotal + a.res_choff + tile0 * 16) * rplane), 0, 0x7FFFFFFF, 0x00020000);
+        unsigned char *rdst = smem_raw + a.res_lds_off * 4;
+        for (unsigned e0 = (unsigned)wave * 64; e0 < total; e0 += 256) {
+            const unsigned e = e0 + lane;
+            const unsigned c = __umulhi(e, a.res_magic_cs), rem = e - c * (unsigned)rw.cs;
+            const unsigned r = __umulhi(rem, a.res_magic_cols), x = rem - r * (unsigned)rw.cols;
+            const int row = min(rw.sy0 + (int)r, a.Hres - 1), col = min(rw.sx0 + (int)x, a.Wres - 1);
+            const bool ok = e < total && rem < per && tile0 * 16 + (int)c < a.Cout;
+            const unsigned off = ok ? (unsigned)((c * rplane + (size_t)row * a.Wres + col) * 4) : kS4Oob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (s4_lds_ptr_t)(rdst + e0 * 4), 4, off, 0, 0, 0);
+        }
+    }
+
     for (int round = 0; round < nrounds; ++round) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weights of this round (and everything older) have landed
         __syncthreads();
-        if (round + 1 < nrounds) issue_round(round + 1, (round + 1) & 1);
-        const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
-        s4_bf16x8 bh[NT], bm[NT], ah[C::MP], am[C::MP];
+        const bool more = round + 1 < nrounds;
+        if (more) {
+            load_weights(round + 1, wbuf((round + 1) & 1));
+            load_round(round + 1, nxt);
+        }
+        const unsigned char *wb = wbuf(round & 1);
+        s4_bf16x8 bh[NT], bm[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             bh[n] = *reinterpret_cast<const s4_bf16x8 *>(wb + ((n * 2 + 0) * 64 + lane) * 16);
             bm[n] = *reinterpret_cast<const s4_bf16x8 *>(wb + ((n * 2 + 1) * 64 + lane) * 16);
         }
 #pragma unroll
-        for (int m = 0; m < C::MP; ++m) {
-            const unsigned char *p = ab + aoff[m];
-            ah[m] = s4_join(*reinterpret_cast<const s4_bf16x4 *>(p), *reinterpret_cast<const s4_bf16x4 *>(p + C::PLANE));
-            am[m] = s4_join(*reinterpret_cast<const s4_bf16x4 *>(p + 8 * C::PLANE), *reinterpret_cast<const s4_bf16x4 *>(p + 9 * C::PLANE));
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {   // q = pixel parity: low / high 8 B of the loads
+                const s4_u32x4 h0 = cur[rr][0][0], h1 = cur[rr][1][0], m0 = cur[rr][0][1], m1 = cur[rr][1][1];
+                const s4_u32x4 fh = q ? s4_u32x4{h0[2], h0[3], h1[2], h1[3]} : s4_u32x4{h0[0], h0[1], h1[0], h1[1]};
+                const s4_u32x4 fm = q ? s4_u32x4{m0[2], m0[3], m1[2], m1[3]} : s4_u32x4{m0[0], m0[1], m1[0], m1[1]};
+                const s4_bf16x8 ah = __builtin_bit_cast(s4_bf16x8, fh), am = __builtin_bit_cast(s4_bf16x8, fm);
+                const int m = rr * 2 + q;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[n], am, acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm[n], ah, acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[n], ah, acc[m][n], 0, 0, 0);
+            }
+        if (more) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) cur[rr][h][t] = nxt[rr][h][t];
         }
-#pragma unroll
-        for (int m = 0; m < C::MP; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m], bh[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < C::MP; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bm[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < C::MP; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
     }
 
-    if (EPI == 0) {
+    // ---- epilogue, lane-local: acc[rr*2 + q][n][r] = cout (tile0+n)*16 + 4g + r at pixel (row 2w + rr, column x0 + 2i + q).
+    //      bias -> (+ bilinearly upsampled residual) -> ReLU -> (2x2 average pool: the pixel pair of a lane and its two rows)
+    //      -> one [2 px][4 ch] unit per term (16 lanes = 256 B contiguous), [1 px][4 ch] when pooled, or fp32 NCHW pairs
+    if (has_res) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // every wave's pieces of the residual window have landed
+    }
+    {
+        const lds_float *res_lds = (const lds_float *)(reinterpret_cast<float *>(smem_raw) + (has_res ? a.res_lds_off : 0));
+        const int i2 = 2 * (lane & 15);
+        const int ox = tileX * C::TW + i2;
+        const bool pooled = EPI == 1 && a.pool;
+        const int Ho = pooled ? a.Hout >> 1 : a.Hout, Wo = pooled ? a.Wout >> 1 : a.Wout;
+        const size_t hw = (size_t)Ho * Wo, term = (size_t)a.dst_c4 * hw * 8;
+        const bool mis = (a.dst_choff & 2) != 0;
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        // finished values of pixel (rr, q), cout tile n
+        auto finish = [&](int rr, int q, int n, const int (&o0)[2], const int (&o1)[2], const float (&lx1)[2], float hy1) {
+            s4_f32x4 v = acc[rr * 2 + q][n];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int co = (tile0 + n) * 16 + (lane & 15);
-            if (epi_skip(a, co)) continue;
-#pragma unroll
-            for (int m = 0; m < C::MP; ++m) {
-                const int mt = wave * C::MP + m;
-                const int oy = tileY * C::TH + mt / C::MTR;
-                const int ox = tileX * C::TW + (mt % C::MTR) * 16 + (lane >> 4) * 4;
-                if (oy >= a.Hout || ox >= a.Wout) continue;
-                s4_f32x4 v = acc[m][n];
+            for (int r = 0; r < 4; ++r) {
+                v[r] += bias4[n][r];
+                if (has_res) {   // same arithmetic as res_apply (conv_epilogue.h)
+                    const lds_float *chan = res_lds + (n * 16 + 4 * g + r) * rw.cs;
+                    const float lx0 = 1.f - lx1[q], hy0 = 1.f - hy1;
+                    const float t0 = lx0 * chan[o0[q]] + lx1[q] * chan[o0[q] + 1];
+                    const float t1 = lx0 * chan[o1[q]] + lx1[q] * chan[o1[q] + 1];
+                    v[r] += hy0 * t0 + hy1 * t1;
+                }
+                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            return v;
+        };
+        // store 4 channels (couts co..co+3) of ONE output pixel at element offset pix
+        auto store_px = [&](int co, size_t pix, s4_f32x4 v) {
+            if (a.dst_fmt) {
+                s4_bf16x4 hi, mid;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] += biasv[n];
-                    if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                    hi[r] = (__bf16)v[r];
+                    mid[r] = (__bf16)(v[r] - (float)hi[r]);
                 }
-                epi_store(a, b, co, oy, ox, v);
-            }
-        }
-    } else {
-        // fused stages (conv_epilogue.h), as in conv_split1_kernel: residual window of this tile -> LDS (the stages are free
-        // once every wave has left the main loop), then pixel-group outer / channel inner
-        ResWin rw = ResWin();
-        const lds_float *res_lds = nullptr;
-        const bool has_res = a.res && a.res_lds_off >= 0;
-        if (has_res) {
-            __syncthreads();
-            rw = res_window(a, tileY * C::TH, C::TH, tileX * C::TW, C::TW);
-            res_stage(a, rw, b, tile0 * 16, NT * 16, (lds_float *)(reinterpret_cast<float *>(smem_raw) + a.res_lds_off), tid, 256);
-            res_lds = (const lds_float *)(reinterpret_cast<float *>(smem_raw) + a.res_lds_off);
-            __syncthreads();
-        }
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
+                const int chb = a.dst_choff + co;
+                const bool ok0 = chb < a.dst_limit, ok1 = chb + 2 < a.dst_limit;
+                char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
+                if (!mis) {
+                    if (ok1) {
+                        *reinterpret_cast<s4_bf16x4 *>(p) = hi;
+                        *reinterpret_cast<s4_bf16x4 *>(p + term) = mid;
+                    } else if (ok0) {
+                        *reinterpret_cast<bf2 *>(p) = bf2{hi[0], hi[1]};
+                        *reinterpret_cast<bf2 *>(p + term) = bf2{mid[0], mid[1]};
+                    }
+                } else {
+                    if (ok0) {
+                        *reinterpret_cast<bf2 *>(p + 4) = bf2{hi[0], hi[1]};
+                        *reinterpret_cast<bf2 *>(p + 4 + term) = bf2{mid[0], mid[1]};
+                    }
+                    if (ok1) {
+                        *reinterpret_cast<bf2 *>(p + hw * 8) = bf2{hi[2], hi[3]};
+                        *reinterpret_cast<bf2 *>(p + hw * 8 + term) = bf2{mid[2], mid[3]};
+                    }
+                }
+            } else {
 #pragma unroll
-        for (int m = 0; m < C::MP; ++m) {
-            const int mt = wave * C::MP + m;
-            const int oy = tileY * C::TH + mt / C::MTR;
-            const int ox = tileX * C::TW + (mt % C::MTR) * 16 + (lane_e >> 4) * 4;
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < a.Cout) a.dst[((size_t)b * a.dst_ctotal + a.dst_choff + co + r) * hw + pix] = v[r];
+            }
+        };
+        // ... and of the PAIR of pixels (pix, pix + 1): one 16-B unit per term when the group is whole
+        auto store_pair = [&](int co, size_t pix, s4_f32x4 v0, s4_f32x4 v1) {
+            const int chb = a.dst_choff + co;
+            if (a.dst_fmt && !mis && chb + 2 < a.dst_limit) {
+                s4_bf16x8 hi, mid;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    hi[r] = (__bf16)v0[r];
+                    mid[r] = (__bf16)(v0[r] - (float)hi[r]);
+                    hi[4 + r] = (__bf16)v1[r];
+                    mid[4 + r] = (__bf16)(v1[r] - (float)hi[4 + r]);
+                }
+                char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
+                *reinterpret_cast<s4_bf16x8 *>(p) = hi;
+                *reinterpret_cast<s4_bf16x8 *>(p + term) = mid;
+            } else if (!a.dst_fmt) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < a.Cout)
+                        *reinterpret_cast<f2 *>(a.dst + ((size_t)b * a.dst_ctotal + a.dst_choff + co + r) * hw + pix) = f2{v0[r], v1[r]};
+            } else {
+                store_px(co, pix, v0);
+                store_px(co, pix + 1, v1);
+            }
+        };
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            if (pooled && rr == 1) continue;   // row 2w+1 is consumed with row 2w
+            const int oy = tileY * C::TH + 2 * wave + rr;
             if (oy >= a.Hout || ox >= a.Wout) continue;
-            const bool pool_top = a.pool && ((m / C::MTR) & 1) == 0 && m + C::MTR < C::MP && oy + 1 < a.Hout;
-            if (a.pool && !pool_top) continue;
-            ResTaps t0, t1;
+            if (pooled && oy + 1 >= a.Hout) continue;
+            // interpolation taps of the two pixels (rows oy and, pooled, oy + 1)
+            int o0[2] = {0, 0}, o1[2] = {0, 0}, p0[2] = {0, 0}, p1[2] = {0, 0};
+            float lx1[2] = {0.f, 0.f}, hy1 = 0.f, hy1b = 0.f;
             if (has_res) {
-                t0 = res_taps(a, rw, oy, ox);
-                if (pool_top) t1 = res_taps(a, rw, oy + 1, ox);
+                int y0, y1;
+                float hy0;
+                lin_coord(oy, a.res_sh, a.Hres, y0, y1, hy0, hy1);
+                int z0 = 0, z1 = 0;
+                if (pooled) lin_coord(oy + 1, a.res_sh, a.Hres, z0, z1, hy0, hy1b);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    int x0, x1;
+                    float lx0;
+                    lin_coord(min(ox + q, a.Wout - 1), a.res_sw, a.Wres, x0, x1, lx0, lx1[q]);
+                    o0[q] = (y0 - rw.sy0) * rw.cols + (x0 - rw.sx0);
+                    o1[q] = (y1 - rw.sy0) * rw.cols + (x0 - rw.sx0);
+                    p0[q] = (z0 - rw.sy0) * rw.cols + (x0 - rw.sx0);
+                    p1[q] = (z1 - rw.sy0) * rw.cols + (x0 - rw.sx0);
+                }
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const int co = (tile0 + n) * 16 + (lane_e & 15);
-                if (epi_skip(a, co)) continue;
-                const lds_float *chan = res_lds + (n * 16 + (lane_e & 15)) * rw.cs;
-                const s4_f32x4 top = epi_finish(a, b, co, oy, ox, acc[m][n], biasv[n], has_res, chan, &t0);
-                if (!a.pool) epi_store(a, b, co, oy, ox, top);
-                else epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, acc[(m + C::MTR) % C::MP][n], biasv[n], has_res, chan, &t1));
+                const int co = (tile0 + n) * 16 + 4 * g;
+                if (co >= a.Cout + 2) continue;   // nothing of this unit is stored (dst_limit <= Cout + 2)
+                const s4_f32x4 va = finish(rr, 0, n, o0, o1, lx1, hy1), vb = finish(rr, 1, n, o0, o1, lx1, hy1);
+                if (!pooled) {
+                    store_pair(co, (size_t)oy * a.Wout + ox, va, vb);
+                } else {
+                    const s4_f32x4 vc = finish(1, 0, n, p0, p1, lx1, hy1b), vd = finish(1, 1, n, p0, p1, lx1, hy1b);
+                    s4_f32x4 pv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[r] = (((va[r] + vb[r]) + vc[r]) + vd[r]) * 0.25f;   // order of avgpool2_kernel
+                    if ((oy >> 1) < Ho && (ox >> 1) < Wo) store_px(co, (size_t)(oy >> 1) * Wo + (ox >> 1), pv);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -424,10 +632,15 @@ static int launch_s41_cfg(const ConvArgs &a0, int B, hipStream_t s) {
     size_t lds = C::MAIN;
     a.res_lds_off = -1;
     if (a.res) {
-        const size_t need = (size_t)NT * 16 * res_chan_stride(res_extent(C::TH, a.res_sh), res_extent(C::TW, a.res_sw)) * sizeof(float);
-        if (need > 64 * 1024) return fail(PF_EUNSUPPORTED, "conv_s4 1x1: residual window of %zu B does not fit LDS", need);
-        a.res_lds_off = 0;
-        if (need > lds) lds = need;
+        a.res_rows = res_extent(C::TH, a.res_sh);
+        a.res_cols = res_extent(C::TW, a.res_sw);
+        const int cs = res_chan_stride(a.res_rows, a.res_cols);
+        const size_t need = (size_t)NT * 16 * cs * sizeof(float);
+        if (need > 64 * 1024 || (size_t)NT * 16 * cs >= 65536) return fail(PF_EUNSUPPORTED, "conv_s4 1x1: residual window of %zu B does not fit LDS", need);
+        a.res_magic_cs = (unsigned)(0x100000000ull / (unsigned)cs) + 1u;          // exact quotients for dividends < 2^16
+        a.res_magic_cols = (unsigned)(0x100000000ull / (unsigned)a.res_cols) + 1u;
+        a.res_lds_off = C::MAIN / 4;
+        lds = C::MAIN + align_up(need, 256);
     }
     static size_t attr_lds = 0;
     if (lds > attr_lds) {

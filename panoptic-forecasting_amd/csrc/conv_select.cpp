@@ -17,6 +17,14 @@ const Tuned kTuned[] = {
 #include "conv_tuned.inc"
 };
 
+// conv_s4 (packed-pair sources): measured per-layer shapes with every eligible layer on conv_s4 (tools/tune_s4.py --emit).
+// kind 5 = run it on conv_s4 with (p0 = cout tiles per workgroup, p1 = 8x64-pixel tiles) if the plan can give it S4 sources,
+// kind 0 = the table's fp32-source kernel measured faster in situ: do not ask for S4 sources.
+const Tuned kTunedS4[] = {
+    {0, 0, 0, 0, 0, 0, {0, 0, 0, 0}},
+#include "conv_s4_tuned.inc"
+};
+
 // LDS bytes of a conv_wave workgroup (mirrors WaveCfg in conv_wave.hip)
 size_t wave_lds_bytes(int ks, int mh, int nt, int wk) {
     const int kc = wave_kc(ks), ih = mh + ks - 1, iw = 16 + (ks == 3 ? 8 : 0);
@@ -25,6 +33,20 @@ size_t wave_lds_bytes(int ks, int mh, int nt, int wk) {
     return 4 * (ring > red ? ring : red);
 }
 }  // namespace
+
+// Row of the conv_s4 table for this layer at the measured batch size nearest to B (in ratio); false: no row at all.
+bool choose_s4(int ks, int cin, int cout, int hout, int wout, int B, ConvChoice *out) {
+    const Tuned *best = nullptr;
+    double best_d = 0.0;
+    for (const Tuned &t : kTunedS4) {
+        if (t.ks != ks || t.cin != cin || t.cout != cout || t.hout != hout || t.wout != wout || t.B <= 0) continue;
+        const double d = t.B > B ? (double)t.B / B : (double)B / t.B;
+        if (!best || d < best_d || (d == best_d && t.B > best->B)) { best = &t; best_d = d; }
+    }
+    if (!best) return false;
+    *out = best->c;
+    return true;
+}
 
 ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B, int need, int use_tuned) {
     if (stride != 1) return ConvChoice{1, 0, 0, 0};           // conv_dma, shape by its cost model

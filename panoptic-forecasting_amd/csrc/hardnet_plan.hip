@@ -248,13 +248,18 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             const bool forced = g_conv_force.kind == 5;
             const long px = (long)B * a.Hout * a.Wout;
             bool want = ch.kind == 4 || (o.k == 1 && px >= 131072 && ch.kind == 1) || forced;
-            r.nt = forced ? g_conv_force.p0 : (ch.kind == 4 ? ch.p0 : 2);
+            r.nt = forced ? g_conv_force.p0 : (o.k == 1 ? 4 : (ch.kind == 4 ? ch.p0 : 2));
             r.wide = forced ? g_conv_force.p1 : (ch.kind == 4 ? ch.p1 : 0);
-            if (o.k == 1 && r.nt > 3) r.nt = a.ntiles == 4 ? 2 : 3;   // conv_s4 1x1: 4 cout tiles leave one workgroup per CU
+            ConvChoice s4c;   // measured conv_s4 row of this layer (conv_select.cpp): decides, and names the shape
+            if (!forced && !generic && p->opt_use_tuned &&
+                choose_s4((int)o.k, a.Cin, a.Cout, a.Hout, a.Wout, p->opt_table_batch > 0 ? p->opt_table_batch : B, &s4c)) {
+                want = s4c.kind == 5;
+                if (want) { r.nt = s4c.p0; r.wide = s4c.p1; }
+            }
             bool res_fits = true;
             if (a.res) {
                 const int nt1 = r.nt < 1 ? 1 : (r.nt > a.ntiles ? a.ntiles : r.nt);
-                res_fits = (size_t)nt1 * 16 * res_chan_stride(res_extent(8, a.res_sh), res_extent(32, a.res_sw)) * sizeof(float) <= 64 * 1024;
+                res_fits = (size_t)nt1 * 16 * res_chan_stride(res_extent(8, a.res_sh), res_extent(32, a.res_sw)) * sizeof(float) <= 60 * 1024;
             }
             r.can_read = s4_allowed && !generic && o.stride == 1 && o.kind == OP_CONV && p->conv[i].has_s4 && (need == 0 || o.k == 1) && want &&
                          res_fits && ((a.src_begin == 0 && a.src_end == a.n_src) || p->conv[i].s4_pad);
