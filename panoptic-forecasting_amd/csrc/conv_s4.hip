@@ -38,6 +38,11 @@
 #define S4_PROBE(i) do { } while (0)
 #endif
 
+#ifndef S4_ISSUE_FIRST
+#define S4_ISSUE_FIRST 1
+#define S4_ISSUE_STEP 3
+#endif
+
 namespace pf {
 
 typedef float s4_f32x4 __attribute__((ext_vector_type(4)));
@@ -169,6 +174,13 @@ __global__ __launch_bounds__(256) void conv_s4_kernel(ConvArgs a) {
                                                          (unsigned)(cb + r) * (3 * 2 * 64 * 16), 0, 0);
     };
 
+    // part j of the next stage goes out after MFMA group S4_ISSUE_FIRST + j * S4_ISSUE_STEP of the round (3 groups per unit)
+    auto issue_slot = [&](int round, bool more, int slot) {
+        if (!more) return;
+#pragma unroll
+        for (int j = 0; j < UNITS; ++j)
+            if (slot == S4_ISSUE_FIRST + j * S4_ISSUE_STEP) issue_part(round + 1, (round + 1) & 1, j);
+    };
     if (nrounds > 0) {
         prepare_round(0);
 #pragma unroll
@@ -209,17 +221,19 @@ __global__ __launch_bounds__(256) void conv_s4_kernel(ConvArgs a) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_h[set][n], fa_m[set][m], acc[m0 + m][n], 0, 0, 0);
+            issue_slot(round, more, 3 * u + 0);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_m[set][n], fa_h[set][m], acc[m0 + m][n], 0, 0, 0);
-            if (more) issue_part(round + 1, (round + 1) & 1, u);
+            issue_slot(round, more, 3 * u + 1);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_h[set][n], fa_h[set][m], acc[m0 + m][n], 0, 0, 0);
+            issue_slot(round, more, 3 * u + 2);
         }
         S4_PROBE(round * 4 + 3);
     }
@@ -248,6 +262,9 @@ __global__ __launch_bounds__(256) void conv_s4_kernel(ConvArgs a) {
                     v[r] += bias4[n][r];
                     if (a.relu) v[r] = fmaxf(v[r], 0.f);
                 }
+#ifdef S4_EXP_NOSTORE
+                if (v[0] != 12345.678f) continue;
+#endif
                 if (a.dst_fmt) {
                     s4_bf16x4 hi, mid;
 #pragma unroll
