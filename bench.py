@@ -266,7 +266,7 @@ def roofline_of(recs, n_steps, frames, measured_on):
     gbs = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
     if dom['flops'] > 0:
         achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-        if 'conv_split' in dom['label'] or 'hblock' in dom['label']:
+        if 'conv_split' in dom['label'] or 'conv_s4' in dom['label']:
             # every algorithmic fp32 MAC is 3 bf16 MFMA MACs (hi*hi + hi*mid + mid*hi): the matrix ceiling of this
             # scheme, in algorithmic flops, is the dense bf16 peak / 3
             peak, note = PEAK_BF16_MFMA_TFLOPS / 3.0, 'dense bf16 MFMA peak 2500 TFLOP/s / 3 products per fp32 MAC'
