@@ -17,11 +17,16 @@
 // reads the whole block reads no padding at all.
 //
 // 3x3: GEMM view as in conv_split.hip (M = 16 pixels of a row, N = 16 couts, K = 32 = 4 lane groups x 8 values), a lane's 8
-// K-values = the 4 channels of TWO group entries for one tap: two ds_read_b64 per term.  A round = 2 entries = 8 channels =
-// 3 instructions of 4 tap slots.  The 9 taps are laid out so that the two lane groups one ds_read_b64 pass serves
-// (lanes 0-31 / 32-63) read the same tile row, or the same addresses: conflict-free for any row pitch -
-//     instr 0: (0,0) (0,1) | (1,0) (1,1)     instr 1: (2,0) (2,1) | (0,2) --     instr 2: (1,2) -- | (2,2) --
-// (-- = zero-weight slot reading its neighbour's addresses).  Wave w DMAs plane (term = w >> 1, entry = w & 1) of a stage.
+// K-values = the 4 channels of TWO group entries for one tap: two ds_read_b64 per term.  A round = 2 entries = 8 channels.
+// Nine taps do not fill whole instructions of 4 tap slots (conv_split.hip and the first version of this kernel spent 12
+// slots on them: a quarter of the matrix instructions multiplied zeros, and with the memory side out of the way these
+// kernels are bound by the matrix pipe - profiles/r02_experiments.md).  Here a round issues TWO full instructions
+//     instr 0: (0,0) (0,1) | (1,0) (1,1)        instr 1: (2,0) (2,1) | (0,2) (1,2)
+// (the two lane groups one ds_read_b64 pass serves read the same tile row - conflict-free for any row pitch - except the
+// last pair, a 2-way conflict on one pass) and the ninth tap (2,2) is COLLECTED: in round r only lane group r & 3 reads
+// its (2,2) fragments, into registers that survive the round; after four rounds the four lane groups hold the K-slices
+// of four different rounds and one more instruction (weights packed to match) retires them: 9 instructions per 4 rounds
+// instead of 12, no zero slots.  Wave w DMAs plane (term = w >> 1, entry = w & 1) of a stage.
 // 1x1: K = 32 = 8 group entries per instruction and round; 8x32-pixel tiles, the fused epilogue stages of conv_epilogue.h.
 #include <cstring>
 #include <vector>
@@ -40,7 +45,7 @@
 
 #ifndef S4_ISSUE_FIRST
 #define S4_ISSUE_FIRST 1
-#define S4_ISSUE_STEP 3
+#define S4_ISSUE_STEP 2
 #endif
 
 namespace pf {
@@ -85,13 +90,18 @@ struct S4Cfg {
     static constexpr int NDMA = (PIECES + 63) / 64;                       // DMA instructions per plane (one wave per plane)
     static constexpr int PLANE = NDMA * 64 * 16;                          // bytes
     static constexpr int ABUF = 4 * PLANE;                                // [term][entry] per stage
-    static constexpr int WBUF = NT * 3 * 2 * 64 * 16;                     // [nt][instr][term][lane][8 bf16]
+    static constexpr int WBLK = 2 * 64 * 16;                              // one instruction's weights of one cout tile: [term][lane][8 bf16]
+    static constexpr int WBUF = NT * 3 * WBLK;                            // [nt][block: instr 0, instr 1, collected tap][term][lane]
     static constexpr int WPIECES = WBUF / 16, NITW = (WPIECES + 255) / 256;
     static constexpr size_t LDS_BYTES = 2 * (size_t)ABUF + 2 * (size_t)WBUF;
 };
 
+// weight blocks in front of round r (2 per round + one collected-tap block per started group of 4 rounds before it)
+__host__ __device__ inline int s4_blocks_before(int r) { return 2 * r + r / 4; }
+__host__ __device__ inline int s4_blocks_total(int rounds) { return 2 * rounds + (rounds + 3) / 4; }
+
 template <int NT, int TW_>
-__global__ __launch_bounds__(256) void conv_s4_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT == 2) ? 3 : 2) void conv_s4_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = S4Cfg<NT, TW_>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -120,22 +130,29 @@ __global__ __launch_bounds__(256) void conv_s4_kernel(ConvArgs a) {
         const int gy = iy0 + row, gx = ix0 + 2 * cp;
         poff[j] = (p < C::PIECES && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? (unsigned)(gy * a.Win + gx) * 8u : kS4Oob;
     }
+    // weight pieces of a stage: piece p -> (cout tile n, block, [term][lane]); the same byte offset in LDS and, per tile, in
+    // the packed stream (blocks of a round are consecutive there)
+    const int nblocks = s4_blocks_total(a.nchunks);
     unsigned woff[C::NITW];
+    bool wcol[C::NITW];                    // piece of the collected-tap block: fetched in flush rounds only
 #pragma unroll
     for (int it = 0; it < C::NITW; ++it) {
-        const int p = it * 256 + tid, n = p / (3 * 2 * 64);
-        woff[it] = (p < C::WPIECES && tile0 + n < a.ntiles) ? (unsigned)((tile0 + n) * a.nchunks * (3 * 2 * 64) + (p - n * (3 * 2 * 64))) * 16u : kS4Oob;
+        const int p = it * 256 + tid, n = p / (3 * 2 * 64), rem = p - n * (3 * 2 * 64);
+        woff[it] = (p < C::WPIECES && tile0 + n < a.ntiles) ? ((unsigned)(tile0 + n) * (unsigned)nblocks * (2 * 64) + (unsigned)rem) * 16u : kS4Oob;
+        wcol[it] = rem >= 2 * 2 * 64;
     }
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wpk, 0, 0x7FFFFFFF, 0x00020000);
 
-    // A-fragment byte offsets inside a plane for instruction s (M-tile part added as an immediate): the lane group picks the tap
-    int aoff[3];
+    // A-fragment byte offsets inside a plane (M-tile part added as an immediate): the lane group picks the tap of instr 0 / 1;
+    // the collected tap (2,2) is the same for every lane
+    const int g = lane >> 4;
+    int aoff[2], aoff_col;
     {
-        const int g = lane >> 4;
-        const int ky[3] = {g >> 1, g < 2 ? 2 : 0, g < 2 ? 1 : 2};
-        const int kx[3] = {g & 1, g < 2 ? g : 2, 2};
+        const int ky[2] = {g >> 1, g < 2 ? 2 : g - 2};
+        const int kx[2] = {g & 1, g < 2 ? g : 2};
 #pragma unroll
-        for (int s = 0; s < 3; ++s) aoff[s] = ((wave * 2 + ky[s]) * C::IW + (lane & 15) + kx[s] + 1) * 8;
+        for (int s = 0; s < 2; ++s) aoff[s] = ((wave * 2 + ky[s]) * C::IW + (lane & 15) + kx[s] + 1) * 8;
+        aoff_col = ((wave * 2 + 2) * C::IW + (lane & 15) + 2 + 1) * 8;
     }
 
     // operand roles are swapped with respect to conv_split.hip (weights = A, pixels = B): the D fragment of lane (g, i) is
@@ -144,47 +161,55 @@ __global__ __launch_bounds__(256) void conv_s4_kernel(ConvArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias4[n][r] = epi_bias(a, (tile0 + n) * 16 + (lane >> 4) * 4 + r);
+        for (int r = 0; r < 4; ++r) bias4[n][r] = epi_bias(a, (tile0 + n) * 16 + g * 4 + r);
 
-    const int cb = a.chunk_begin, nrounds = a.chunk_end - cb;
-    // The DMA instructions of the next stage are issued in UNITS parts between the matrix units of the current one (a part =
-    // one activation piece + its share of the weight pieces): issued in one block they cost the wave ~1000 clocks per
-    // round in which it feeds no MFMA (tools/probe_s4.py).
-    constexpr int HALVES = C::MP / 4, UNITS = 3 * HALVES;
-    static_assert(C::NDMA == UNITS, "one activation DMA instruction per matrix unit");
+    const int nrounds = a.nchunks;   // 3x3 launches always run the whole K range (the collected tap spans 4 rounds)
+    // The DMA instructions of the next stage go out between the matrix groups of the current one (a part = one activation
+    // piece + its share of the weight pieces): issued in one block they cost the wave ~1000 clocks per round in which it
+    // feeds no MFMA (tools/probe_s4.py).
+    constexpr int HALVES = C::MP / 4;
     __amdgpu_buffer_rsrc_t ars;
     unsigned asoff = 0;
     bool areal = true;
     auto prepare_round = [&](int r) {
-        // activations: wave w fetches plane (term = w >> 1, entry = 2 (cb + r) + (w & 1))
+        // activations: wave w fetches plane (term = w >> 1, entry = 2 r + (w & 1))
         const char *base;
         unsigned goff, tstride;
-        areal = s4_entry(a, 2 * (cb + r) + (wave & 1), b, plane_bytes, base, goff, tstride);
+        areal = s4_entry(a, 2 * r + (wave & 1), b, plane_bytes, base, goff, tstride);
         ars = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7FFFFFFF, 0x00020000);
         asoff = goff + (unsigned)(wave >> 1) * tstride;
     };
+    auto is_flush = [&](int r) { return (r & 3) == 3 || r == nrounds - 1; };
     auto issue_part = [&](int r, int stage, int j) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (s4_lds_ptr_t)(abuf(stage) + wave * C::PLANE + j * 1024), 16,
                                                  areal ? poff[j] : kS4Oob, asoff, 0, 0);
         unsigned char *wdst = wbuf(stage);
+        const bool flush = is_flush(r);
 #pragma unroll
-        for (int it = j; it < C::NITW; it += UNITS)
-            if (it * 256 + tid < C::WPIECES)
+        for (int it = j; it < C::NITW; it += C::NDMA)
+            if (it * 256 + tid < C::WPIECES && (flush || !wcol[it]))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (s4_lds_ptr_t)(wdst + (it * 256 + wave * 64) * 16), 16, woff[it],
-                                                         (unsigned)(cb + r) * (3 * 2 * 64 * 16), 0, 0);
+                                                         (unsigned)s4_blocks_before(r) * C::WBLK, 0, 0);
     };
-
-    // part j of the next stage goes out after MFMA group S4_ISSUE_FIRST + j * S4_ISSUE_STEP of the round (3 groups per unit)
+    // part j of the next stage goes out after MFMA group S4_ISSUE_FIRST + j * S4_ISSUE_STEP of the round (6 HALVES groups)
     auto issue_slot = [&](int round, bool more, int slot) {
         if (!more) return;
 #pragma unroll
-        for (int j = 0; j < UNITS; ++j)
+        for (int j = 0; j < C::NDMA; ++j)
             if (slot == S4_ISSUE_FIRST + j * S4_ISSUE_STEP) issue_part(round + 1, (round + 1) & 1, j);
     };
+    static_assert(S4_ISSUE_FIRST + (C::NDMA - 1) * S4_ISSUE_STEP < 6 * HALVES, "every DMA part needs a slot inside the two full instructions");
+
+    // collected tap: K-slice g of these fragments = entries of round 4q + g
+    s4_bf16x8 col_h[C::MP], col_m[C::MP];
+    const s4_bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < C::MP; ++m) col_h[m] = col_m[m] = zero8;
+
     if (nrounds > 0) {
         prepare_round(0);
 #pragma unroll
-        for (int j = 0; j < UNITS; ++j) issue_part(0, 0, j);
+        for (int j = 0; j < C::NDMA; ++j) issue_part(0, 0, j);
     }
     for (int round = 0; round < nrounds; ++round) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
@@ -195,45 +220,67 @@ __global__ __launch_bounds__(256) void conv_s4_kernel(ConvArgs a) {
         if (more) prepare_round(round + 1);
         S4_PROBE(round * 4 + 2);
         const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
-        s4_bf16x8 fa_h[2][4], fa_m[2][4], fb_h[2][NT], fb_m[2][NT];
-        auto fetch = [&](int u, int set) {
-            const int s = u / HALVES, m0 = (u % HALVES) * 4;
+        auto frag = [&](const unsigned char *p, s4_bf16x8 &h, s4_bf16x8 &md) {
+            h = s4_join(*reinterpret_cast<const s4_bf16x4 *>(p), *reinterpret_cast<const s4_bf16x4 *>(p + C::PLANE));
+            md = s4_join(*reinterpret_cast<const s4_bf16x4 *>(p + 2 * C::PLANE), *reinterpret_cast<const s4_bf16x4 *>(p + 3 * C::PLANE));
+        };
+        auto mtile_off = [&](int mm) { return ((mm / C::MTR) * C::IW + (mm % C::MTR) * 16) * 8; };
+        // the three products of one block of weights with 4 M-tiles; `slot0` numbers the MFMA groups for the DMA parts
+        auto products = [&](int blk, int m0, const s4_bf16x8 (&fh)[4], const s4_bf16x8 (&fm)[4], int slot0, bool dma) {
+            s4_bf16x8 wh[NT], wm[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                fb_h[set][n] = *reinterpret_cast<const s4_bf16x8 *>(wb + (((n * 3 + s) * 2 + 0) * 64 + lane) * 16);
-                fb_m[set][n] = *reinterpret_cast<const s4_bf16x8 *>(wb + (((n * 3 + s) * 2 + 1) * 64 + lane) * 16);
+                wh[n] = *reinterpret_cast<const s4_bf16x8 *>(wb + (((n * 3 + blk) * 2 + 0) * 64 + lane) * 16);
+                wm[n] = *reinterpret_cast<const s4_bf16x8 *>(wb + (((n * 3 + blk) * 2 + 1) * 64 + lane) * 16);
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int mm = m0 + m, mo = ((mm / C::MTR) * C::IW + (mm % C::MTR) * 16) * 8;
-                const unsigned char *p = ab + aoff[s] + mo;
-                fa_h[set][m] = s4_join(*reinterpret_cast<const s4_bf16x4 *>(p), *reinterpret_cast<const s4_bf16x4 *>(p + C::PLANE));
-                fa_m[set][m] = s4_join(*reinterpret_cast<const s4_bf16x4 *>(p + 2 * C::PLANE), *reinterpret_cast<const s4_bf16x4 *>(p + 3 * C::PLANE));
-            }
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], fm[m], acc[m0 + m][n], 0, 0, 0);
+            if (dma) issue_slot(round, more, slot0 + 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[n], fh[m], acc[m0 + m][n], 0, 0, 0);
+            if (dma) issue_slot(round, more, slot0 + 1);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], fh[m], acc[m0 + m][n], 0, 0, 0);
+            if (dma) issue_slot(round, more, slot0 + 2);
         };
-        fetch(0, 0);
 #pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            const int set = u & 1, m0 = (u % HALVES) * 4;
-            if (u + 1 < UNITS) fetch(u + 1, set ^ 1);
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int hf = 0; hf < HALVES; ++hf) {
+                s4_bf16x8 fh[4], fm[4];
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_h[set][n], fa_m[set][m], acc[m0 + m][n], 0, 0, 0);
-            issue_slot(round, more, 3 * u + 0);
+                for (int m = 0; m < 4; ++m) frag(ab + aoff[s] + mtile_off(hf * 4 + m), fh[m], fm[m]);
+                products(s, hf * 4, fh, fm, 3 * (s * HALVES + hf), true);
+                __builtin_amdgcn_sched_barrier(0);   // keep the next unit's fragment reads behind these MFMAs (registers)
+            }
+        // the ninth tap of this round's entries: K-slice (round & 3)
+        if (g == (round & 3)) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < C::MP; ++m) frag(ab + aoff_col + mtile_off(m), col_h[m], col_m[m]);
+        }
+        if (is_flush(round)) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_m[set][n], fa_h[set][m], acc[m0 + m][n], 0, 0, 0);
-            issue_slot(round, more, 3 * u + 1);
+            for (int hf = 0; hf < HALVES; ++hf) {
+                s4_bf16x8 fh[4], fm[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m) {
+                    fh[m] = col_h[hf * 4 + m];
+                    fm[m] = col_m[hf * 4 + m];
+                }
+                products(2, hf * 4, fh, fm, 0, false);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb_h[set][n], fa_h[set][m], acc[m0 + m][n], 0, 0, 0);
-            issue_slot(round, more, 3 * u + 2);
+            for (int m = 0; m < C::MP; ++m) col_h[m] = col_m[m] = zero8;
         }
         S4_PROBE(round * 4 + 3);
     }
@@ -686,6 +733,7 @@ int launch_conv_s4(const ConvArgs &a, int ks, int nt, int wide, int B, hipStream
     nt = nt < 1 ? 1 : (nt > a.ntiles ? a.ntiles : nt);
     if (ks == 3) {
         if (a.pool || a.res || a.no_bias) return fail(PF_EUNSUPPORTED, "conv_s4 3x3: no fused epilogue stages");
+        if (a.chunk_begin != 0 || a.chunk_end != a.nchunks) return fail(PF_EUNSUPPORTED, "conv_s4 3x3: whole K range only");
         if (wide) {
             if (nt == 1) return launch_s4_cfg<1, 64>(a, B, s);
             if (nt == 2) return launch_s4_cfg<2, 64>(a, B, s);
@@ -733,11 +781,14 @@ int s4_rounds(const S4Range *r, int n_src, int ks, int pad_sources) {
     return (s4_entries(r, n_src, ks, pad_sources) + per - 1) / per;
 }
 size_t s4_packed_floats(const S4Range *r, int n_src, int cout, int ks, int pad_sources) {
-    return (size_t)((cout + 15) / 16) * s4_rounds(r, n_src, ks, pad_sources) * (ks == 3 ? 3 : 1) * 2 * 64 * 4;
+    const int rounds = s4_rounds(r, n_src, ks, pad_sources);
+    return (size_t)((cout + 15) / 16) * (ks == 3 ? s4_blocks_total(rounds) : rounds) * 2 * 64 * 4;
 }
 
-// 3x3: [tile][round][instr 3][term 2][lane 64][8 bf16]; 1x1: [tile][round][term 2][lane 64][8 bf16]; lane = (cout n = lane & 15,
-// group g = lane >> 4), the lane's 8 values = 4 channels of two group entries
+// Blocks of [term 2][lane 64][8 bf16]; lane = (cout n = lane & 15, lane group g = lane >> 4), the lane's 8 values = 4 channels
+// of two group entries.  1x1: [tile][round], g = entry pair of the round.  3x3: [tile][per round: instr 0, instr 1, and after
+// every 4th (and the last) round the collected-tap block]; instr blocks: g = tap, entries of the round; collected block:
+// g = round 4q + g of its group of four, tap (2,2)
 void pack_conv_weights_s4(const float *w, int cin, int cout, int ks, const S4Range *r, int n_src, int pad_sources, float *out_f) {
     unsigned short *out = reinterpret_cast<unsigned short *>(out_f);
     // entry -> (first conv input channel of the group's channel 0, may be negative; valid channel window)
@@ -759,26 +810,36 @@ void pack_conv_weights_s4(const float *w, int cin, int cout, int ks, const S4Ran
         c0 += r[j].ch;
     }
     const int n_ent = (int)ent_c0.size(), rounds = (n_ent + per - 1) / per, ntiles = (cout + 15) / 16;
-    // tap of (instr, lane group); -1 = zero slot
-    static const int tap3[3][4] = {{0, 1, 3, 4}, {6, 7, 2, -1}, {5, -1, 8, -1}};
     size_t o = 0;
+    // one block: value of (lane, e) = weight of cout (t, lane & 15), entry ent_of(lane >> 4, e / 4), channel e & 3, tap tap_of(lane >> 4)
+    auto block = [&](int t, auto ent_of, auto tap_of) {
+        for (int term = 0; term < 2; ++term)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int co = t * 16 + (lane & 15), g = lane >> 4;
+                    const int ent = ent_of(g, e / 4), tap = tap_of(g);
+                    float v = 0.f;
+                    if (co < cout && tap >= 0 && ent >= 0 && ent < n_ent) {
+                        const int ci = ent_c0[ent] + (e & 3);
+                        if (ci >= ent_lo[ent] && ci < ent_hi[ent]) v = w[((size_t)co * cin + ci) * ks * ks + tap];
+                    }
+                    const unsigned short hi = s4_bf16_rne(v);
+                    out[o++] = term == 0 ? hi : s4_bf16_rne(v - s4_bf16_f32(hi));
+                }
+    };
+    static const int tap3[2][4] = {{0, 1, 3, 4}, {6, 7, 2, 5}};   // ky * 3 + kx of (instr, lane group): see the kernel's aoff
     for (int t = 0; t < ntiles; ++t)
-        for (int rd = 0; rd < rounds; ++rd)
-            for (int s = 0; s < (ks == 3 ? 3 : 1); ++s)
-                for (int term = 0; term < 2; ++term)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int e = 0; e < 8; ++e) {
-                            const int co = t * 16 + (lane & 15), g = lane >> 4;
-                            const int ent = ks == 3 ? rd * 2 + e / 4 : rd * 8 + g * 2 + e / 4;
-                            const int tap = ks == 3 ? tap3[s][g] : 0;
-                            float v = 0.f;
-                            if (co < cout && tap >= 0 && ent < n_ent) {
-                                const int ci = ent_c0[ent] + (e & 3);
-                                if (ci >= ent_lo[ent] && ci < ent_hi[ent]) v = w[((size_t)co * cin + ci) * ks * ks + tap];
-                            }
-                            const unsigned short hi = s4_bf16_rne(v);
-                            out[o++] = term == 0 ? hi : s4_bf16_rne(v - s4_bf16_f32(hi));
-                        }
+        for (int rd = 0; rd < rounds; ++rd) {
+            if (ks == 1) {
+                block(t, [&](int g, int h) { return rd * 8 + g * 2 + h; }, [](int) { return 0; });
+                continue;
+            }
+            for (int s = 0; s < 2; ++s) block(t, [&](int, int h) { return rd * 2 + h; }, [&](int g) { return tap3[s][g]; });
+            if ((rd & 3) == 3 || rd == rounds - 1) {
+                const int q = rd / 4;
+                block(t, [&](int g, int h) { return 4 * q + g < rounds ? (4 * q + g) * 2 + h : -1; }, [](int) { return 8; });
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------ layout conversion
