@@ -34,10 +34,6 @@ __device__ __forceinline__ void lin_coord(int o, float scale, int in_size, int &
 // upper bound of source rows (cols) touched by n_out consecutive output rows (cols) at `scale` (host + device)
 __host__ __device__ inline int res_extent(int n_out, float scale) { return (int)(scale * (float)(n_out - 1)) + 3; }
 __host__ __device__ inline int res_chan_stride(int rows, int cols) { return (rows * cols) | 1; }
-// conv_s4 1x1: the window is staged in 16-B pieces (4 floats, aligned in the tensor row): pieces per window row for a window
-// of `cols` elements starting anywhere, and 16-B pieces per channel (odd: 4 channels apart = 16 banks apart)
-__host__ __device__ inline int res_piece_cols(int cols) { return (cols + 3 + 3) / 4; }
-__host__ __device__ inline int res_chan_pieces(int rows, int cols) { return (rows * res_piece_cols(cols)) | 1; }
 
 struct ResWin {
     int sy0, sx0, rows, cols, cs;   // window origin in the residual tensor, its size, channel stride (floats)

@@ -481,29 +481,26 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
         load_weights(0, wbuf(0));
         load_round(0, cur);
     }
-    // residual window -> LDS, asynchronously, behind the first round's loads: 16-B pieces (4 floats, aligned in their tensor
-    // row - one DMA instruction moves 1 KB, a 4-B gather 256 B), a fixed number of rows x pieces per channel; rows past the
-    // tensor edge are copies of the edge row, pieces past the row end land as zeros and are never sampled (lin_coord clamps)
+    // residual window -> LDS, asynchronously, behind the first round's loads (fixed-size window of res_rows x res_cols per
+    // channel, edge-clamped)
     if (has_res) {
         rw = res_window(a, tileY * C::TH, C::TH, tileX * C::TW, C::TW);
-        const int pw = res_piece_cols(a.res_cols), csp = res_chan_pieces(a.res_rows, a.res_cols);
-        rw.sx0 &= ~3;
         rw.rows = a.res_rows;
-        rw.cols = 4 * pw;        // element pitch of a window row
-        rw.cs = 4 * csp;         // ... and of a channel
-        const unsigned per = (unsigned)(rw.rows * pw), total = (unsigned)(NT * 16 * csp);
+        rw.cols = a.res_cols;
+        rw.cs = res_chan_stride(a.res_rows, a.res_cols);
+        const unsigned per = (unsigned)(rw.rows * rw.cols), total = (unsigned)(NT * 16 * rw.cs);
         const size_t rplane = (size_t)a.Hres * a.Wres;
         const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(a.res + ((size_t)b * a.res_ctotal + a.res_choff + tile0 * 16) * rplane), 0, 0x7FFFFFFF, 0x00020000);
         unsigned char *rdst = smem_raw + a.res_lds_off * 4;
         for (unsigned e0 = (unsigned)wave * 64; e0 < total; e0 += 256) {
             const unsigned e = e0 + lane;
-            const unsigned c = __umulhi(e, a.res_magic_cs), rem = e - c * (unsigned)csp;
-            const unsigned r = __umulhi(rem, a.res_magic_cols), xp = rem - r * (unsigned)pw;
-            const int row = min(rw.sy0 + (int)r, a.Hres - 1), col = rw.sx0 + 4 * (int)xp;
-            const bool ok = e < total && rem < per && tile0 * 16 + (int)c < a.Cout && col < a.Wres;
+            const unsigned c = __umulhi(e, a.res_magic_cs), rem = e - c * (unsigned)rw.cs;
+            const unsigned r = __umulhi(rem, a.res_magic_cols), x = rem - r * (unsigned)rw.cols;
+            const int row = min(rw.sy0 + (int)r, a.Hres - 1), col = min(rw.sx0 + (int)x, a.Wres - 1);
+            const bool ok = e < total && rem < per && tile0 * 16 + (int)c < a.Cout;
             const unsigned off = ok ? (unsigned)((c * rplane + (size_t)row * a.Wres + col) * 4) : kS4Oob;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (s4_lds_ptr_t)(rdst + e0 * 16), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (s4_lds_ptr_t)(rdst + e0 * 4), 4, off, 0, 0, 0);
         }
     }
 
@@ -565,7 +562,7 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
         const bool mis = (a.dst_choff & 2) != 0;
         typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
         // finished values of pixel (rr, q), cout tile n
-        auto finish = [&](int rr, int q, int n, const int (&o0)[2], const int (&o1)[2], const int (&dx)[2], const float (&lx1)[2], float hy1) {
+        auto finish = [&](int rr, int q, int n, const int (&o0)[2], const int (&o1)[2], const float (&lx1)[2], float hy1) {
             s4_f32x4 v = acc[rr * 2 + q][n];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -573,8 +570,8 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
                 if (has_res) {   // same arithmetic as res_apply (conv_epilogue.h)
                     const lds_float *chan = res_lds + (n * 16 + 4 * g + r) * rw.cs;
                     const float lx0 = 1.f - lx1[q], hy0 = 1.f - hy1;
-                    const float t0 = lx0 * chan[o0[q]] + lx1[q] * chan[o0[q] + dx[q]];
-                    const float t1 = lx0 * chan[o1[q]] + lx1[q] * chan[o1[q] + dx[q]];
+                    const float t0 = lx0 * chan[o0[q]] + lx1[q] * chan[o0[q] + 1];
+                    const float t1 = lx0 * chan[o1[q]] + lx1[q] * chan[o1[q] + 1];
                     v[r] += hy0 * t0 + hy1 * t1;
                 }
                 if (a.relu) v[r] = fmaxf(v[r], 0.f);
@@ -650,7 +647,7 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
             if (oy >= a.Hout || ox >= a.Wout) continue;
             if (pooled && oy + 1 >= a.Hout) continue;
             // interpolation taps of the two pixels (rows oy and, pooled, oy + 1)
-            int o0[2] = {0, 0}, o1[2] = {0, 0}, p0[2] = {0, 0}, p1[2] = {0, 0}, dx[2] = {0, 0};
+            int o0[2] = {0, 0}, o1[2] = {0, 0}, p0[2] = {0, 0}, p1[2] = {0, 0};
             float lx1[2] = {0.f, 0.f}, hy1 = 0.f, hy1b = 0.f;
             if (has_res) {
                 int y0, y1;
@@ -663,7 +660,6 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
                     int x0, x1;
                     float lx0;
                     lin_coord(min(ox + q, a.Wout - 1), a.res_sw, a.Wres, x0, x1, lx0, lx1[q]);
-                    dx[q] = x1 - x0;   // 0 at the right edge: the clamped tap of lin_coord, not the element behind it
                     o0[q] = (y0 - rw.sy0) * rw.cols + (x0 - rw.sx0);
                     o1[q] = (y1 - rw.sy0) * rw.cols + (x0 - rw.sx0);
                     p0[q] = (z0 - rw.sy0) * rw.cols + (x0 - rw.sx0);
@@ -674,11 +670,11 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
             for (int n = 0; n < NT; ++n) {
                 const int co = (tile0 + n) * 16 + 4 * g;
                 if (co >= a.Cout + 2) continue;   // nothing of this unit is stored (dst_limit <= Cout + 2)
-                const s4_f32x4 va = finish(rr, 0, n, o0, o1, dx, lx1, hy1), vb = finish(rr, 1, n, o0, o1, dx, lx1, hy1);
+                const s4_f32x4 va = finish(rr, 0, n, o0, o1, lx1, hy1), vb = finish(rr, 1, n, o0, o1, lx1, hy1);
                 if (!pooled) {
                     store_pair(co, (size_t)oy * a.Wout + ox, va, vb);
                 } else {
-                    const s4_f32x4 vc = finish(1, 0, n, p0, p1, dx, lx1, hy1b), vd = finish(1, 1, n, p0, p1, dx, lx1, hy1b);
+                    const s4_f32x4 vc = finish(1, 0, n, p0, p1, lx1, hy1b), vd = finish(1, 1, n, p0, p1, lx1, hy1b);
                     s4_f32x4 pv;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pv[r] = (((va[r] + vb[r]) + vc[r]) + vd[r]) * 0.25f;   // order of avgpool2_kernel
@@ -702,11 +698,11 @@ static int launch_s41_cfg(const ConvArgs &a0, int B, hipStream_t s) {
     if (a.res) {
         a.res_rows = res_extent(C::TH, a.res_sh);
         a.res_cols = res_extent(C::TW, a.res_sw);
-        const int csp = res_chan_pieces(a.res_rows, a.res_cols);                   // 16-B pieces per channel
-        const size_t need = (size_t)NT * 16 * csp * 16;
-        if (need > 64 * 1024 || (size_t)NT * 16 * csp >= 65536) return fail(PF_EUNSUPPORTED, "conv_s4 1x1: residual window of %zu B does not fit LDS", need);
-        a.res_magic_cs = (unsigned)(0x100000000ull / (unsigned)csp) + 1u;         // exact quotients for dividends < 2^16
-        a.res_magic_cols = (unsigned)(0x100000000ull / (unsigned)res_piece_cols(a.res_cols)) + 1u;
+        const int cs = res_chan_stride(a.res_rows, a.res_cols);
+        const size_t need = (size_t)NT * 16 * cs * sizeof(float);
+        if (need > 64 * 1024 || (size_t)NT * 16 * cs >= 65536) return fail(PF_EUNSUPPORTED, "conv_s4 1x1: residual window of %zu B does not fit LDS", need);
+        a.res_magic_cs = (unsigned)(0x100000000ull / (unsigned)cs) + 1u;          // exact quotients for dividends < 2^16
+        a.res_magic_cols = (unsigned)(0x100000000ull / (unsigned)a.res_cols) + 1u;
         a.res_lds_off = C::MAIN / 4;
         lds = C::MAIN + align_up(need, 256);
     }

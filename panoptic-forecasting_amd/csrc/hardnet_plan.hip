@@ -259,7 +259,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             bool res_fits = true;
             if (a.res) {
                 const int nt1 = r.nt < 1 ? 1 : (r.nt > a.ntiles ? a.ntiles : r.nt);
-                res_fits = (size_t)nt1 * 16 * res_chan_pieces(res_extent(8, a.res_sh), res_extent(32, a.res_sw)) * 16 <= 60 * 1024;
+                res_fits = (size_t)nt1 * 16 * res_chan_stride(res_extent(8, a.res_sh), res_extent(32, a.res_sw)) * sizeof(float) <= 60 * 1024;
             }
             r.can_read = s4_allowed && !generic && o.stride == 1 && o.kind == OP_CONV && p->conv[i].has_s4 && (need == 0 || o.k == 1) && want &&
                          res_fits && ((a.src_begin == 0 && a.src_end == a.n_src) || p->conv[i].s4_pad);
