@@ -166,3 +166,14 @@ def make_state_dict(seed=1234, in_ch=36, n_cls=11, calib=None, depth_norm=(20.0,
             sd[p + '.weight'] = torch.from_numpy(w)
             sd[p + '.bias'] = torch.from_numpy(b)
     return sd
+
+
+def make_pretrained_checkpoint(seed=77):
+    """A synthetic FC-HarDNet "pretrain_path" pickle payload: the 19-class, 3-channel-stem network the reference's
+    ``build_hardnet`` loads (hardnet.py:390-400: ``torch.load(path)['model_state']`` with ``module.``-prefixed keys)."""
+    sd = make_state_dict(seed=seed, in_ch=3, n_cls=19)
+    out = {}
+    for k, v in sd.items():
+        if k.startswith('model.'):
+            out['module.' + k[len('model.'):]] = v
+    return {'model_state': out}

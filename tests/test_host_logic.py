@@ -90,3 +90,25 @@ def test_pq_accumulators_add_across_shards():
     parts = pq.pq_accumulate(pred[0::2], gt[0::2], 11) + pq.pq_accumulate(pred[1::2], gt[1::2], 11)
     assert torch.equal(whole[:, 1:], parts[:, 1:])                 # integer counts add exactly
     assert (whole[:, 0] - parts[:, 0]).abs().max() < 1e-12
+
+
+def test_pretrained_checkpoint_path_matches_reference(tmp_path):
+    """params['model']['hardnet']['pretrain_path'] (hardnet.py:390-400, bg_model.py:45-48): the 19-class / RGB-stem pickle is
+    loaded with its ``module.`` prefix stripped, the stem is averaged over RGB and tiled to the 36 input channels, the
+    19-class head is replaced by a fresh one.  g7_pretrained.npz holds what the reference's own BGModel.__init__ made of the
+    same synthetic pickle (tests/golden/make_golden_pretrained.py): every tensor but the re-initialised head must agree."""
+    from panoptic_forecasting_amd.bg_model import BGModel
+    path = str(tmp_path / 'hardnet70_pretrained.pkl')
+    torch.save(synth.make_pretrained_checkpoint(seed=77), path)
+    params = {'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])]},
+              'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True, 'hardnet': {'pretrain_path': path}}}
+    sd = BGModel(params).state_dict()
+    g = np.load(os.path.join(GOLDEN, 'g7_pretrained.npz'))
+    keys = [str(k) for k in g['keys']]
+    assert sorted(k for k in sd if not k.startswith('model.finalConv')) == keys
+    for k, (s1, s2) in zip(keys, g['sums']):
+        v = sd[k].double()
+        assert abs(float(v.sum()) - s1) <= 1e-9 * max(1.0, abs(s1)), k
+        assert abs(float((v ** 2).sum()) - s2) <= 1e-9 * max(1.0, abs(s2)), k
+    assert np.array_equal(sd['model.base.0.conv.weight'].numpy(), g['stem'])
+    assert tuple(sd['model.finalConv.weight'].shape) == tuple(g['final_shape'])
