@@ -16,7 +16,7 @@ when the ranks that joined differ from ``--gpus`` or the node has fewer GPUs tha
 
 At N=1 the same line also carries (driver-timed, same process):
     by_batch   frames/s of ONE stream at B = 1, 2, 4 frames per step (SURVEY.md 8d Config 2; the reference loop batches 2)
-    fp32_only  the headline workload with every convolution on the fp32 MFMA (no bf16 operand split) + its parity
+    fp32_only  the headline workload with every convolution on the fp32 MFMA (no two-term fp16 operands) + its parity
     roofline   dominant kernel (live hipEvent timing) + ``step``: whole-step algorithmic bytes / kernel time, per stage
     cpu_baseline  the oracle pipeline on all host cores
 """
@@ -41,7 +41,7 @@ from panoptic_forecasting_amd import synth  # noqa: E402
 H, W, T = 1024, 2048, 3
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec (6.3 TB/s achievable)
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (2495 measured)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 (2495 measured; tools/ubench/f16_split.hip: same rate)
 CPU_BUDGET_S = 20.0             # stop starting new baseline frames after this much CPU time
 SUB_BATCH = 16                  # frames per concurrent sub-batch of the headline workload
 
@@ -267,9 +267,9 @@ def roofline_of(recs, n_steps, frames, measured_on):
     if dom['flops'] > 0:
         achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
         if 'conv_split' in dom['label'] or 'conv_s4' in dom['label']:
-            # every algorithmic fp32 MAC is 3 bf16 MFMA MACs (hi*hi + hi*mid + mid*hi): the matrix ceiling of this
-            # scheme, in algorithmic flops, is the dense bf16 peak / 3
-            peak, note = PEAK_BF16_MFMA_TFLOPS / 3.0, 'dense bf16 MFMA peak 2500 TFLOP/s / 3 products per fp32 MAC'
+            # every algorithmic fp32 MAC is 3 fp16 MFMA MACs (hi*hi + hi*mid + mid*hi): the matrix ceiling of this
+            # scheme, in algorithmic flops, is the dense 16-bit peak / 3
+            peak, note = PEAK_BF16_MFMA_TFLOPS / 3.0, 'dense fp16/bf16 MFMA peak 2500 TFLOP/s / 3 products per fp32 MAC'
         else:
             peak, note = PEAK_FP32_MFMA_TFLOPS, 'fp32 MFMA (= fp32 vector) peak'
         mf, hf = achieved / peak, gbs / PEAK_HBM_GBPS
@@ -342,8 +342,8 @@ def parse_args(argv=None):
     ap.add_argument('--no-legs', action='store_true', help='skip the by_batch / fp32_only legs (N=1 only)')
     ap.add_argument('--cpu-frames', type=int, default=12)
     ap.add_argument('--profile-steps', type=int, default=3)
-    ap.add_argument('--fp32-mfma-only', action='store_true', help='headline itself without the bf16-split kernels '
-                    "(model param split_bf16=0): every convolution on v_mfma_f32_16x16x4_f32 / the fp32 VALU")
+    ap.add_argument('--fp32-mfma-only', action='store_true', help='headline itself without the split kernels '
+                    "(model param split_f16=0): every convolution on v_mfma_f32_16x16x4_f32 / the fp32 VALU")
     ap.add_argument('--streams', type=int, default=0, help='sub-batches run concurrently on this many HIP streams '
                     '(0 = one per 16 frames of the batch)')
     ap.add_argument('--term', choices=['short', 'mid'], default='short',
@@ -406,7 +406,7 @@ def main():
     B = args.batch
     S = max(1, min(args.streams, B)) if args.streams > 0 else max(1, B // SUB_BATCH)
     use_graph = not args.no_graph
-    head_kw = {'split_bf16': 0} if args.fp32_mfma_only else {}
+    head_kw = {'split_f16': 0} if args.fp32_mfma_only else {}
     wl = Workload(sd, B, S, dev, seed0=rank * B, term=args.term, use_graph=use_graph, **head_kw)
     elapsed = wl.timed(args.steps, args.warmup, dev, barrier=True)
     frames = world * B * args.steps
@@ -478,8 +478,8 @@ def main():
             del leg
             torch.cuda.empty_cache()
         if not args.fp32_mfma_only:
-            # strict-precision configuration: no bf16 operand split anywhere (fp32 MFMA / fp32 VALU only)
-            leg = Workload(sd, B, S, dev, seed0=0, term=args.term, use_graph=use_graph, split_bf16=0)
+            # fp32-instruction configuration: no two-term fp16 operands anywhere (fp32 MFMA / fp32 VALU only)
+            leg = Workload(sd, B, S, dev, seed0=0, term=args.term, use_graph=use_graph, split_f16=0)
             dt = leg.timed(args.steps, args.warmup, dev)
             fp32_only = {'value': B * args.steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / args.steps,
                          'frames_per_gpu_per_step': B, 'streams': S, 'dtype': 'f32'}
@@ -489,7 +489,7 @@ def main():
                                                          'kernel_ms_per_step')}
             fp32_only['roofline_step_frac'] = r32['step']['frac']
             if ref is not None:
-                p32 = parity_of(leg.subs[0], {'split_bf16': 0})
+                p32 = parity_of(leg.subs[0], {'split_f16': 0})
                 fp32_only['max_abs_dlogit'] = p32['max_abs_dlogit_vs_oracle']
                 fp32_only['argmax_agreement_vs_oracle'] = p32['argmax_agreement_vs_oracle']
             del leg
@@ -500,7 +500,7 @@ def main():
                 'n_gpus': joined, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                 'dtype': 'f32' if args.fp32_mfma_only else 'f32 (storage, accumulation, strided/low-res convs: fp32 MFMA; tuned 3x3 and 1x1 layers: '
-                         'operands split into bf16 hi+mid, 3 products on the bf16 MFMA, fp32 accumulate)', 'data': 'synthetic',
+                         'operands split into two fp16 terms hi+mid (22 significand bits), 3 products on the fp16 MFMA, fp32 accumulate)', 'data': 'synthetic',
                 'config': {'workload': ('configs[1]: bg short-term forecast, 3 frames in, dt=3' if args.term == 'short' else
                                         'configs[2]: bg mid-term forecast, 3 frames in, dt=9, predicted-odometry ego chain') +
                                        ', 1024x2048, random-init calibrated weights; step = 3 warp/splats + HarDNet + upsample/argmax',

@@ -188,9 +188,12 @@ int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void 
  *                   evaluated as W_skip*skip + up(W_x*x): same result up to fp32 rounding, no upsampled tensor;
  *   "use_tuned_table" (default 1) per-layer kernel shapes come from the measured table (csrc/conv_tuned.inc) where it
  *                   has the shape, else from the cost model; 0 = cost model only (tools/tune_convs.py);
- *   "split_bf16"    (default 1) the table may select conv_split for stride-1 3x3 layers: fp32 operands split into bf16
- *                   hi+mid terms, three products on v_mfma_f32_16x16x32_bf16, fp32 accumulation (single layers within
- *                   2e-4*(1+max|ref|) of fp64; the fp32 kernels 2e-5); 0 = every convolution on fp32 MFMA / fp32 VALU;
+ *   "split_f16"     (default 1; "split_bf16", its name while the terms were bf16, is still accepted) the table may select
+ *                   the split kernels (conv_split, conv_s4) for stride-1 3x3 and 1x1 layers: every fp32 operand split into
+ *                   two fp16 terms hi + mid (22 significand bits; weights pre-scaled by an exact power of two per conv),
+ *                   three products on v_mfma_f32_16x16x32_f16, fp32 accumulation - single layers within 2e-5*(1+max|ref|)
+ *                   of fp64 like the fp32 kernels, whole-network logits within 1e-4 either way; activations beyond
+ *                   +-65504 lose precision and saturate at +-131008; 0 = every convolution on fp32 MFMA / fp32 VALU;
  *   "valu_remainder" (default 1) trailing cout % 16 <= 8 channels of a conv_dma layer on the vector ALU. */
 int pf_set_option(const char *name, int value);
 /* The same options per plan: a plan copies the process-wide values when it is created; this call changes them for
@@ -198,7 +201,7 @@ int pf_set_option(const char *name, int value);
  * name exists only here:
  *   "table_batch"   (default 0) n > 0: the per-layer kernel table is consulted as if every forward had a batch of n —
  *                   a frame's logits then do not depend on how many frames share the call (the tuned table is keyed on
- *                   the batch size, and the bf16-split and fp32 kernels differ in the last bits). */
+ *                   the batch size, and the split and fp32 kernels differ in the last bits). */
 int pf_hardnet_plan_set_option(pf_plan *plan, const char *name, int value);
 
 /* ------------------------------------------------------------------------------------------
@@ -246,8 +249,8 @@ int pf_sgd_step(float *theta, float *grad, float *momentum_buf, const uint8_t *t
 int pf_hardnet_tensor_view(const pf_plan *plan, const char *name, int B, int H, int W,
                            size_t *ws_offset, int *channels, int *h, int *w);
 /* Copy tensor `name` of the LAST forward of this plan out of its workspace as fp32 NCHW [B,channels,h,w].  Intermediate
- * tensors may live in the packed-pair layout of conv_s4.hip (plan option "packed_acts", on by default): two bf16 terms
- * hi = bf16(x), mid = bf16(x - hi) per element in [B][2][ceil(C/4)][H][W][4] order - this call undoes it. */
+ * tensors may live in the packed-pair layout of conv_s4.hip (plan option "packed_acts", on by default): two fp16 terms
+ * hi = fp16(x), mid = fp16(x - hi) per element in [B][2][ceil(C/4)][H][W][4] order - this call undoes it. */
 int pf_hardnet_tensor_read(const pf_plan *plan, const char *name, int B, int H, int W, const void *ws, float *dst, void *stream);
 /* fp32 NCHW <-> packed-pair layout (dst of pf_s4_pack: 16 * B * ceil(C/4) * H * W bytes); tests and tensor taps */
 int pf_s4_pack(const float *src, void *dst, int B, int C, int H, int W, void *stream);

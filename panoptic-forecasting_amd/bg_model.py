@@ -20,7 +20,7 @@ from .pc_transform_model import _as_u8
 
 
 # params['model'] key -> option name of pf_hardnet_plan_set_option
-PLAN_OPTIONS = {'split_bf16': 'split_bf16', 'fuse_pool': 'fuse_pool', 'fuse_upsample': 'fuse_upsample',
+PLAN_OPTIONS = {'split_f16': 'split_f16', 'split_bf16': 'split_f16', 'fuse_pool': 'fuse_pool', 'fuse_upsample': 'fuse_upsample',
                 'use_tuned_table': 'use_tuned_table', 'valu_remainder': 'valu_remainder', 'conv_table_batch': 'table_batch'}
 
 
@@ -105,8 +105,9 @@ class BGModel(BaseModel):
         if pretrain is not None:
             self.model.load_pretrained(pretrain)
         # execution options of this model's device plan (include/pfhip.h: pf_hardnet_plan_set_option); absent keys keep
-        # the library defaults.  ``split_bf16: 0`` = strict fp32 arithmetic in every convolution (logits within 1e-4 of
-        # the fp32 reference instead of 1e-3); ``conv_table_batch: n`` pins the per-layer kernel choice to the one made
+        # the library defaults.  ``split_f16: 0`` (``split_bf16`` is the same switch under its round-1 name) = fp32 matrix
+        # instructions in every convolution instead of two-term fp16 operands (logits within 1e-4 of the fp32 reference
+        # either way, the fp16-pair path is 1.8x faster); ``conv_table_batch: n`` pins the per-layer kernel choice to the one made
         # for batches of n, so a frame's logits do not depend on the size of the batch it arrives in.
         self.plan_options = {c_name: int(params['model'][key]) for key, c_name in PLAN_OPTIONS.items()
                              if params['model'].get(key) is not None}

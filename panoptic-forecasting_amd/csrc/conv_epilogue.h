@@ -156,39 +156,35 @@ __device__ __forceinline__ epi_f32x4 quad_transpose(epi_f32x4 v) {
     return v;
 }
 
-typedef __bf16 epi_bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 epi_bf16x4 __attribute__((ext_vector_type(4)));
+typedef split_x2 epi_h2;   // fp16 terms of the operand split (conv_mfma.h)
+typedef split_x4 epi_h4;
 
 // c = 4 consecutive channels (buffer channels chb .. chb+3, chb even) of the pixel at element offset `pix` of an h x w plane
 __device__ __forceinline__ void s4_store_unit(const ConvArgs &a, int b, int chb, size_t plane_px, size_t pix, epi_f32x4 c) {
-    epi_bf16x4 hi, mid;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        hi[r] = (__bf16)c[r];
-        mid[r] = (__bf16)(c[r] - (float)hi[r]);
-    }
+    epi_h4 hi, mid;
+    split_terms4(c, hi, mid);
     const size_t term = (size_t)a.dst_c4 * plane_px * 8;                      // bytes between the hi and the mid block
     char *base = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8;
     const bool ok0 = chb < a.dst_limit, ok1 = chb + 2 < a.dst_limit;
     if ((chb & 3) == 0) {
         char *p = base + (size_t)(chb >> 2) * plane_px * 8;
         if (ok1) {
-            *reinterpret_cast<epi_bf16x4 *>(p) = hi;
-            *reinterpret_cast<epi_bf16x4 *>(p + term) = mid;
+            *reinterpret_cast<epi_h4 *>(p) = hi;
+            *reinterpret_cast<epi_h4 *>(p + term) = mid;
         } else if (ok0) {
-            *reinterpret_cast<epi_bf16x2 *>(p) = epi_bf16x2{hi[0], hi[1]};
-            *reinterpret_cast<epi_bf16x2 *>(p + term) = epi_bf16x2{mid[0], mid[1]};
+            *reinterpret_cast<epi_h2 *>(p) = epi_h2{hi[0], hi[1]};
+            *reinterpret_cast<epi_h2 *>(p + term) = epi_h2{mid[0], mid[1]};
         }
     } else {   // the range starts in the middle of a group: upper half of one group, lower half of the next
         char *p = base + (size_t)(chb >> 2) * plane_px * 8 + 4;
         if (ok0) {
-            *reinterpret_cast<epi_bf16x2 *>(p) = epi_bf16x2{hi[0], hi[1]};
-            *reinterpret_cast<epi_bf16x2 *>(p + term) = epi_bf16x2{mid[0], mid[1]};
+            *reinterpret_cast<epi_h2 *>(p) = epi_h2{hi[0], hi[1]};
+            *reinterpret_cast<epi_h2 *>(p + term) = epi_h2{mid[0], mid[1]};
         }
         p += plane_px * 8 - 4;
         if (ok1) {
-            *reinterpret_cast<epi_bf16x2 *>(p) = epi_bf16x2{hi[2], hi[3]};
-            *reinterpret_cast<epi_bf16x2 *>(p + term) = epi_bf16x2{mid[2], mid[3]};
+            *reinterpret_cast<epi_h2 *>(p) = epi_h2{hi[2], hi[3]};
+            *reinterpret_cast<epi_h2 *>(p + term) = epi_h2{mid[2], mid[3]};
         }
     }
 }

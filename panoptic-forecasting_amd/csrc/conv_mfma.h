@@ -43,9 +43,11 @@ struct ConvArgs {
     int chunk_begin, chunk_end;  // = src_chunk0[src_begin], src_chunk0[src_end] (filled at launch)
     long long *probe;        // PF_PROBE builds only: in-kernel timestamps of workgroup 0 / wave 0 (else nullptr)
     int accum;               // generic kernel (conv_mfma.hip) only: dst += result (gradient accumulation of the training path)
+    float acc_scale;         // split kernels (conv_split.hip, conv_s4.hip) only: their weights are packed as fp16 terms of
+                             // w * 2^k (k per conv, split_weight_scale()); the raw sums are multiplied by 2^-k (exact)
     // ---- packed-pair ("S4") activation layout, conv_s4.hip: a tensor of C channels is stored as
-    //      [B][2 terms: hi, mid][C4 = ceil(C/4)][H][W][4] bf16 with x ~= hi + mid, hi = bf16(x), mid = bf16(x - hi): the same
-    //      4 B per element as fp32 and exactly the two terms the bf16-split kernels feed the matrix pipe with
+    //      [B][2 terms: hi, mid][C4 = ceil(C/4)][H][W][4] fp16 with x ~= hi + mid (split_terms() below): the same
+    //      4 B per element as fp32 and exactly the two terms the split kernels feed the matrix pipe with
     int dst_fmt;             // 0: fp32 NCHW, 1: S4 (epi_store / epi_store_pooled of conv_epilogue.h)
     int dst_c4;              // channel groups of the dst tensor
     int dst_limit;           // S4: stores cover buffer channels [dst_choff, dst_limit) = dst_choff + Cout, rounded up to a
@@ -57,6 +59,49 @@ struct ConvArgs {
     int src_ent0[kConvMaxSrc + 1];// first K entry of each range ("group entries": one group of one range; padded per range to
                                   // whole rounds when the conv was packed with pad_sources)
 };
+
+// ---- the two-term operand split of conv_split.hip / conv_s4.hip ------------------------------------------------------
+// Every fp32 operand x of a convolution is fed to the 16-bit matrix pipe as x ~= hi + mid with TWO fp16 TERMS:
+//     hi = fp16(x),  mid = fp16(x - hi)          (x - hi is exact in fp32)
+// 11 + 11 significand bits: |x - hi - mid| <= 2^-21 |x| (and never more than one fp16 subnormal step, 6e-8, for small
+// |x|), against 2^-17 |x| for a pair of bf16 terms at the same storage, the same instruction rate
+// (v_mfma_f32_16x16x32_f16) and the same three products hi*hi + hi*mid + mid*hi.  The price is fp16's range, paid this way:
+//   * activations: both conversions round toward zero (v_cvt_pkrtz_f16_f32, two values per instruction), which SATURATES
+//     at +-65504 instead of producing inf: hi + mid is x to 2^-21 up to |x| = 65504, to 2^-11 up to 131008 (hi is pinned
+//     at 65504 there and mid carries the rest), and clamps beyond (FC-HarDNet activations behind folded BatchNorm are
+//     O(1..100); the split kernels' results stay finite for any finite input);
+//   * weights: packed on the host (round to nearest even) after an exact per-conv scaling by 2^k that puts max|w| into
+//     [2^14, 2^15) - small weights keep both terms in fp16's normal range - and the kernels multiply their raw sums
+//     by 2^-k (ConvArgs::acc_scale) before the bias: exact, so the scaling is invisible in the result.
+// v_mfma_f32_16x16x32_f16 multiplies fp16 subnormals exactly (measured: tools/ubench/f16_split.hip).
+typedef _Float16 split_t;
+typedef split_t split_x2 __attribute__((ext_vector_type(2)));
+typedef split_t split_x4 __attribute__((ext_vector_type(4)));
+typedef split_t split_x8 __attribute__((ext_vector_type(8)));
+// two values at a time: {hi0, hi1}, {mid0, mid1}
+__device__ __forceinline__ void split_terms2(float x0, float x1, split_x2 &hi, split_x2 &mid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __fp16 rtz2 __attribute__((ext_vector_type(2)));
+    const rtz2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const rtz2 m = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+    hi = __builtin_bit_cast(split_x2, h);
+    mid = __builtin_bit_cast(split_x2, m);
+#endif
+}
+template <typename V4>   // any 4-float vector type
+__device__ __forceinline__ void split_terms4(const V4 &v, split_x4 &hi, split_x4 &mid) {
+    split_x2 h0, m0, h1, m1;
+    split_terms2(v[0], v[1], h0, m0);
+    split_terms2(v[2], v[3], h1, m1);
+    hi = split_x4{h0[0], h0[1], h1[0], h1[1]};
+    mid = split_x4{m0[0], m0[1], m1[0], m1[1]};
+}
+#define PF_MFMA_SPLIT(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+// host side (weight packing): fp32 -> fp16 bits, round to nearest even, subnormals kept; and back
+unsigned short split_host_f16(float x);
+float split_host_f32(unsigned short h);
+// 2^k with max|w| * 2^k in [2^14, 2^15) (1 for an all-zero tensor)
+float split_weight_scale(const float *w, size_t n);
 
 // Tiling choice for one conv (depends on shape only; fixed at plan time for the weight packing).
 struct ConvTiling {
@@ -115,8 +160,9 @@ size_t valu_packed_floats(const int *src_ch, int n_src, int cout);
 void pack_conv_weights_valu(const float *w_oihw, int cin, int cout, const int *src_ch, int n_src, float *out);
 int launch_conv_valu(const ConvArgs &a, int rows, int B, hipStream_t stream);
 
-// bf16-split path (conv_split.hip; 3x3/s1, Wout % 4 == 0, no fused epilogue; opt-in: results differ from the fp32
-// kernels by ~1e-5 relative): a.wpk must point at pack_conv_weights_split() output, chunks of 8 channels.
+// split path (conv_split.hip; 3x3/s1, Wout % 4 == 0, no fused epilogue; two fp16 terms per operand, see split_terms2
+// above): a.wpk must point at pack_conv_weights_split() output, chunks of 8 channels; the packers take the weights
+// ALREADY multiplied by split_weight_scale() and a.acc_scale = 1 / that scale.
 int split_chunks(const int *src_ch, int n_src);
 size_t split_packed_floats(const int *src_ch, int n_src, int cout);
 void pack_conv_weights_split(const float *w_oihw, int cin, int cout, const int *src_ch, int n_src, float *out);

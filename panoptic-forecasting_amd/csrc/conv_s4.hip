@@ -1,11 +1,11 @@
-// Convolutions on activations stored PRE-SPLIT ("S4" layout, conv_mfma.h): the bf16-split scheme of conv_split.hip without its
+// Convolutions on activations stored PRE-SPLIT ("S4" layout, conv_mfma.h): the operand-split scheme of conv_split.hip without its
 // memory side.
 //
 // conv_split.hip reads fp32 NCHW, and every consumer of a tensor splits it again: per round of 8 channels a thread holds 32
 // staging registers, spends 15-20 % of the round on conversions + 8 ds_write_b128 and needs two barriers because the
 // activation buffer cannot be overwritten while it is read (profiles/r02_experiments.md: the memory side and the matrix
 // side of a 91->28 layer need 285 and 318 us alone and 406 us together).  Here the PRODUCER's epilogue writes
-//     [B][2 terms: hi, mid][C4 = ceil(C/4)][H][W][4 channels] bf16       hi = bf16(x), mid = bf16(x - hi)
+//     [B][2 terms: hi, mid][C4 = ceil(C/4)][H][W][4 channels] fp16       hi = fp16(x), mid = fp16(x - hi)
 // - the same 4 B per element as fp32 and exactly what these consumers feed the matrix pipe with, so nothing is lost for
 // them - and a consumer's halo tile arrives by LDS-DMA (buffer_load_dwordx4 ... lds, 16 B = 2 pixels x 4 channels of one
 // term; out-of-image pieces carry an out-of-range offset and land as zeros = the convolution's padding): no staging
@@ -51,12 +51,12 @@
 namespace pf {
 
 typedef float s4_f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 s4_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 s4_bf16x4 __attribute__((ext_vector_type(4)));
+typedef split_x8 s4_h8;   // 8 / 4 fp16 terms (conv_mfma.h: split_terms2)
+typedef split_x4 s4_h4;
 typedef __attribute__((address_space(3))) void *s4_lds_ptr_t;
 [[maybe_unused]] constexpr unsigned kS4Oob = 0x80000000u;
 
-__device__ __forceinline__ s4_bf16x8 s4_join(s4_bf16x4 lo, s4_bf16x4 hi) {
+__device__ __forceinline__ s4_h8 s4_join(s4_h4 lo, s4_h4 hi) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -90,7 +90,7 @@ struct S4Cfg {
     static constexpr int NDMA = (PIECES + 63) / 64;                       // DMA instructions per plane (one wave per plane)
     static constexpr int PLANE = NDMA * 64 * 16;                          // bytes
     static constexpr int ABUF = 4 * PLANE;                                // [term][entry] per stage
-    static constexpr int WBLK = 2 * 64 * 16;                              // one instruction's weights of one cout tile: [term][lane][8 bf16]
+    static constexpr int WBLK = 2 * 64 * 16;                              // one instruction's weights of one cout tile: [term][lane][8 fp16]
     static constexpr int WBUF = NT * 3 * WBLK;                            // [nt][block: instr 0, instr 1, collected tap][term][lane]
     static constexpr int WPIECES = WBUF / 16, NITW = (WPIECES + 255) / 256;
     static constexpr size_t LDS_BYTES = 2 * (size_t)ABUF + 2 * (size_t)WBUF;
@@ -201,8 +201,8 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT 
     static_assert(S4_ISSUE_FIRST + (C::NDMA - 1) * S4_ISSUE_STEP < 6 * HALVES, "every DMA part needs a slot inside the two full instructions");
 
     // collected tap: K-slice g of these fragments = entries of round 4q + g
-    s4_bf16x8 col_h[C::MP], col_m[C::MP];
-    const s4_bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    s4_h8 col_h[C::MP], col_m[C::MP];
+    const s4_h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int m = 0; m < C::MP; ++m) col_h[m] = col_m[m] = zero8;
 
@@ -220,43 +220,43 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT 
         if (more) prepare_round(round + 1);
         S4_PROBE(round * 4 + 2);
         const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
-        auto frag = [&](const unsigned char *p, s4_bf16x8 &h, s4_bf16x8 &md) {
-            h = s4_join(*reinterpret_cast<const s4_bf16x4 *>(p), *reinterpret_cast<const s4_bf16x4 *>(p + C::PLANE));
-            md = s4_join(*reinterpret_cast<const s4_bf16x4 *>(p + 2 * C::PLANE), *reinterpret_cast<const s4_bf16x4 *>(p + 3 * C::PLANE));
+        auto frag = [&](const unsigned char *p, s4_h8 &h, s4_h8 &md) {
+            h = s4_join(*reinterpret_cast<const s4_h4 *>(p), *reinterpret_cast<const s4_h4 *>(p + C::PLANE));
+            md = s4_join(*reinterpret_cast<const s4_h4 *>(p + 2 * C::PLANE), *reinterpret_cast<const s4_h4 *>(p + 3 * C::PLANE));
         };
         auto mtile_off = [&](int mm) { return ((mm / C::MTR) * C::IW + (mm % C::MTR) * 16) * 8; };
         // the three products of one block of weights with 4 M-tiles; `slot0` numbers the MFMA groups for the DMA parts
-        auto products = [&](int blk, int m0, const s4_bf16x8 (&fh)[4], const s4_bf16x8 (&fm)[4], int slot0, bool dma) {
-            s4_bf16x8 wh[NT], wm[NT];
+        auto products = [&](int blk, int m0, const s4_h8 (&fh)[4], const s4_h8 (&fm)[4], int slot0, bool dma) {
+            s4_h8 wh[NT], wm[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                wh[n] = *reinterpret_cast<const s4_bf16x8 *>(wb + (((n * 3 + blk) * 2 + 0) * 64 + lane) * 16);
-                wm[n] = *reinterpret_cast<const s4_bf16x8 *>(wb + (((n * 3 + blk) * 2 + 1) * 64 + lane) * 16);
+                wh[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * 3 + blk) * 2 + 0) * 64 + lane) * 16);
+                wm[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * 3 + blk) * 2 + 1) * 64 + lane) * 16);
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], fm[m], acc[m0 + m][n], 0, 0, 0);
+                    acc[m0 + m][n] = PF_MFMA_SPLIT(wh[n], fm[m], acc[m0 + m][n]);
             if (dma) issue_slot(round, more, slot0 + 0);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[n], fh[m], acc[m0 + m][n], 0, 0, 0);
+                    acc[m0 + m][n] = PF_MFMA_SPLIT(wm[n], fh[m], acc[m0 + m][n]);
             if (dma) issue_slot(round, more, slot0 + 1);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], fh[m], acc[m0 + m][n], 0, 0, 0);
+                    acc[m0 + m][n] = PF_MFMA_SPLIT(wh[n], fh[m], acc[m0 + m][n]);
             if (dma) issue_slot(round, more, slot0 + 2);
         };
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int hf = 0; hf < HALVES; ++hf) {
-                s4_bf16x8 fh[4], fm[4];
+                s4_h8 fh[4], fm[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) frag(ab + aoff[s] + mtile_off(hf * 4 + m), fh[m], fm[m]);
                 products(s, hf * 4, fh, fm, 3 * (s * HALVES + hf), true);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT 
         if (is_flush(round)) {
 #pragma unroll
             for (int hf = 0; hf < HALVES; ++hf) {
-                s4_bf16x8 fh[4], fm[4];
+                s4_h8 fh[4], fm[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     fh[m] = col_h[hf * 4 + m];
@@ -306,39 +306,35 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT 
                 s4_f32x4 v = acc[m][n];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] += bias4[n][r];
+                    v[r] = v[r] * a.acc_scale + bias4[n][r];   // acc_scale = 2^-k of the weight scaling: exact
                     if (a.relu) v[r] = fmaxf(v[r], 0.f);
                 }
 #ifdef S4_EXP_NOSTORE
                 if (v[0] != 12345.678f) continue;
 #endif
                 if (a.dst_fmt) {
-                    s4_bf16x4 hi, mid;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        hi[r] = (__bf16)v[r];
-                        mid[r] = (__bf16)(v[r] - (float)hi[r]);
-                    }
+                    s4_h4 hi, mid;
+                    split_terms4(v, hi, mid);
                     const int chb = a.dst_choff + co;
                     const bool ok0 = chb < a.dst_limit, ok1 = chb + 2 < a.dst_limit;
                     char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
-                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                    typedef split_x2 h2;
                     if (!mis) {
                         if (ok1) {
-                            *reinterpret_cast<s4_bf16x4 *>(p) = hi;
-                            *reinterpret_cast<s4_bf16x4 *>(p + term) = mid;
+                            *reinterpret_cast<s4_h4 *>(p) = hi;
+                            *reinterpret_cast<s4_h4 *>(p + term) = mid;
                         } else if (ok0) {
-                            *reinterpret_cast<bf2 *>(p) = bf2{hi[0], hi[1]};
-                            *reinterpret_cast<bf2 *>(p + term) = bf2{mid[0], mid[1]};
+                            *reinterpret_cast<h2 *>(p) = h2{hi[0], hi[1]};
+                            *reinterpret_cast<h2 *>(p + term) = h2{mid[0], mid[1]};
                         }
                     } else {   // upper half of one group, lower half of the next
                         if (ok0) {
-                            *reinterpret_cast<bf2 *>(p + 4) = bf2{hi[0], hi[1]};
-                            *reinterpret_cast<bf2 *>(p + 4 + term) = bf2{mid[0], mid[1]};
+                            *reinterpret_cast<h2 *>(p + 4) = h2{hi[0], hi[1]};
+                            *reinterpret_cast<h2 *>(p + 4 + term) = h2{mid[0], mid[1]};
                         }
                         if (ok1) {
-                            *reinterpret_cast<bf2 *>(p + hw * 8) = bf2{hi[2], hi[3]};
-                            *reinterpret_cast<bf2 *>(p + hw * 8 + term) = bf2{mid[2], mid[3]};
+                            *reinterpret_cast<h2 *>(p + hw * 8) = h2{hi[2], hi[3]};
+                            *reinterpret_cast<h2 *>(p + hw * 8 + term) = h2{mid[2], mid[3]};
                         }
                     }
                 } else {
@@ -388,7 +384,7 @@ static int launch_s4_cfg(const ConvArgs &a0, int B, hipStream_t s) {
 template <int NT>
 struct S41Cfg {
     static constexpr int TW = 32, TH = 8, MP = 4;
-    static constexpr int WBUF = NT * 2 * 64 * 16;                   // [nt][term][lane][8 bf16]
+    static constexpr int WBUF = NT * 2 * 64 * 16;                   // [nt][term][lane][8 fp16]
     static constexpr int MAIN = 2 * WBUF;
     static constexpr int WPIECES = WBUF / 16, NITW = (WPIECES + 255) / 256;
 };
@@ -513,11 +509,11 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
             load_round(round + 1, nxt);
         }
         const unsigned char *wb = wbuf(round & 1);
-        s4_bf16x8 bh[NT], bm[NT];
+        s4_h8 bh[NT], bm[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            bh[n] = *reinterpret_cast<const s4_bf16x8 *>(wb + ((n * 2 + 0) * 64 + lane) * 16);
-            bm[n] = *reinterpret_cast<const s4_bf16x8 *>(wb + ((n * 2 + 1) * 64 + lane) * 16);
+            bh[n] = *reinterpret_cast<const s4_h8 *>(wb + ((n * 2 + 0) * 64 + lane) * 16);
+            bm[n] = *reinterpret_cast<const s4_h8 *>(wb + ((n * 2 + 1) * 64 + lane) * 16);
         }
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
@@ -526,14 +522,14 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
                 const s4_u32x4 h0 = cur[rr][0][0], h1 = cur[rr][1][0], m0 = cur[rr][0][1], m1 = cur[rr][1][1];
                 const s4_u32x4 fh = q ? s4_u32x4{h0[2], h0[3], h1[2], h1[3]} : s4_u32x4{h0[0], h0[1], h1[0], h1[1]};
                 const s4_u32x4 fm = q ? s4_u32x4{m0[2], m0[3], m1[2], m1[3]} : s4_u32x4{m0[0], m0[1], m1[0], m1[1]};
-                const s4_bf16x8 ah = __builtin_bit_cast(s4_bf16x8, fh), am = __builtin_bit_cast(s4_bf16x8, fm);
+                const s4_h8 ah = __builtin_bit_cast(s4_h8, fh), am = __builtin_bit_cast(s4_h8, fm);
                 const int m = rr * 2 + q;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[n], am, acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) acc[m][n] = PF_MFMA_SPLIT(bh[n], am, acc[m][n]);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm[n], ah, acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) acc[m][n] = PF_MFMA_SPLIT(bm[n], ah, acc[m][n]);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[n], ah, acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) acc[m][n] = PF_MFMA_SPLIT(bh[n], ah, acc[m][n]);
             }
         if (more) {
 #pragma unroll
@@ -560,13 +556,13 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
         const int Ho = pooled ? a.Hout >> 1 : a.Hout, Wo = pooled ? a.Wout >> 1 : a.Wout;
         const size_t hw = (size_t)Ho * Wo, term = (size_t)a.dst_c4 * hw * 8;
         const bool mis = (a.dst_choff & 2) != 0;
-        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        typedef split_x2 h2;
         // finished values of pixel (rr, q), cout tile n
         auto finish = [&](int rr, int q, int n, const int (&o0)[2], const int (&o1)[2], const float (&lx1)[2], float hy1) {
             s4_f32x4 v = acc[rr * 2 + q][n];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] += bias4[n][r];
+                v[r] = v[r] * a.acc_scale + bias4[n][r];   // acc_scale = 2^-k of the weight scaling: exact
                 if (has_res) {   // same arithmetic as res_apply (conv_epilogue.h)
                     const lds_float *chan = res_lds + (n * 16 + 4 * g + r) * rw.cs;
                     const float lx0 = 1.f - lx1[q], hy0 = 1.f - hy1;
@@ -581,31 +577,27 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
         // store 4 channels (couts co..co+3) of ONE output pixel at element offset pix
         auto store_px = [&](int co, size_t pix, s4_f32x4 v) {
             if (a.dst_fmt) {
-                s4_bf16x4 hi, mid;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    hi[r] = (__bf16)v[r];
-                    mid[r] = (__bf16)(v[r] - (float)hi[r]);
-                }
+                s4_h4 hi, mid;
+                split_terms4(v, hi, mid);
                 const int chb = a.dst_choff + co;
                 const bool ok0 = chb < a.dst_limit, ok1 = chb + 2 < a.dst_limit;
                 char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
                 if (!mis) {
                     if (ok1) {
-                        *reinterpret_cast<s4_bf16x4 *>(p) = hi;
-                        *reinterpret_cast<s4_bf16x4 *>(p + term) = mid;
+                        *reinterpret_cast<s4_h4 *>(p) = hi;
+                        *reinterpret_cast<s4_h4 *>(p + term) = mid;
                     } else if (ok0) {
-                        *reinterpret_cast<bf2 *>(p) = bf2{hi[0], hi[1]};
-                        *reinterpret_cast<bf2 *>(p + term) = bf2{mid[0], mid[1]};
+                        *reinterpret_cast<h2 *>(p) = h2{hi[0], hi[1]};
+                        *reinterpret_cast<h2 *>(p + term) = h2{mid[0], mid[1]};
                     }
                 } else {
                     if (ok0) {
-                        *reinterpret_cast<bf2 *>(p + 4) = bf2{hi[0], hi[1]};
-                        *reinterpret_cast<bf2 *>(p + 4 + term) = bf2{mid[0], mid[1]};
+                        *reinterpret_cast<h2 *>(p + 4) = h2{hi[0], hi[1]};
+                        *reinterpret_cast<h2 *>(p + 4 + term) = h2{mid[0], mid[1]};
                     }
                     if (ok1) {
-                        *reinterpret_cast<bf2 *>(p + hw * 8) = bf2{hi[2], hi[3]};
-                        *reinterpret_cast<bf2 *>(p + hw * 8 + term) = bf2{mid[2], mid[3]};
+                        *reinterpret_cast<h2 *>(p + hw * 8) = h2{hi[2], hi[3]};
+                        *reinterpret_cast<h2 *>(p + hw * 8 + term) = h2{mid[2], mid[3]};
                     }
                 }
             } else {
@@ -618,17 +610,13 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
         auto store_pair = [&](int co, size_t pix, s4_f32x4 v0, s4_f32x4 v1) {
             const int chb = a.dst_choff + co;
             if (a.dst_fmt && !mis && chb + 2 < a.dst_limit) {
-                s4_bf16x8 hi, mid;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    hi[r] = (__bf16)v0[r];
-                    mid[r] = (__bf16)(v0[r] - (float)hi[r]);
-                    hi[4 + r] = (__bf16)v1[r];
-                    mid[4 + r] = (__bf16)(v1[r] - (float)hi[4 + r]);
-                }
+                s4_h4 h0, m0, h1, m1;
+                split_terms4(v0, h0, m0);
+                split_terms4(v1, h1, m1);
+                const s4_h8 hi = s4_join(h0, h1), mid = s4_join(m0, m1);
                 char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
-                *reinterpret_cast<s4_bf16x8 *>(p) = hi;
-                *reinterpret_cast<s4_bf16x8 *>(p + term) = mid;
+                *reinterpret_cast<s4_h8 *>(p) = hi;
+                *reinterpret_cast<s4_h8 *>(p + term) = mid;
             } else if (!a.dst_fmt) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -753,20 +741,6 @@ int launch_conv_s4(const ConvArgs &a, int ks, int nt, int wide, int B, hipStream
 }
 
 // ------------------------------------------------------------------------------------------------ host side: weights
-static unsigned short s4_bf16_rne(float x) {
-    unsigned u;
-    memcpy(&u, &x, 4);
-    if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-static float s4_bf16_f32(unsigned short h) {
-    const unsigned u = (unsigned)h << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-
 // group entries of range j; with pad_sources every range is padded to whole rounds (convs that may run one range at a
 // time: the two halves of a commuted upsample + 1x1, hardnet_plan.hip)
 static int s4_range_groups(const S4Range &r) { return (r.choff + r.ch + 3) / 4 - r.choff / 4; }
@@ -785,7 +759,7 @@ size_t s4_packed_floats(const S4Range *r, int n_src, int cout, int ks, int pad_s
     return (size_t)((cout + 15) / 16) * (ks == 3 ? s4_blocks_total(rounds) : rounds) * 2 * 64 * 4;
 }
 
-// Blocks of [term 2][lane 64][8 bf16]; lane = (cout n = lane & 15, lane group g = lane >> 4), the lane's 8 values = 4 channels
+// Blocks of [term 2][lane 64][8 fp16]; lane = (cout n = lane & 15, lane group g = lane >> 4), the lane's 8 values = 4 channels
 // of two group entries.  1x1: [tile][round], g = entry pair of the round.  3x3: [tile][per round: instr 0, instr 1, and after
 // every 4th (and the last) round the collected-tap block]; instr blocks: g = tap, entries of the round; collected block:
 // g = round 4q + g of its group of four, tap (2,2)
@@ -823,8 +797,8 @@ void pack_conv_weights_s4(const float *w, int cin, int cout, int ks, const S4Ran
                         const int ci = ent_c0[ent] + (e & 3);
                         if (ci >= ent_lo[ent] && ci < ent_hi[ent]) v = w[((size_t)co * cin + ci) * ks * ks + tap];
                     }
-                    const unsigned short hi = s4_bf16_rne(v);
-                    out[o++] = term == 0 ? hi : s4_bf16_rne(v - s4_bf16_f32(hi));
+                    const unsigned short hi = split_host_f16(v);
+                    out[o++] = term == 0 ? hi : split_host_f16(v - split_host_f32(hi));
                 }
     };
     static const int tap3[2][4] = {{0, 1, 3, 4}, {6, 7, 2, 5}};   // ky * 3 + kx of (instr, lane group): see the kernel's aoff
@@ -850,10 +824,10 @@ __global__ void s4_pack_kernel(const float *src, unsigned short *dst, int B, int
         for (int r = 0; r < 4; ++r) {
             const int c = (int)g * 4 + r;
             const float x = c < C ? src[((size_t)b * C + c) * hw + px] : 0.f;
-            const __bf16 h = (__bf16)x;
-            const __bf16 m = (__bf16)(x - (float)h);
-            dst[(((b * 2 + 0) * c4 + g) * hw + px) * 4 + r] = __builtin_bit_cast(unsigned short, h);
-            dst[(((b * 2 + 1) * c4 + g) * hw + px) * 4 + r] = __builtin_bit_cast(unsigned short, m);
+            split_x2 h, m;
+            split_terms2(x, 0.f, h, m);
+            dst[(((b * 2 + 0) * c4 + g) * hw + px) * 4 + r] = __builtin_bit_cast(unsigned short, h[0]);
+            dst[(((b * 2 + 1) * c4 + g) * hw + px) * 4 + r] = __builtin_bit_cast(unsigned short, m[0]);
         }
     }
 }
@@ -862,8 +836,8 @@ __global__ void s4_unpack_kernel(const unsigned short *src, float *dst, int B, i
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t px = i % hw, c = (i / hw) % C, b = i / (hw * C);
         const size_t at = ((c / 4) * hw + px) * 4 + (c & 3);
-        const unsigned h = src[(b * 2 + 0) * c4 * hw * 4 + at], m = src[(b * 2 + 1) * c4 * hw * 4 + at];
-        dst[i] = __uint_as_float(h << 16) + __uint_as_float(m << 16);
+        const unsigned short h = src[(b * 2 + 0) * c4 * hw * 4 + at], m = src[(b * 2 + 1) * c4 * hw * 4 + at];
+        dst[i] = (float)__builtin_bit_cast(split_t, h) + (float)__builtin_bit_cast(split_t, m);
     }
 }
 int launch_s4_pack(const float *src, void *dst, int B, int C, int H, int W, hipStream_t s) {

@@ -64,10 +64,10 @@ ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout
         if (use_tuned && t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == Bt &&
             (!(need & 2) || t.c.kind != 2 || t.c.p0 != 1))
             return t.c;
-    // Untuned shape.  Large stride-1 3x3 layers go to the bf16-split kernel: on every measured shape with >= 64x128
+    // Untuned shape.  Large stride-1 3x3 layers go to the split kernel: on every measured shape with >= 64x128
     // pixels x 4 images it beat the fp32-MFMA kernels by 1.3-2.2x (profiles/README.md); cout tiles per workgroup by
     // channel count, 8x64 tiles where the image is wide enough to still fill the chip.  (The executor falls back to
-    // conv_dma when the layer needs a fused epilogue or split_bf16 is off.)
+    // conv_dma when the layer needs a fused epilogue or split_f16 is off.)
     if (ks == 3 && (need == 0) && (wout & 3) == 0 && (long)B * hout * wout >= 32768) {
         const int nt = cout <= 16 ? 1 : (cout <= 32 ? 2 : 3);
         const long tiles_wide = (long)B * ((hout + 7) / 8) * ((wout + 63) / 64) * (((cout + 15) / 16 + nt - 1) / nt);

@@ -1,13 +1,15 @@
-// 3x3/s1 convolution with fp32 operands SPLIT into bf16 terms on the bf16 matrix pipe of gfx950 (the default for the layers the tuned
-// table gives it; plan option split_bf16 = 0 keeps everything on the fp32 matrix instructions).
+// 3x3/s1 convolution with fp32 operands SPLIT into two fp16 terms on the 16-bit matrix pipe of gfx950 (the default for the layers
+// the tuned table gives it; plan option split_f16 = 0 keeps everything on the fp32 matrix instructions).
 //
 // fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at the fp32 vector rate and shares its budget with the VALU: ~135 TF/s is
-// the ceiling of conv_dma.hip.  v_mfma_f32_16x16x32_bf16 is 16x faster.  Every fp32 value x is split exactly into
-//     x = hi + mid + lo,   hi = bf16(x),  mid = bf16(x - hi)            (both round-to-nearest; x - hi is exact in fp32)
+// the ceiling of conv_dma.hip.  v_mfma_f32_16x16x32_f16 is 16x faster.  Every fp32 value x is split into
+//     x = hi + mid + lo,   hi = fp16(x),  mid = fp16(x - hi)            (x - hi is exact in fp32; conv_mfma.h: split_terms2)
 // and a product a*b is evaluated as  a_hi*b_hi + a_hi*b_mid + a_mid*b_hi  in fp32 accumulators: three matrix
-// instructions instead of one at 3/16 of the time.  The dropped terms (a_mid*b_mid, a*b_lo, a_lo*b) are <= 2^-16 of
-// the product each, so a K-term dot product carries a relative error of ~2^-16/sqrt(K)..2^-16: logits agree with the
-// fp32 path to ~1e-4 (tests/test_gpu_conv.py::test_split_bf16_conv states 2e-4*(1+max|ref|); the fp32 kernels 2e-5).
+// instructions instead of one at 3/16 of the time.  The dropped terms (a_mid*b_mid, a*b_lo, a_lo*b) are <= 2^-21 of
+// the product each - below the rounding of the fp32 accumulation itself: the tests hold these kernels to the tolerance of
+// the fp32 kernels (tests/test_gpu_conv.py: 2e-5*(1+max|ref|)) and whole-network logits move by 4e-5 either way.  (Round 1
+// and most of round 2 used bf16 terms, 8 + 8 bits: 2^-16 per product, 5e-4 on the logits, same speed.)  fp16's range is
+// handled by saturating conversions for activations and an exact power-of-two scaling of the weights (conv_mfma.h).
 // Inputs and outputs stay fp32 NCHW: the split happens inside the kernel, so the path is a drop-in for single layers.
 //
 // GEMM view: M = 16 pixels of a row, N = 16 output channels, K = 32 per instruction = 8 input channels x 4 TAPS: lane l
@@ -36,7 +38,7 @@
 namespace pf {
 
 typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef split_x8 sp_h8;   // 8 fp16 terms (conv_mfma.h: split_terms2)
 typedef __attribute__((address_space(3))) void *sp_lds_ptr_t;
 [[maybe_unused]] constexpr unsigned kSplitOob = 0x80000000u;
 
@@ -45,8 +47,8 @@ struct SplitCfg {
     static constexpr int KC = 8, TW = TW_, TH = 8, MTR = TW / 16, MP = 2 * MTR;   // 4 waves x MP M-tiles = 8 rows x TW pixels
     static constexpr int IW = TW + 8, IH = TH + 2, NPIX = IH * IW;       // halo tile with a 4-pixel apron left/right
     static constexpr int GW = IW / 4, NGRP = IH * GW;                    // 4-pixel groups: one per thread (<= 256)
-    static constexpr int ABUF = 2 * NPIX * 16;                           // bytes: [term][pixel][8 bf16]
-    static constexpr int WBUF = NT * 3 * 2 * 64 * 16;                    // bytes: [nt][step][term][lane][8 bf16]
+    static constexpr int ABUF = 2 * NPIX * 16;                           // bytes: [term][pixel][8 fp16]
+    static constexpr int WBUF = NT * 3 * 2 * 64 * 16;                    // bytes: [nt][step][term][lane][8 fp16]
     // ONE activation buffer (an extra barrier per round before it is overwritten) and two weight buffers: 47-49 KB for the
     // common shapes = 3 workgroups per CU; double-buffering the activations as well (70 KB, 2 per CU) measured ~10 % slower
     static constexpr size_t LDS_BYTES = (size_t)ABUF + 2 * (size_t)WBUF;
@@ -147,15 +149,16 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
         if (tid >= C::NGRP) return;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            sp_bf16x8 hi, mid;
+            sp_h8 hi, mid;
 #pragma unroll
-            for (int c = 0; c < C::KC; ++c) {
-                const __bf16 h = (__bf16)xr[c][k];
-                hi[c] = h;
-                mid[c] = (__bf16)(xr[c][k] - (float)h);
+            for (int c = 0; c < C::KC; c += 2) {
+                split_x2 h, m;
+                split_terms2(xr[c][k], xr[c + 1][k], h, m);
+                hi[c] = h[0]; hi[c + 1] = h[1];
+                mid[c] = m[0]; mid[c + 1] = m[1];
             }
-            *reinterpret_cast<sp_bf16x8 *>(adst + (tid * 4 + k) * 16) = hi;
-            *reinterpret_cast<sp_bf16x8 *>(adst + C::NPIX * 16 + (tid * 4 + k) * 16) = mid;
+            *reinterpret_cast<sp_h8 *>(adst + (tid * 4 + k) * 16) = hi;
+            *reinterpret_cast<sp_h8 *>(adst + C::NPIX * 16 + (tid * 4 + k) * 16) = mid;
         }
     };
 
@@ -178,18 +181,18 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
         // Within a unit the order is product-major: consecutive MFMAs hit different accumulators (a 16x16x32 MFMA has 8
         // passes; back-to-back updates of ONE accumulator would serialise on its result); smallest terms first.
         constexpr int HALVES = C::MP / 4, UNITS = 3 * HALVES;
-        sp_bf16x8 fa_h[2][4], fa_m[2][4], fb_h[2][NT], fb_m[2][NT];
+        sp_h8 fa_h[2][4], fa_m[2][4], fb_h[2][NT], fb_m[2][NT];
         auto fetch = [&](int u, int set) {
             const int s = u / HALVES, m0 = (u % HALVES) * 4;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                fb_h[set][n] = *reinterpret_cast<const sp_bf16x8 *>(wb + (((n * 3 + s) * 2 + 0) * 64 + lane) * 16);
-                fb_m[set][n] = *reinterpret_cast<const sp_bf16x8 *>(wb + (((n * 3 + s) * 2 + 1) * 64 + lane) * 16);
+                fb_h[set][n] = *reinterpret_cast<const sp_h8 *>(wb + (((n * 3 + s) * 2 + 0) * 64 + lane) * 16);
+                fb_m[set][n] = *reinterpret_cast<const sp_h8 *>(wb + (((n * 3 + s) * 2 + 1) * 64 + lane) * 16);
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                fa_h[set][m] = *reinterpret_cast<const sp_bf16x8 *>(ab + aoff[s][m0 + m]);
-                fa_m[set][m] = *reinterpret_cast<const sp_bf16x8 *>(ab + C::NPIX * 16 + aoff[s][m0 + m]);
+                fa_h[set][m] = *reinterpret_cast<const sp_h8 *>(ab + aoff[s][m0 + m]);
+                fa_m[set][m] = *reinterpret_cast<const sp_h8 *>(ab + C::NPIX * 16 + aoff[s][m0 + m]);
             }
         };
         fetch(0, 0);
@@ -201,17 +204,17 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_m[set][m], fb_h[set][n], acc[m0 + m][n], 0, 0, 0);
+                    acc[m0 + m][n] = PF_MFMA_SPLIT(fa_m[set][m], fb_h[set][n], acc[m0 + m][n]);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[set][m], fb_m[set][n], acc[m0 + m][n], 0, 0, 0);
+                    acc[m0 + m][n] = PF_MFMA_SPLIT(fa_h[set][m], fb_m[set][n], acc[m0 + m][n]);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h[set][m], fb_h[set][n], acc[m0 + m][n], 0, 0, 0);
+                    acc[m0 + m][n] = PF_MFMA_SPLIT(fa_h[set][m], fb_h[set][n], acc[m0 + m][n]);
         }
         SPLIT_PROBE(round * 6 + 2);   // all MFMAs of the round issued
         if (round + 1 < nrounds) {
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
             sp_f32x4 v = acc[m][n];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] += biasv[n];
+                v[r] = v[r] * a.acc_scale + biasv[n];   // acc_scale = 2^-k of the weight scaling: exact
                 if (a.relu) v[r] = fmaxf(v[r], 0.f);
             }
             epi_store(a, b, co, oy, ox, v);
@@ -296,8 +299,8 @@ int launch_conv_split(const ConvArgs &a, int nt, int wide, int B, hipStream_t s)
 template <int NT>
 struct Split1Cfg {
     static constexpr int KC = 32, TW = 32, TH = 8, MTR = 2, MP = 4, NPIX = TH * TW;
-    static constexpr int ABUF = 2 * 4 * NPIX * 16;                  // bytes: [term][k-group][pixel][8 bf16]
-    static constexpr int WBUF = NT * 2 * 64 * 16;                   // bytes: [nt][term][lane][8 bf16]
+    static constexpr int ABUF = 2 * 4 * NPIX * 16;                  // bytes: [term][k-group][pixel][8 fp16]
+    static constexpr int WBUF = NT * 2 * 64 * 16;                   // bytes: [nt][term][lane][8 fp16]
     static constexpr int MAIN = ABUF + 2 * WBUF;                    // one activation buffer, two weight buffers (see SplitCfg)
     static constexpr int WPIECES = WBUF / 16;
 };
@@ -384,15 +387,16 @@ __global__ __launch_bounds__(256) void conv_split1_kernel(ConvArgs a) {
     auto split_store = [&](unsigned char *adst) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            sp_bf16x8 hi, mid;
+            sp_h8 hi, mid;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const __bf16 h = (__bf16)xr[c][k];
-                hi[c] = h;
-                mid[c] = (__bf16)(xr[c][k] - (float)h);
+            for (int c = 0; c < 8; c += 2) {
+                split_x2 h, m;
+                split_terms2(xr[c][k], xr[c + 1][k], h, m);
+                hi[c] = h[0]; hi[c + 1] = h[1];
+                mid[c] = m[0]; mid[c + 1] = m[1];
             }
-            *reinterpret_cast<sp_bf16x8 *>(adst + (q * C::NPIX + g * 4 + k) * 16) = hi;
-            *reinterpret_cast<sp_bf16x8 *>(adst + (4 * C::NPIX + q * C::NPIX + g * 4 + k) * 16) = mid;
+            *reinterpret_cast<sp_h8 *>(adst + (q * C::NPIX + g * 4 + k) * 16) = hi;
+            *reinterpret_cast<sp_h8 *>(adst + (4 * C::NPIX + q * C::NPIX + g * 4 + k) * 16) = mid;
         }
     };
 
@@ -407,29 +411,29 @@ __global__ __launch_bounds__(256) void conv_split1_kernel(ConvArgs a) {
     for (int round = 0; round < nrounds; ++round) {
         const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
         if (round + 1 < nrounds) load_round(cb + round + 1, wbuf((round + 1) & 1));
-        sp_bf16x8 bh[NT], bm[NT], ah[C::MP], am[C::MP];
+        sp_h8 bh[NT], bm[NT], ah[C::MP], am[C::MP];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            bh[n] = *reinterpret_cast<const sp_bf16x8 *>(wb + ((n * 2 + 0) * 64 + lane) * 16);
-            bm[n] = *reinterpret_cast<const sp_bf16x8 *>(wb + ((n * 2 + 1) * 64 + lane) * 16);
+            bh[n] = *reinterpret_cast<const sp_h8 *>(wb + ((n * 2 + 0) * 64 + lane) * 16);
+            bm[n] = *reinterpret_cast<const sp_h8 *>(wb + ((n * 2 + 1) * 64 + lane) * 16);
         }
 #pragma unroll
         for (int m = 0; m < C::MP; ++m) {
-            ah[m] = *reinterpret_cast<const sp_bf16x8 *>(ab + aoff[m]);
-            am[m] = *reinterpret_cast<const sp_bf16x8 *>(ab + 4 * C::NPIX * 16 + aoff[m]);
+            ah[m] = *reinterpret_cast<const sp_h8 *>(ab + aoff[m]);
+            am[m] = *reinterpret_cast<const sp_h8 *>(ab + 4 * C::NPIX * 16 + aoff[m]);
         }
 #pragma unroll
         for (int m = 0; m < C::MP; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m], bh[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[m][n] = PF_MFMA_SPLIT(am[m], bh[n], acc[m][n]);
 #pragma unroll
         for (int m = 0; m < C::MP; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bm[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[m][n] = PF_MFMA_SPLIT(ah[m], bm[n], acc[m][n]);
 #pragma unroll
         for (int m = 0; m < C::MP; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[m][n] = PF_MFMA_SPLIT(ah[m], bh[n], acc[m][n]);
         if (round + 1 < nrounds) {
             __syncthreads();   // everyone is done reading the activation buffer
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(256) void conv_split1_kernel(ConvArgs a) {
                 sp_f32x4 v = acc[m][n];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] += biasv[n];
+                    v[r] = v[r] * a.acc_scale + biasv[n];   // acc_scale = 2^-k of the weight scaling: exact
                     if (a.relu) v[r] = fmaxf(v[r], 0.f);
                 }
                 epi_store(a, b, co, oy, ox, v);
@@ -490,9 +494,9 @@ __global__ __launch_bounds__(256) void conv_split1_kernel(ConvArgs a) {
                 const int co = (tile0 + n) * 16 + (lane_e & 15);
                 if (epi_skip(a, co)) continue;
                 const lds_float *chan = res_lds + (n * 16 + (lane_e & 15)) * rw.cs;
-                const sp_f32x4 top = epi_finish(a, b, co, oy, ox, acc[m][n], biasv[n], has_res, chan, &t0);
+                const sp_f32x4 top = epi_finish(a, b, co, oy, ox, acc[m][n] * a.acc_scale, biasv[n], has_res, chan, &t0);
                 if (!a.pool) epi_store(a, b, co, oy, ox, top);
-                else epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, acc[(m + C::MTR) % C::MP][n], biasv[n], has_res, chan, &t1));
+                else epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, acc[(m + C::MTR) % C::MP][n] * a.acc_scale, biasv[n], has_res, chan, &t1));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -551,10 +555,7 @@ int split1_chunks(const int *src_ch, int n_src) {
     return n;
 }
 
-static unsigned short bf16_rne(float x);
-static float bf16_to_f32(unsigned short h);
-
-// bytes as floats: [tile][chunk of 32 ch][term 2][lane 64][8 bf16]; lane = (cout n = lane & 15, k-group lane >> 4)
+// bytes as floats: [tile][chunk of 32 ch][term 2][lane 64][8 fp16]; lane = (cout n = lane & 15, k-group lane >> 4)
 size_t split1_packed_floats(const int *src_ch, int n_src, int cout) {
     return (size_t)((cout + 15) / 16) * split1_chunks(src_ch, n_src) * 2 * 64 * 4;
 }
@@ -572,26 +573,53 @@ void pack_conv_weights_split1(const float *w, int cin, int cout, const int *src_
                         for (int e = 0; e < 8; ++e) {
                             const int co = t * 16 + (lane & 15), cl = lc * 32 + (lane >> 4) * 8 + e;
                             const float v = (co < cout && cl < src_ch[j]) ? w[(size_t)co * cin + c0 + cl] : 0.f;
-                            const unsigned short hi = bf16_rne(v);
-                            out[o++] = term == 0 ? hi : bf16_rne(v - bf16_to_f32(hi));
+                            const unsigned short hi = split_host_f16(v);
+                            out[o++] = term == 0 ? hi : split_host_f16(v - split_host_f32(hi));
                         }
             c0 += src_ch[j];
         }
     }
 }
 
-static unsigned short bf16_rne(float x) {
+// ---- host halves of the operand split (conv_mfma.h)
+unsigned short split_host_f16(float x) {
     unsigned u;
     memcpy(&u, &x, 4);
-    if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);   // inf / nan: truncate
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+    const unsigned short sign = (unsigned short)((u >> 16) & 0x8000u);
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (unsigned short)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));   // nan / inf
+    if (u >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);                                  // >= 65520 rounds to inf
+    if (u < 0x38800000u) {   // below 2^-14: a multiple of the subnormal step 2^-24 (1024 steps = the smallest normal: same bits)
+        float f;
+        memcpy(&f, &u, 4);
+        return (unsigned short)(sign | (unsigned)nearbyintf(f * 16777216.0f));   // default rounding mode: nearest even
+    }
+    u -= 0x38000000u;                        // exponent bias 127 -> 15
+    u += 0xfffu + ((u >> 13) & 1u);          // nearest even on the 13 dropped bits (a carry moves into the exponent)
+    return (unsigned short)(sign | (u >> 13));
 }
-static float bf16_to_f32(unsigned short h) {
-    const unsigned u = (unsigned)h << 16;
+float split_host_f32(unsigned short h) {
+    const unsigned sign = (unsigned)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
     float f;
+    if (e == 0) {
+        f = (float)m * (1.0f / 16777216.0f);
+        unsigned u;
+        memcpy(&u, &f, 4);
+        u |= sign;
+        memcpy(&f, &u, 4);
+        return f;
+    }
+    const unsigned u = sign | (e == 31 ? 0x7f800000u | (m << 13) : ((e + 112u) << 23) | (m << 13));
     memcpy(&f, &u, 4);
     return f;
+}
+float split_weight_scale(const float *w, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(w[i]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
+    int e;
+    frexpf(mx, &e);                          // mx = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.0f, 15 - e);             // mx * 2^(15 - e) in [2^14, 2^15)
 }
 
 int split_chunks(const int *src_ch, int n_src) {
@@ -600,7 +628,7 @@ int split_chunks(const int *src_ch, int n_src) {
     return n;
 }
 
-// bytes as floats (the weight arena is a float array): [tile][chunk][step 3][term 2][lane 64][8 bf16] = 16 B per lane
+// bytes as floats (the weight arena is a float array): [tile][chunk][step 3][term 2][lane 64][8 fp16] = 16 B per lane
 size_t split_packed_floats(const int *src_ch, int n_src, int cout) {
     return (size_t)((cout + 15) / 16) * split_chunks(src_ch, n_src) * 3 * 2 * 64 * 4;
 }
@@ -620,8 +648,8 @@ void pack_conv_weights_split(const float *w, int cin, int cout, const int *src_c
                                 const int co = t * 16 + (lane & 15), tap = 4 * s + (lane >> 4), cl = lc * 8 + e;
                                 float v = 0.f;
                                 if (co < cout && tap < 9 && cl < src_ch[j]) v = w[((size_t)co * cin + c0 + cl) * 9 + tap];
-                                const unsigned short hi = bf16_rne(v);
-                                out[o++] = term == 0 ? hi : bf16_rne(v - bf16_to_f32(hi));
+                                const unsigned short hi = split_host_f16(v);
+                                out[o++] = term == 0 ? hi : split_host_f16(v - split_host_f32(hi));
                             }
             c0 += src_ch[j];
         }

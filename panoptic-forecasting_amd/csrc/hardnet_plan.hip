@@ -31,12 +31,13 @@ struct ConvPlan {
     int wave_chunks = 0;
     size_t valu_off = 0;  // [chunk][ch][tap][cout] rows for the vector-ALU path (3x3/s1 with a supported cout), else 0
     bool has_valu = false;
-    size_t split_off = 0; // bf16 hi/mid fragments for the bf16-split path (3x3/s1), else 0
+    size_t split_off = 0; // fp16 hi/mid fragments for the split path (3x3/s1 and 1x1), else 0
     int split_chunks = 0;
     bool has_split = false;
     size_t s4_off = 0;    // conv_s4.hip packing (stride-1 3x3 and 1x1), else 0
     int s4_rounds = 0;
     bool has_s4 = false, s4_pad = false;   // s4_pad: ranges padded to whole rounds (the conv may run one range at a time)
+    float split_acc_scale = 1.0f;          // 2^-k: the split / S4 packings hold fp16 terms of w * 2^k (conv_mfma.h)
 };
 
 struct pf_plan {
@@ -50,7 +51,7 @@ struct pf_plan {
     size_t dev_floats = 0;
     // execution options of THIS plan (pf_hardnet_plan_set_option); initialised from the process-wide defaults
     // (pf_set_option) when the plan is created and read only by forwards of this plan
-    int opt_fuse_pool = 1, opt_fuse_upsample = 1, opt_valu_rem = 1, opt_split_bf16 = 1, opt_use_tuned = 1;
+    int opt_fuse_pool = 1, opt_fuse_upsample = 1, opt_valu_rem = 1, opt_split = 1, opt_use_tuned = 1;
     int opt_table_batch = 0;   // > 0: per-layer kernel choice as if the batch were this (batch-invariant numerics)
     int opt_packed_acts = 1;   // tensors whose producers and consumers all support it live in the S4 layout (conv_s4.hip)
     // formats of the last forward (pf_hardnet_tensor_read): 1 = S4
@@ -58,7 +59,7 @@ struct pf_plan {
 };
 
 namespace pf {
-int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_split_bf16 = 1, g_opt_packed_acts = 1;
+int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_split = 1, g_opt_packed_acts = 1;
 extern int g_opt_use_tuned;
 }
 
@@ -68,7 +69,7 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "fuse_upsample")) g_opt_fuse_upsample = value;
     else if (!strcmp(name, "use_tuned_table")) g_opt_use_tuned = value;
     else if (!strcmp(name, "valu_remainder")) g_opt_valu_rem = value;
-    else if (!strcmp(name, "split_bf16")) g_opt_split_bf16 = value;
+    else if (!strcmp(name, "split_f16") || !strcmp(name, "split_bf16")) g_opt_split = value;   // (round-1 name kept)
     else if (!strcmp(name, "packed_acts")) g_opt_packed_acts = value;
     else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);
     return PF_OK;
@@ -80,7 +81,7 @@ extern "C" int pf_hardnet_plan_set_option(pf_plan *p, const char *name, int valu
     else if (!strcmp(name, "fuse_upsample")) p->opt_fuse_upsample = value;
     else if (!strcmp(name, "use_tuned_table")) p->opt_use_tuned = value;
     else if (!strcmp(name, "valu_remainder")) p->opt_valu_rem = value;
-    else if (!strcmp(name, "split_bf16")) p->opt_split_bf16 = value;
+    else if (!strcmp(name, "split_f16") || !strcmp(name, "split_bf16")) p->opt_split = value;
     else if (!strcmp(name, "packed_acts")) p->opt_packed_acts = value;
     else if (!strcmp(name, "table_batch")) p->opt_table_batch = value < 0 ? 0 : value;
     else return fail(PF_EINVAL, "pf_hardnet_plan_set_option: unknown option '%s'", name);
@@ -182,7 +183,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
     std::vector<uint8_t> fmt(nT, 0), cand(nT, 1);
     std::vector<std::vector<uint8_t>> written(nT);
     for (size_t t = 0; t < nT; ++t) written[t].assign(p->tensors[t].channels + 8, 0);
-    const bool s4_allowed = p->opt_packed_acts && p->opt_split_bf16 && (g_conv_force.kind == 0 || g_conv_force.kind == 5);
+    const bool s4_allowed = p->opt_packed_acts && p->opt_split && (g_conv_force.kind == 0 || g_conv_force.kind == 5);
     bool dry = true;
     size_t rec_i = 0;
     struct ConvMeta {
@@ -214,6 +215,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         a.ntiles = ((int)o.cout + 15) / 16;
         a.src_begin = 0;
         a.src_end = a.n_src;
+        a.acc_scale = 1.0f;
         static const bool probe_on = getenv("PF_PROBE") != nullptr;
         a.probe = probe_on ? probe_buffer() : nullptr;
     };
@@ -231,7 +233,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             if (g_conv_force.kind == 1) ch = g_conv_force;
             if (g_conv_force.kind == 3 && p->conv[i].has_valu && !need) ch = g_conv_force;
             if (g_conv_force.kind == 4 && p->conv[i].has_split && (!need || o.k == 1)) ch = g_conv_force;
-            if (ch.kind == 4 && (!p->conv[i].has_split || (need && o.k != 1) || !p->opt_split_bf16)) ch = ConvChoice{1, 0, 0, 0};
+            if (ch.kind == 4 && (!p->conv[i].has_split || (need && o.k != 1) || !p->opt_split)) ch = ConvChoice{1, 0, 0, 0};
             if (ch.kind == 3 && (!p->conv[i].has_valu || need)) ch = ConvChoice{1, 0, 0, 0};
             // pf_debug_force_conv(5, ..): launches that cannot read S4 (fp32 sources) still have to be able to WRITE it
             if (g_conv_force.kind == 5) ch = ConvChoice{1, 0, 0, 0};
@@ -243,7 +245,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             r.dst_t = mt.dst_t;
             r.sb = a.src_begin;
             r.se = a.src_end;
-            // reads S4: the layers the table gives to the bf16-split kernels (same tile parameters), big 1x1 convs, or all
+            // reads S4: the layers the table gives to the split kernels (same tile parameters), big 1x1 convs, or all
             // eligible convs under pf_debug_force_conv(5, nt, wide)
             const bool forced = g_conv_force.kind == 5;
             const long px = (long)B * a.Hout * a.Wout;
@@ -293,6 +295,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             }
             for (int j = a.n_src; j <= kConvMaxSrc; ++j) a.src_ent0[j] = e;
             a.src_fmt = 1;
+            a.acc_scale = p->conv[i].split_acc_scale;
             a.wpk = p->dev_weights + p->conv[i].s4_off;
             a.nchunks = p->conv[i].s4_rounds;
             a.chunk_begin = a.src_ent0[a.src_begin] / per;
@@ -315,6 +318,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         };
         if (ch.kind == 4) {
             a.wpk = p->dev_weights + p->conv[i].split_off;
+            a.acc_scale = p->conv[i].split_acc_scale;
             a.nchunks = p->conv[i].split_chunks;
             set_chunks(o.k == 1 ? 32 : 8);
             rc = o.k == 1 ? launch_conv_split1(a, ch.p0, B, s) : launch_conv_split(a, ch.p0, ch.p1, B, s);
@@ -538,7 +542,7 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
         return fail(PF_EINVAL, "blob is for in_ch=%u n_cls=%u, caller asked for %d/%d", h.in_ch, h.n_cls, in_ch, n_cls);
     pf_plan *p = new pf_plan();
     p->opt_fuse_pool = g_opt_fuse_pool; p->opt_fuse_upsample = g_opt_fuse_upsample; p->opt_valu_rem = g_opt_valu_rem;
-    p->opt_split_bf16 = g_opt_split_bf16; p->opt_use_tuned = g_opt_use_tuned; p->opt_packed_acts = g_opt_packed_acts;
+    p->opt_split = g_opt_split; p->opt_use_tuned = g_opt_use_tuned; p->opt_packed_acts = g_opt_packed_acts;
     p->hdr = h;
     p->tensors.resize(h.n_tensors);
     p->ops.resize(h.n_ops);
@@ -604,13 +608,24 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
             host.resize(host.size() + (size_t)c.tiled_chunks * (kc / 4) * 9 * rv * 4);
             pack_conv_weights_rem(wts + o.w_off, (int)o.cin, (int)o.cout, split, 3, kc, src_ch, (int)o.n_src, host.data() + c.rem_off);
         }
+        // the split packings hold fp16 terms of w * 2^k (exact scaling, k per conv: conv_mfma.h)
+        std::vector<float> wsc;
+        const float *wsplit = wts + o.w_off;
+        if (o.stride == 1 && (o.k == 3 || o.k == 1)) {
+            const size_t nw = (size_t)o.cout * o.cin * o.k * o.k;
+            const float sc = split_weight_scale(wts + o.w_off, nw);
+            wsc.resize(nw);
+            for (size_t q = 0; q < nw; ++q) wsc[q] = wts[o.w_off + q] * sc;
+            wsplit = wsc.data();
+            c.split_acc_scale = 1.0f / sc;
+        }
         if (o.k == 3 && o.stride == 1) {
             host.resize(align_up(host.size(), 16), 0.f);
             c.split_off = host.size();
             c.split_chunks = split_chunks(src_ch, (int)o.n_src);
             c.has_split = true;
             host.resize(host.size() + split_packed_floats(src_ch, (int)o.n_src, (int)o.cout));
-            pack_conv_weights_split(wts + o.w_off, (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, host.data() + c.split_off);
+            pack_conv_weights_split(wsplit, (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, host.data() + c.split_off);
         }
         if (o.k == 1 && o.stride == 1) {
             host.resize(align_up(host.size(), 16), 0.f);
@@ -618,7 +633,7 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
             c.split_chunks = split1_chunks(src_ch, (int)o.n_src);
             c.has_split = true;
             host.resize(host.size() + split1_packed_floats(src_ch, (int)o.n_src, (int)o.cout));
-            pack_conv_weights_split1(wts + o.w_off, (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, host.data() + c.split_off);
+            pack_conv_weights_split1(wsplit, (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, host.data() + c.split_off);
         }
         if (o.stride == 1 && o.kind == OP_CONV) {
             S4Range rg[kMaxSrc];
@@ -634,7 +649,7 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
                 c.s4_rounds = s4_rounds(rg, (int)o.n_src, (int)o.k, c.s4_pad);
                 c.has_s4 = true;
                 host.resize(host.size() + s4_packed_floats(rg, (int)o.n_src, (int)o.cout, (int)o.k, c.s4_pad));
-                pack_conv_weights_s4(wts + o.w_off, (int)o.cin, (int)o.cout, (int)o.k, rg, (int)o.n_src, c.s4_pad, host.data() + c.s4_off);
+                pack_conv_weights_s4(wsplit, (int)o.cin, (int)o.cout, (int)o.k, rg, (int)o.n_src, c.s4_pad, host.data() + c.s4_off);
             }
         }
         if (o.k == 3 && o.stride == 1 && conv_valu_supports((int)o.cout)) {

@@ -71,9 +71,10 @@ def test_fused_matches_two_stage_oracle(h, w, b, gap, predicted):
 
 
 def test_fp32_mfma_only_option():
-    """pf_set_option("split_bf16", 0): every convolution on the fp32 matrix/vector pipes - the logits then agree with the
-    torch-CPU oracle an order of magnitude closer than the stated 1e-3 (pure fp32 FMA chains, only the summation order
-    differs); with the default (bf16-split 3x3/1x1 layers where tuned or large) they stay inside 1e-3."""
+    """pf_set_option("split_f16", 0) ("split_bf16", its round-1 name, is still accepted - used below): every convolution on the fp32 matrix/vector
+    pipes - the logits agree with the torch-CPU oracle an order of magnitude closer than the stated 1e-3 (pure fp32 FMA
+    chains, only the summation order differs).  The default (3x3/1x1 layers on the 16-bit matrix pipe with every operand
+    split into two fp16 terms, 22 significand bits) is held to the SAME 1e-4."""
     from panoptic_forecasting_amd import lib as pflib
     from panoptic_forecasting_amd import synth
     from panoptic_forecasting_amd.registry import build_model
@@ -98,13 +99,13 @@ def test_fp32_mfma_only_option():
     finally:
         L.pf_set_option(b'split_bf16', 1)
     assert errs[0] <= 1e-4, errs
-    assert errs[1] <= 1e-3, errs
+    assert errs[1] <= 1e-4, errs
 
 
-@pytest.mark.parametrize('b,split,tol', [(1, 1, 1e-3), (1, 0, 1e-4), (16, 1, 1e-3), (16, 0, 1e-4), (3, 1, 1e-3)],
+@pytest.mark.parametrize('b,split,tol', [(1, 1, 1e-4), (1, 0, 1e-4), (16, 1, 1e-4), (16, 0, 1e-4), (3, 1, 1e-4)],
                          ids=['B1_split', 'B1_fp32', 'B16_split', 'B16_fp32', 'B3_nearest_row'])
 def test_full_size_timed_configuration_vs_oracle(b, split, tol):
-    """The configuration bench.py times (1024x2048, the B=1 and B=16 rows of csrc/conv_tuned.inc, bf16-split kernels on
+    """The configuration bench.py times (1024x2048, the B=1 and B=16 rows of csrc/conv_tuned.inc, split kernels on
     and off) against the oracle pipeline at its own size: logits of the first and the last frame of the batch, argmax
     agreement and bit-exact warped inputs.  The per-layer kernel choice is keyed on (shape, B), so the small-size tests
     above never execute these table rows.  B=3 is not a measured batch size: it takes the rows of the nearest one (4)."""
@@ -113,7 +114,7 @@ def test_full_size_timed_configuration_vs_oracle(b, split, tol):
     from panoptic_forecasting_amd.registry import build_model
     h, w = 1024, 2048
     sd = _sd()
-    m = build_model(_params(h, w, return_logits='orig', split_bf16=split, emulate_disk_hop=True, seg_is_label_id=True,
+    m = build_model(_params(h, w, return_logits='orig', split_f16=split, emulate_disk_hop=True, seg_is_label_id=True,
                             per_sample_sentinel=True))
     m.load_state_dict(sd)
     parts = [synth.make_inputs(b=1, h=h, w=w, seed=40 + i, gap_len=3) for i in range(b)]
