@@ -187,7 +187,8 @@ class Workload:
     one captured hipGraph.  The low-resolution layers of one sub-batch (small grids, latency-bound) and its memory-bound
     splat/stem kernels overlap the matrix-bound high-resolution layers of another."""
 
-    def __init__(self, sd, B, S, dev, seed0, term, use_graph=True, **model_kw):
+    def __init__(self, sd, B, S, dev, seed0, term, use_graph=True, stagger=False, **model_kw):
+        self.stagger = stagger
         if B % S:
             raise SystemExit('--batch must be a multiple of --streams')
         self.B, self.S, self.use_graph = B, S, use_graph
@@ -220,6 +221,25 @@ class Workload:
     def step(self):
         cur = torch.cuda.current_stream()
         outs = [None] * self.S
+        if self.stagger and self.S > 1:
+            # software pipeline inside the step: sub-batch i + 1 starts when the warp/splat of sub-batch i has finished, so
+            # that its vector-ALU-bound warp/splat + stem run beside the matrix-bound convolutions of sub-batch i instead
+            # of beside another warp/splat (two identical chains started together stay in lockstep: tools/graph_timeline.py)
+            streams = [cur] + self.side
+            prev = None
+            for i in range(self.S):
+                st = streams[i]
+                if i > 0:
+                    st.wait_event(prev)
+                ev = torch.cuda.Event()
+                self.models[i].after_splat = (lambda e=ev, q=st: e.record(q))
+                with torch.cuda.stream(st):
+                    outs[i] = self.models[i].predict(self.subs[i], None)
+                self.models[i].after_splat = None
+                prev = ev
+            for i in range(1, self.S):
+                cur.wait_stream(self.side[i - 1])
+            return outs
         for i in range(1, self.S):
             self.side[i - 1].wait_stream(cur)
             with torch.cuda.stream(self.side[i - 1]):
@@ -346,6 +366,8 @@ def parse_args(argv=None):
                     "(model param split_f16=0): every convolution on v_mfma_f32_16x16x4_f32 / the fp32 VALU")
     ap.add_argument('--streams', type=int, default=0, help='sub-batches run concurrently on this many HIP streams '
                     '(0 = one per 16 frames of the batch)')
+    ap.add_argument('--stagger', type=int, default=0, help='1: sub-batch i + 1 of a step starts when the warp/splat of '
+                    'sub-batch i is done (software pipeline inside the step) instead of all sub-batches starting together')
     ap.add_argument('--term', choices=['short', 'mid'], default='short',
                     help="short = BASELINE configs[1] (dt=3, the headline); mid = configs[2] (dt=9, predicted odometry)")
     ap.add_argument('--dry-run', action='store_true', help='rendezvous + the sharded metric exchange only (gloo, no GPU '
@@ -407,7 +429,7 @@ def main():
     S = max(1, min(args.streams, B)) if args.streams > 0 else max(1, B // SUB_BATCH)
     use_graph = not args.no_graph
     head_kw = {'split_f16': 0} if args.fp32_mfma_only else {}
-    wl = Workload(sd, B, S, dev, seed0=rank * B, term=args.term, use_graph=use_graph, **head_kw)
+    wl = Workload(sd, B, S, dev, seed0=rank * B, term=args.term, use_graph=use_graph, stagger=bool(args.stagger), **head_kw)
     elapsed = wl.timed(args.steps, args.warmup, dev, barrier=True)
     frames = world * B * args.steps
     value = frames / elapsed

@@ -32,6 +32,9 @@ class BGForecastModel(BaseModel):
         self.return_logits = mp.get('return_logits', False)   # True: full-size + network-size logits; 'orig': network-size only
         self.per_sample_sentinel = bool(mp.get('per_sample_sentinel', False))   # see pc_transform_model.PCTransformModel
         self._splat = WarpSplat()
+        # optional callable run between the warp/splat launches and the network launches of a predict() - a caller that
+        # pipelines several sub-batches on several streams records its cross-stream event here (bench.py --stagger)
+        self.after_splat = None
 
     # checkpoint compatibility: a reference bg_model.pt loads straight into the fused model
     def load_state_dict(self, state_dict, strict=True):
@@ -46,6 +49,8 @@ class BGForecastModel(BaseModel):
                                         Kinv=inputs.get('intrinsics_inv'), Einv=inputs.get('extrinsics_inv'),
                                         per_frame=True, want_result2d=False,
                                         per_sample_sentinel=self.per_sample_sentinel)
+        if self.after_splat is not None:
+            self.after_splat()
         hop = 0
         if self.emulate_disk_hop:
             hop |= PF_HOP_DEPTH_U16

@@ -417,22 +417,33 @@ __global__ __launch_bounds__(256) void head4_kernel(HeadArgs a) {
     }
 }
 
-// Tiled head: head4_kernel issues 6 scalar loads per channel per lane - 66 load instructions for 4 output pixels - and
-// is bound by the texture addresser (16 cycles per wave-load), not by bytes (188 us for 16 frames at 0.7 TB/s).  Here a
-// workgroup owns a 16 x 256 output tile, copies the source window of all channels into LDS once (coalesced rows) and the
-// lanes interpolate from there: the same arithmetic in the same order, 15x fewer global load instructions.
-constexpr int kHeadTH = 16, kHeadTW = 256;
+// Column head.  head4_kernel issues 6 scalar loads per channel per lane - 66 load instructions for 4 output pixels - and is
+// bound by the texture addresser (188 us for 16 frames at 0.7 TB/s); a first tiled version (round 1: source window of a
+// 16 x 256 output tile staged in LDS, a lane = 4 consecutive pixels of a row) removed the loads but left ~165 vector
+// instructions per output pixel - per pixel and channel six selects of the 3 source columns its 4 pixels straddle, two
+// horizontal and one vertical interpolation, the argmax update: 165 us, vector-ALU-bound (profiles/README.md).
+// Here a lane owns ONE output column of a 32 x 256 tile and walks down its 32 rows:
+//   * its two source columns and their weights are fixed: no selects;
+//   * the horizontal interpolation of a source row (per channel: 2 LDS reads, mul, fma) is done once and serves the ~4
+//     output rows between two source rows - the rows a lane needs are wave-uniform, so "next source row" is a scalar branch;
+//   * per pixel and channel there remain the vertical interpolation (mul, fma) and the argmax update (compare, 2 selects);
+//   * the per-row coordinates (lin_coord) are computed once per workgroup by 32 lanes and read back as LDS broadcasts.
+// Same operations on the same values as head_kernel: u = lx0*a + lx1*b per source row, v = hy0*u0 + hy1*u1.
+constexpr int kHeadTH = 16, kHeadTW = 256;   // tile of seg_loss_tile_kernel below
+constexpr int kHeadCH = 32, kHeadCW = 256;   // tile of head_col_kernel
 template <int CC>
-__global__ __launch_bounds__(256) void head_tile_kernel(HeadArgs a, int win_rows_max, int win_cols_max) {
-    extern __shared__ float hl[];
+__global__ __launch_bounds__(256) void head_col_kernel(HeadArgs a) {
+    extern __shared__ float hl[];            // [CC][rows][cols] source window
+    __shared__ int row_r0[kHeadCH], row_r1[kHeadCH];
+    __shared__ float row_h1[kHeadCH];
     const float sh = a.Hout > 1 ? (float)(a.Hin - 1) / (float)(a.Hout - 1) : 0.f;
     const float sw = a.Wout > 1 ? (float)(a.Win - 1) / (float)(a.Wout - 1) : 0.f;
     const size_t opl = (size_t)a.Hout * a.Wout, ipl = (size_t)a.Hin * a.Win;
-    const int ty0 = blockIdx.y * kHeadTH, tx0 = blockIdx.x * kHeadTW, b = blockIdx.z;
-    const int ylast = min(ty0 + kHeadTH, a.Hout) - 1, xlast = min(tx0 + kHeadTW, a.Wout) - 4;
+    const int ty0 = blockIdx.y * kHeadCH, tx0 = blockIdx.x * kHeadCW, b = blockIdx.z;
+    const int ylast = min(ty0 + kHeadCH, a.Hout) - 1, xlast = min(tx0 + kHeadCW, a.Wout) - 1;
     const int sy0 = min((int)(sh * (float)ty0), a.Hin - 1), sx0 = min((int)(sw * (float)tx0), a.Win - 1);
     const int rows = min(min((int)(sh * (float)ylast), a.Hin - 1) + 1, a.Hin - 1) - sy0 + 1;
-    const int cols = min(min((int)(sw * (float)xlast), a.Win - 1) + 2, a.Win - 1) - sx0 + 1;
+    const int cols = min(min((int)(sw * (float)xlast), a.Win - 1) + 1, a.Win - 1) - sx0 + 1;
     const int per = rows * cols;
     const float *src = a.logits + (size_t)b * CC * ipl;
     for (int e = threadIdx.x; e < per; e += 256) {
@@ -441,56 +452,61 @@ __global__ __launch_bounds__(256) void head_tile_kernel(HeadArgs a, int win_rows
 #pragma unroll
         for (int c = 0; c < CC; ++c) hl[c * per + e] = src[(size_t)c * ipl + off];
     }
-    __syncthreads();
-    const int x = tx0 + (threadIdx.x & 63) * 4;
-    if (x >= a.Wout) return;
-    int i0[4], i1[4];
-    float l0[4], l1[4];
-    int xa = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int x0, x1;
-        lin_coord(x + k, sw, a.Win, x0, x1, l0[k], l1[k]);
-        if (k == 0) xa = x0;
-        i0[k] = x0 - xa;
-        i1[k] = x1 - xa;
-    }
-    const int ca = xa - sx0, cb = min(xa + 1, a.Win - 1) - sx0, cc = min(xa + 2, a.Win - 1) - sx0;
-    for (int ry = threadIdx.x >> 6; ry < kHeadTH; ry += 4) {
-        const int y = ty0 + ry;
-        if (y >= a.Hout) break;
+    if (threadIdx.x < kHeadCH) {
         int y0, y1;
         float hy0, hy1;
-        lin_coord(y, sh, a.Hin, y0, y1, hy0, hy1);
-        const float *r0 = hl + (y0 - sy0) * cols, *r1 = hl + (y1 - sy0) * cols;
-        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int arg[4] = {0, 0, 0, 0};
+        lin_coord(min(ty0 + (int)threadIdx.x, a.Hout - 1), sh, a.Hin, y0, y1, hy0, hy1);
+        row_r0[threadIdx.x] = y0 - sy0;
+        row_r1[threadIdx.x] = y1 - sy0;
+        row_h1[threadIdx.x] = hy1;
+    }
+    __syncthreads();
+    const int x = tx0 + threadIdx.x;
+    if (x >= a.Wout) return;
+    int x0, x1;
+    float lx0, lx1;
+    lin_coord(x, sw, a.Win, x0, x1, lx0, lx1);
+    const float *p0 = hl + (x0 - sx0), *p1 = hl + (x1 - sx0);
+    float tA[CC], tB[CC];                    // horizontally interpolated source rows curA (= y0) and curB (= y1)
+    int curA = -1, curB = -1;                // wave-uniform
+    auto hrow = [&](int r, float (&t)[CC]) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) t[c] = lx0 * p0[c * per + r * cols] + lx1 * p1[c * per + r * cols];
+    };
+    for (int ry = 0; ry < kHeadCH; ++ry) {
+        const int y = ty0 + ry;
+        if (y >= a.Hout) break;
+        const int r0 = __builtin_amdgcn_readfirstlane(row_r0[ry]), r1 = __builtin_amdgcn_readfirstlane(row_r1[ry]);
+        const float hy1 = row_h1[ry], hy0 = 1.f - hy1;
+        if (r0 != curA) {
+            if (r0 == curB) {
+#pragma unroll
+                for (int c = 0; c < CC; ++c) tA[c] = tB[c];
+            } else {
+                hrow(r0, tA);
+            }
+            curA = r0;
+        }
+        if (r1 != curB) {
+            if (r1 == curA) {
+#pragma unroll
+                for (int c = 0; c < CC; ++c) tB[c] = tA[c];
+            } else {
+                hrow(r1, tB);
+            }
+            curB = r1;
+        }
+        float best = -INFINITY;
+        int arg = 0;
+        const size_t o = (size_t)b * opl + (size_t)y * a.Wout + x;
 #pragma unroll
         for (int c = 0; c < CC; ++c) {
-            const float t0[3] = {r0[c * per + ca], r0[c * per + cb], r0[c * per + cc]};
-            const float t1[3] = {r1[c * per + ca], r1[c * per + cb], r1[c * per + cc]};
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float a0 = i0[k] ? t0[1] : t0[0], a1 = i1[k] == 2 ? t0[2] : (i1[k] ? t0[1] : t0[0]);
-                const float b0 = i0[k] ? t1[1] : t1[0], b1 = i1[k] == 2 ? t1[2] : (i1[k] ? t1[1] : t1[0]);
-                const float u0 = l0[k] * a0 + l1[k] * a1;
-                const float u1 = l0[k] * b0 + l1[k] * b1;
-                v[k] = hy0 * u0 + hy1 * u1;
-                if (v[k] > best[k]) { best[k] = v[k]; arg[k] = c; }   // first maximum wins, like torch.argmax on CPU
-            }
-            if (a.out_logits)
-                *reinterpret_cast<f32x4v *>(a.out_logits + ((size_t)b * CC + c) * opl + (size_t)y * a.Wout + x) = f32x4v{v[0], v[1], v[2], v[3]};
+            const float v = hy0 * tA[c] + hy1 * tB[c];
+            if (a.out_logits) a.out_logits[((size_t)b * CC + c) * opl + (size_t)y * a.Wout + x] = v;
+            if (v > best) { best = v; arg = c; }   // first maximum wins, like torch.argmax on CPU
         }
-        const size_t o = (size_t)b * opl + (size_t)y * a.Wout + x;
-        if (a.out_is_i64) {
-            long long *d = reinterpret_cast<long long *>(a.out_seg) + o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] = arg[k];
-        } else {
-            *reinterpret_cast<unsigned *>(reinterpret_cast<uint8_t *>(a.out_seg) + o) =
-                (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
-        }
+        if (a.out_is_i64) reinterpret_cast<long long *>(a.out_seg)[o] = arg;
+        else reinterpret_cast<uint8_t *>(a.out_seg)[o] = (uint8_t)arg;
     }
 }
 
@@ -661,11 +677,18 @@ int launch_head(const HeadArgs &a, hipStream_t s) {
                                                           (a.out_logits ? opx * a.C * 4 : 0));
     const float sw = a.Wout > 1 ? (float)(a.Win - 1) / (float)(a.Wout - 1) : 0.f;
     const float shh = a.Hout > 1 ? (float)(a.Hin - 1) / (float)(a.Hout - 1) : 0.f;
-    const int wr = (int)(shh * (kHeadTH - 1)) + 3, wc = (int)(sw * (kHeadTW - 1)) + 4;   // window bounds of one tile
+    const size_t win = ((size_t)(shh * (kHeadCH - 1)) + 3) * ((size_t)(sw * (kHeadCW - 1)) + 3) * 4;   // window bound of one tile, per channel
     static const bool no_tile = getenv("PF_HEAD_UNTILED") != nullptr;   // A/B switch
-    if ((a.Wout & 3) == 0 && 3.f * sw < 1.f && a.Win >= 3 && a.C == 11 && (size_t)wr * wc * 11 * 4 <= 48 * 1024 && !no_tile) {
-        const dim3 grid((a.Wout + kHeadTW - 1) / kHeadTW, (a.Hout + kHeadTH - 1) / kHeadTH, a.B);
-        hipLaunchKernelGGL(head_tile_kernel<11>, grid, dim3(256), (size_t)wr * wc * 11 * 4, s, a, wr, wc);
+    if ((a.C == 11 || a.C == 19) && a.Hin >= 2 && a.Win >= 2 && win * a.C <= 60 * 1024 && !no_tile) {
+        const dim3 grid((a.Wout + kHeadCW - 1) / kHeadCW, (a.Hout + kHeadCH - 1) / kHeadCH, a.B);
+        static bool attr = false;
+        if (!attr) {
+            PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&head_col_kernel<11>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024));
+            PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&head_col_kernel<19>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024));
+            attr = true;
+        }
+        if (a.C == 11) hipLaunchKernelGGL(head_col_kernel<11>, grid, dim3(256), win * 11, s, a);
+        else hipLaunchKernelGGL(head_col_kernel<19>, grid, dim3(256), win * 19, s, a);
     } else if ((a.Wout & 3) == 0 && 3.f * sw < 1.f && a.Win >= 3)   // 4 consecutive outputs span <= 2 source columns
         hipLaunchKernelGGL(head4_kernel, dim3(grid_for((size_t)a.B * a.Hout * (a.Wout >> 2))), dim3(256), 0, s, a);
     else
