@@ -143,10 +143,19 @@ struct Proj {
 // :106-114 `.floor().long()` / `.ceil().long()` then clamp(0, hi).  Clamping in float first keeps the conversion in range;
 // a value the reference's float -> int64 cast cannot represent (NaN, +-inf, |f| >= 2^63: x86 returns INT64_MIN, which the
 // clamp turns into 0) gives 0 here too, so that bins of points with non-finite projections (invalid, but they still mark
-// bins and appear in result2d) agree with the reference run on x86.
+// bins and appear in result2d) agree with the reference run on x86.  (v_med3_f32 with a NaN operand returns the minimum of
+// the other two: 0.)
 __device__ __forceinline__ int to_bin(float f, float hi) {
-    const float c = fminf(fmaxf(f, 0.0f), hi);
+    const float c = __builtin_amdgcn_fmed3f(f, 0.0f, hi);
     return (f < 9223372036854775808.0f) ? (int)c : 0;
+}
+// both bins of one coordinate.  The ceil bin is the floor bin or the next one: clamp(ceil(u)) != clamp(floor(u)) exactly
+// when 0 < u < hi and u is not an integer (u <= 0: both clamp to 0; u >= hi: both clamp to hi, or to 0 beyond the int64
+// range; NaN: both 0) - one floor and three compares instead of floor, ceil and two clamped conversions.
+__device__ __forceinline__ void bins(float u, float hi, int &b0, int &b1) {
+    const float fl = floorf(u);
+    b0 = to_bin(fl, hi);
+    b1 = b0 + (int)((u > 0.0f) & (u < hi) & (u != fl));
 }
 
 // pc_transform_model.py:54-114 for one pixel.  Used by BOTH kernels so they agree bit for bit.
@@ -167,11 +176,9 @@ __device__ __forceinline__ Proj project(const Camera &c, int x, int y, float d, 
     p.z = z;
     const bool inb = (uu >= 0.0f) && (uu < Wf) && (vv >= 0.0f) && (vv < Hf);                          // :83-86
     p.valid = m && (z > 0.0f) && inb;                                                                 // :87-89
-    // :106-114 floor/ceil then clamp (clamping in float first keeps the int conversion in range)
-    p.x0 = to_bin(floorf(uu), Wf - 1.0f);
-    p.x1 = to_bin(ceilf(uu), Wf - 1.0f);
-    p.y0 = to_bin(floorf(vv), Hf - 1.0f);
-    p.y1 = to_bin(ceilf(vv), Hf - 1.0f);
+    // :106-114 floor/ceil then clamp
+    bins(uu, Wf - 1.0f, p.x0, p.x1);
+    bins(vv, Hf - 1.0f, p.y0, p.y1);
     return p;
 }
 
@@ -209,10 +216,8 @@ __device__ __forceinline__ Proj finish(float uu, float vv, float z, bool m, floa
     p.z = z;
     const bool inb = (uu >= 0.0f) && (uu < Wf) && (vv >= 0.0f) && (vv < Hf);
     p.valid = m && (z > 0.0f) && inb;
-    p.x0 = to_bin(floorf(uu), Wf - 1.0f);
-    p.x1 = to_bin(ceilf(uu), Wf - 1.0f);
-    p.y0 = to_bin(floorf(vv), Hf - 1.0f);
-    p.y1 = to_bin(ceilf(vv), Hf - 1.0f);
+    bins(uu, Wf - 1.0f, p.x0, p.x1);
+    bins(vv, Hf - 1.0f, p.y0, p.y1);
     return p;
 }
 
@@ -308,11 +313,14 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
                 bx0 = min(bx0, p.x0); by0 = min(by0, p.y0);
                 bx1 = max(bx1, p.x1); by1 = max(by1, p.y1);
             } else {
-                // every invalid point carries depth max+1 and payload 0: marking its bins is enough
-                mark[(long long)p.y0 * a.W + p.x0] = 1;
-                mark[(long long)p.y1 * a.W + p.x0] = 1;
-                mark[(long long)p.y0 * a.W + p.x1] = 1;
-                mark[(long long)p.y1 * a.W + p.x1] = 1;
+                // every invalid point carries depth max+1 and payload 0: marking its bins is enough (32-bit offsets from
+                // the uniform base: N < 2^30 is checked at launch)
+                const unsigned o00 = (unsigned)p.y0 * (unsigned)a.W + (unsigned)p.x0, dxo = (unsigned)(p.x1 - p.x0);
+                const unsigned o10 = (unsigned)p.y1 * (unsigned)a.W + (unsigned)p.x0;
+                mark[o00] = 1;
+                mark[o10] = 1;
+                mark[o00 + dxo] = 1;
+                mark[o10 + dxo] = 1;
             }
         }
         if ((a.W & 3) == 0) {   // the raster pass re-reads these instead of re-projecting (coalesced 32 B per thread)
@@ -320,27 +328,51 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
             reinterpret_cast<uint4 *>(pj)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
         }
     }
-    // block reductions: max z, bounding box
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        zmax = fmaxf(zmax, __shfl_xor(zmax, o));
-        bx0 = min(bx0, __shfl_xor(bx0, o)); by0 = min(by0, __shfl_xor(by0, o));
-        bx1 = max(bx1, __shfl_xor(bx1, o)); by1 = max(by1, __shfl_xor(by1, o));
+    // block reductions: max z, bounding box.  In the wave by DPP butterflies (xor 1, xor 2, half-row mirror, row mirror, then
+    // lane 15 / 31 of a row broadcast into the following rows: lane 63 ends up with the reduction) on three values - the
+    // box corners are < 2^13, so the two minima travel as one packed pair of u16 and the two maxima as one of i16;
+    // the shuffles this replaces were 30 LDS round trips + ~150 vector instructions per lane of a kernel that is bound by
+    // vector issue (profiles/r02_experiments.md)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    u16x2 bmin = {(unsigned short)min(bx0, 0xFFFF), (unsigned short)min(by0, 0xFFFF)};
+    i16x2 bmax = {(short)bx1, (short)by1};
+#define PF_DPP_STEP(ctrl, rmask)                                                                                              \
+    {                                                                                                                         \
+        zmax = fmaxf(zmax, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(zmax), __float_as_int(zmax), ctrl, rmask, 0xF, false))); \
+        const int mn = __builtin_bit_cast(int, bmin), mx = __builtin_bit_cast(int, bmax);                                     \
+        bmin = __builtin_elementwise_min(bmin, __builtin_bit_cast(u16x2, __builtin_amdgcn_update_dpp(mn, mn, ctrl, rmask, 0xF, false))); \
+        bmax = __builtin_elementwise_max(bmax, __builtin_bit_cast(i16x2, __builtin_amdgcn_update_dpp(mx, mx, ctrl, rmask, 0xF, false))); \
     }
+    PF_DPP_STEP(0xB1, 0xF)    // quad_perm [1,0,3,2]
+    PF_DPP_STEP(0x4E, 0xF)    // quad_perm [2,3,0,1]
+    PF_DPP_STEP(0x141, 0xF)   // row_half_mirror
+    PF_DPP_STEP(0x140, 0xF)   // row_mirror: every lane of a row holds the row's reduction
+    PF_DPP_STEP(0x142, 0xA)   // row_bcast:15 into rows 1 and 3
+    PF_DPP_STEP(0x143, 0xC)   // row_bcast:31 into rows 2 and 3
+#undef PF_DPP_STEP
     __shared__ float zred[kThreads / 64];
-    __shared__ int bred[kThreads / 64][4];
-    if ((threadIdx.x & 63) == 0) {
+    __shared__ int bred[kThreads / 64][2];
+    if ((threadIdx.x & 63) == 63) {
         const int w = threadIdx.x >> 6;
         zred[w] = zmax;
-        bred[w][0] = bx0; bred[w][1] = by0; bred[w][2] = bx1; bred[w][3] = by1;
+        bred[w][0] = __builtin_bit_cast(int, bmin);
+        bred[w][1] = __builtin_bit_cast(int, bmax);
     }
     __syncthreads();
+    zmax = zred[0];
+    bmin = __builtin_bit_cast(u16x2, bred[0][0]);
+    bmax = __builtin_bit_cast(i16x2, bred[0][1]);
 #pragma unroll
-    for (int w = 0; w < kThreads / 64; ++w) {
+    for (int w = 1; w < kThreads / 64; ++w) {
         zmax = fmaxf(zmax, zred[w]);
-        bx0 = min(bx0, bred[w][0]); by0 = min(by0, bred[w][1]);
-        bx1 = max(bx1, bred[w][2]); by1 = max(by1, bred[w][3]);
+        bmin = __builtin_elementwise_min(bmin, __builtin_bit_cast(u16x2, bred[w][0]));
+        bmax = __builtin_elementwise_max(bmax, __builtin_bit_cast(i16x2, bred[w][1]));
     }
+    bx0 = bmin[0] == 0xFFFF ? 0x7fffffff : (int)bmin[0];
+    by0 = bmin[1] == 0xFFFF ? 0x7fffffff : (int)bmin[1];
+    bx1 = bmax[0];
+    by1 = bmax[1];
     if (threadIdx.x == 0) {
         const long long ntile = (long long)a.stx * a.sty;
         // :105 the sentinel is max(z)+1 over the whole predict call (one frame's points in per_frame mode): one
