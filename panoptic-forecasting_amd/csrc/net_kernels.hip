@@ -8,7 +8,9 @@
 //   avgpool2_kernel    : nn.AvgPool2d(2,2)                     hardnet.py:296
 //   upsample_kernel    : F.interpolate(bilinear, align_corners) hardnet.py:248-253
 //   head_kernel        : final bilinear upsample + argmax      hardnet.py:372-384, bg_model.py:98
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "net_kernels.h"
 #include "conv_epilogue.h"
@@ -287,6 +289,134 @@ __global__ __launch_bounds__(256) void stem_onehot_v3_kernel(StemArgs a) {
     for (int i = 0; i < 8; ++i) {
         o[(2 * i) * op] = fmaxf(acc[i].x, 0.f);
         o[(2 * i + 1) * op] = fmaxf(acc[i].y, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem, 2 x 2 outputs per lane (u8 labels, in-register depth hop: the configuration of the fused forecast model).
+// stem_onehot_v3_kernel is 82 % vector-ALU-busy (PMC) and most of its instructions are not arithmetic on the accumulators:
+// a lane evaluates the label -> row and depth -> hop -> normalise chain for all 9 x T taps of ITS output pixel, although a
+// stride-2 3x3 window shares 5 of its 9 columns/rows with the neighbouring outputs - every input pixel goes through the
+// chain 2.25 times - and it issues 2 loads per tap and frame (54 per output pixel).  Here a lane owns the outputs
+// (oy0..oy0+1) x (ox0..ox0+1): their windows cover 5 x 5 input pixels, so
+//   * the chain runs once per input pixel and frame: 75 instead of 108 evaluations per 4 outputs;
+//   * the five pixels of a window row are ONE aligned 4-byte (labels) / 16-byte (depth) load plus the left neighbour:
+//     4 load instructions per row and frame, 15 per output pixel instead of 54;
+//   * an input pixel is accumulated into the 1-4 (output, tap) pairs it belongs to; which output ROWS an input row feeds
+//     (row 2 feeds both) is wave-uniform: scalar branches in a rolled loop over the 5 input rows.
+// For every output the operations and their order are those of v3 (ky, kx, t ascending; one-hot row, then depth): the
+// results are bit-identical.  FAST_DIV: (d - mean) / std as q = x*r, q += fma(-q, std, x) * r with r = 1/std - correctly
+// rounded for every value the hop chain can produce, which launch_stem() proves by trying all 65 281 of them on the host
+// (stem_fast_div_exact) before it selects this variant.
+// (134 registers = 3 waves per SIMD; capped at 128 for 4 waves it measures the same 342 us with 5 spills)
+template <int T, bool HOP_LUT, bool FAST_DIV>
+__global__ __launch_bounds__(256) void stem_onehot_v4_kernel(StemArgs a, float inv_std) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [tap][t][n_cls + 1][16]
+    __shared__ uint8_t lut[256];
+    const int rows_per = a.n_cls + 1;
+    {
+        const f32x4v *src = reinterpret_cast<const f32x4v *>(a.woh);
+        f32x4v *dst = reinterpret_cast<f32x4v *>(wl);
+        for (int e = threadIdx.x; e < 9 * T * rows_per * 4; e += 256) dst[e] = src[e];
+    }
+    lut[threadIdx.x] = HOP_LUT ? a.lut[threadIdx.x] : (uint8_t)threadIdx.x;
+    __syncthreads();
+
+    const int ox0 = blockIdx.x * 128 + 2 * (threadIdx.x & 63);
+    const int oy0 = blockIdx.y * 8 + 2 * (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (ox0 >= a.Wout || oy0 >= a.Hout) return;          // Wout, Hout even and W = 2 Wout, H = 2 Hout (checked at launch)
+    const unsigned N = (unsigned)a.H * (unsigned)a.W;
+    const uint8_t *seg8 = reinterpret_cast<const uint8_t *>(a.seg) + (size_t)b * T * N;
+    const float *depth = a.depth + (size_t)b * T * N;
+    const int ix0 = 2 * ox0;                               // multiple of 4: window columns ix0 - 1 .. ix0 + 3
+    const bool left_ok = ix0 > 0;
+    struct Row { unsigned lab4[T], labl[T]; f32x4v dep4[T]; float depl[T]; bool ok; };
+    auto issue = [&](int r, Row &p) {
+        const int iy = 2 * oy0 - 1 + r;                    // <= H - 1 for r <= 4
+        p.ok = iy >= 0;
+        const unsigned row = (unsigned)(p.ok ? iy : 0) * (unsigned)a.W + (unsigned)ix0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const unsigned idx = (unsigned)t * N + row;
+            p.lab4[t] = *reinterpret_cast<const unsigned *>(seg8 + idx);
+            p.dep4[t] = *reinterpret_cast<const f32x4v *>(depth + idx);
+            const unsigned il = left_ok ? idx - 1u : idx;
+            p.labl[t] = seg8[il];
+            p.depl[t] = depth[il];
+        }
+    };
+    f32x2v acc[2][2][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[o >> 1][o & 1][i] = f32x2v{a.bias[2 * i], a.bias[2 * i + 1]};
+    const float mean_ = a.depth_mean, std_ = a.depth_std;
+    // one (output, tap) pair: the one-hot row of the label, then the depth channel - as in v3
+    auto accum = [&](f32x2v (&ac)[8], const float *wrow, const float *wd, float dn) {
+        const f32x4v *row = reinterpret_cast<const f32x4v *>(wrow);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4v w4 = row[q];
+            ac[2 * q] += f32x2v{w4[0], w4[1]};
+            ac[2 * q + 1] += f32x2v{w4[2], w4[3]};
+        }
+        const f32x2v dn2 = f32x2v{dn, dn};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ac[i] = __builtin_elementwise_fma(f32x2v{wd[2 * i], wd[2 * i + 1]}, dn2, ac[i]);
+    };
+    Row cur, nxt;
+    issue(0, cur);
+#pragma unroll 1
+    for (int r = 0; r < 5; ++r) {
+        issue(r < 4 ? r + 1 : 4, nxt);
+        const bool f0 = r <= 2, f1 = r >= 2;               // input row r = tap row r of output row 0, r - 2 of output row 1
+        const int tap0 = r * 3, tap1 = (r - 2) * 3;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const bool okc = cur.ok && (c > 0 || left_ok);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                int cls = c == 0 ? (int)cur.labl[t] : (int)((cur.lab4[t] >> (8 * (c - 1))) & 255u);
+                float d = c == 0 ? cur.depl[t] : cur.dep4[t][c == 0 ? 0 : c - 1];
+                if (HOP_LUT) cls = lut[cls & 255];
+                // labels >= n_cls contribute nothing (bg_model.py:54-57): they, and taps outside the image, read the zero row
+                const int rowi = (okc && (unsigned)cls < (unsigned)a.n_cls) ? cls : a.n_cls;
+                const float q = rintf(fminf(fmaxf(d + 1.f, 0.f), 255.f) * 256.f);  // export :119-124
+                d = q / 256.f - 1.f;                                                // load bg_dataset.py:225
+                const bool mk = d > 0.f;
+                d = mk ? fminf(fmaxf(d, a.min_depth), a.max_depth) : -1.f;           // :227-228,:166-170
+                const float m = mk ? 1.f : 0.f;
+                float qn;
+                if (FAST_DIV) {
+                    const float x = d - mean_;
+                    const float q0 = x * inv_std;
+                    qn = __builtin_fmaf(__builtin_fmaf(-q0, std_, x), inv_std, q0);
+                } else {
+                    qn = (d - mean_) / std_;
+                }
+                const float dn = okc ? qn * m : 0.f;                                 // (bg_model.py:50-51,66-67)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int kx = c - 2 * dx;
+                    if (kx < 0 || kx > 2) continue;
+                    if (f0) accum(acc[0][dx], wl + (((tap0 + kx) * T + t) * rows_per + rowi) * 16, a.wdep + ((tap0 + kx) * T + t) * 16, dn);
+                    if (f1) accum(acc[1][dx], wl + (((tap1 + kx) * T + t) * rows_per + rowi) * 16, a.wdep + ((tap1 + kx) * T + t) * 16, dn);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    const size_t op = (size_t)a.Hout * a.Wout;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        float *o = a.dst + (size_t)b * 16 * op + (size_t)(oy0 + dy) * a.Wout + ox0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            *reinterpret_cast<f32x2v *>(o + (2 * i) * op) = f32x2v{fmaxf(acc[dy][0][i].x, 0.f), fmaxf(acc[dy][1][i].x, 0.f)};
+            *reinterpret_cast<f32x2v *>(o + (2 * i + 1) * op) = f32x2v{fmaxf(acc[dy][0][i].y, 0.f), fmaxf(acc[dy][1][i].y, 0.f)};
+        }
     }
 }
 
@@ -620,6 +750,32 @@ static unsigned grid_for(size_t total) {
     return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+// Is  q = x * r;  q += fma(-q, std, x) * r  (r = 1 / std rounded to fp32) the correctly rounded x / std for EVERY x the
+// in-register depth hop can produce?  The hop quantises depth to a u16 code c in 0..65280 (round(clamp(d + 1, 0, 255) * 256)),
+// so x = clamp(c / 256 - 1) - mean takes at most 65 281 values: all of them are tried here (fmaf of the host libm is exact).
+// Cached for the last parameter set.
+static bool stem_fast_div_exact(float mean, float stdv, float dmin, float dmax) {
+    static float key[4] = {0.f, 0.f, 0.f, 0.f};
+    static int cached = -1;
+    if (cached >= 0 && key[0] == mean && key[1] == stdv && key[2] == dmin && key[3] == dmax) return cached != 0;
+    bool ok = std::isfinite(stdv) && stdv != 0.f;
+    const volatile float r = 1.0f / stdv;
+    for (int c = 0; ok && c <= 65280; ++c) {
+        float d = (float)c / 256.f - 1.f;
+        d = d > 0.f ? fminf(fmaxf(d, dmin), dmax) : -1.f;
+        const volatile float x = d - mean;
+        const volatile float q0 = x * r;
+        const volatile float e = fmaf(-q0, stdv, x);
+        const volatile float q1 = fmaf(e, r, q0);
+        const volatile float want = x / stdv;
+        const float got = q1, w = want;
+        ok = memcmp(&got, &w, 4) == 0;
+    }
+    key[0] = mean; key[1] = stdv; key[2] = dmin; key[3] = dmax;
+    cached = ok ? 1 : 0;
+    return ok;
+}
+
 int launch_stem(const StemArgs &a, hipStream_t s) {
     if (a.T * (a.n_cls + 1) * 9 * 16 * sizeof(float) > 60000)
         return fail(PF_EUNSUPPORTED, "stem: T=%d n_cls=%d weights exceed LDS budget", a.T, a.n_cls);
@@ -636,7 +792,20 @@ int launch_stem(const StemArgs &a, hipStream_t s) {
     ProfScope ps(s, label, 2.0 * opx * 16 * a.T * (a.n_cls + 1) * 9,
                  ipx * ((a.seg_is_i64 ? 8 : 1) + 4 + ((a.hop & PF_HOP_DEPTH_U16) ? 0 : 1)) + opx * 16 * 4);
     const dim3 grid((a.Wout + 63) / 64, (a.Hout + 3) / 4, a.B);
-    if (v3) {
+    static const bool no_v4 = getenv("PF_STEM_V3") != nullptr;            // A/B switch: one output per lane
+    const bool v4 = v3 && !no_v4 && !a.seg_is_i64 && (a.hop & PF_HOP_DEPTH_U16) && (a.W & 3) == 0 && (a.H & 3) == 0 &&
+                    a.Wout * 2 == a.W && a.Hout * 2 == a.H;
+    if (v4) {
+        const size_t lds4 = (size_t)9 * a.T * (a.n_cls + 1) * 16 * sizeof(float);
+        const bool fast = stem_fast_div_exact(a.depth_mean, a.depth_std, a.min_depth, a.max_depth);
+        const float inv_std = 1.0f / a.depth_std;
+        const dim3 grid4((a.Wout + 127) / 128, (a.Hout + 7) / 8, a.B);
+        const bool hl = (a.hop & PF_HOP_TRAINID_LUT) != 0;
+        if (hl && fast) hipLaunchKernelGGL((stem_onehot_v4_kernel<3, true, true>), grid4, dim3(256), lds4, s, a, inv_std);
+        else if (hl) hipLaunchKernelGGL((stem_onehot_v4_kernel<3, true, false>), grid4, dim3(256), lds4, s, a, inv_std);
+        else if (fast) hipLaunchKernelGGL((stem_onehot_v4_kernel<3, false, true>), grid4, dim3(256), lds4, s, a, inv_std);
+        else hipLaunchKernelGGL((stem_onehot_v4_kernel<3, false, false>), grid4, dim3(256), lds4, s, a, inv_std);
+    } else if (v3) {
         const size_t lds3 = (size_t)9 * a.T * (a.n_cls + 1) * kStemRow * sizeof(float);
         const int variant = (a.seg_is_i64 ? 4 : 0) | ((a.hop & PF_HOP_DEPTH_U16) ? 2 : 0) | ((a.hop & PF_HOP_TRAINID_LUT) ? 1 : 0);
 #define PF_STEM3(V, S64, HD, HL) \
