@@ -16,8 +16,8 @@
 //                  bounding box of the destination bins its VALID points reach; a byte mark per bin reached by an
 //                  INVALID point (plain stores of the constant 1 - no atomics needed); optional result2d.  The tile then
 //                  appends its id to the list of every destination tile its box touches (one global atomicAdd per pair).
-//   raster_kernel  one workgroup per 32x128 DESTINATION tile: reads its list (kFlight source tiles' 32-B-per-lane records in
-//                  flight at a time; a list that overflowed kListCap falls back to testing every box of the frame), and
+//   raster_kernel  one workgroup (512 threads = two groups of 256, each taking its own source tiles) per 32x128 DESTINATION
+//                  tile: reads its list (kFlight source tiles' 32-B-per-lane records in flight per group at a time; a list that overflowed kListCap falls back to testing every box of the frame), and
 //                  resolves "min depth, ties -> lowest element index" with 64-bit ds_min on a packed key in a 32 KB LDS
 //                  z-buffer it alone owns; then writes seg/depth for its pixels.  The z-buffer never exists in HBM.
 //                  List order is arbitrary (atomic appends); min() does not care: the output is deterministic.
@@ -48,12 +48,28 @@ long long *probe_buffer();
 
 constexpr unsigned long long kEmpty = ~0ull;
 constexpr int kThreads = 256;
+// raster workgroup shape (A/B builds: -DPF_RASTER_THREADS=256 -DPF_RASTER_FLIGHT=8 -DPF_RASTER_MINWAVES=1 is the round-2 start).
+// The kernel waits on dependent memory round trips (list -> records -> LDS -> gather -> store) at a workgroup count per CU
+// that its 32 KB z-buffer fixes at 4: waves hide that better than loads in flight per wave.  Same box, 16 frames:
+// 256 threads x 8 tiles in flight (4 waves per SIMD, 109 registers) 557 us; 512 x 4 at 4 waves 652; 512 x 4 at 5 waves (66
+// registers) 517; 512 x 2 at 8 waves (64 registers) 460-478; 512 x 3 at 8 waves 470; 512 x 1 at 8 waves 485.
+#ifndef PF_RASTER_THREADS
+#define PF_RASTER_THREADS 512
+#endif
+#ifndef PF_RASTER_FLIGHT
+#define PF_RASTER_FLIGHT 2
+#endif
+#ifndef PF_RASTER_MINWAVES
+#define PF_RASTER_MINWAVES 8   // __launch_bounds__' second argument on HIP: waves per SIMD -> 64 registers
+#endif
+constexpr int kRThreads = PF_RASTER_THREADS;   // raster workgroup: kRHalves groups of 256 threads, each group takes its own source tile
+constexpr int kRHalves = kRThreads / 256;
 constexpr int kSrcTH = 16, kSrcTW = 64;   // source tile (pixels); 256 threads x 4 consecutive pixels
 constexpr int kDstTH = 32, kDstTW = 128;  // destination tile owned by one raster workgroup (32 KB LDS)
 constexpr int kScan = 256;                // bounding boxes tested per thread-pass (overflow path only)
-constexpr int kScanBatches = 8;           // passes per list fill (list holds kScan * kScanBatches tile ids)
+constexpr int kScanBatches = 8;           // (the list holds kScan * kScanBatches = 2048 tile ids)
 constexpr int kListCap = 64;              // source-tile ids per destination-tile list written by bin_kernel (typical fill 6-12)
-constexpr int kFlight = 8;                // source tiles whose projections a raster workgroup keeps in flight
+constexpr int kFlight = PF_RASTER_FLIGHT;  // source tiles whose projections a group of 256 raster threads keeps in flight
 constexpr int kIdFrameShift = 20;         // list entry = (frame inside the z-buffer group) << 20 | source tile
 constexpr int kZSlots = 64;               // atomicMax slots per z-buffer group (spreads the memory-side atomics)
 
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
+__global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(SplatArgs a) {
     __shared__ unsigned long long zb[kDstTH * kDstTW];   // 16 KB
     __shared__ unsigned short list[kScan * kScanBatches];
     __shared__ unsigned ent[kListCap];
@@ -414,7 +430,8 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
 
     RPROBE(0);
     int n_hits_total = 0;
-    for (int i = threadIdx.x; i < kDstTH * kDstTW; i += kThreads) zb[i] = kEmpty;
+    for (int i = threadIdx.x; i < kDstTH * kDstTW; i += kRThreads) zb[i] = kEmpty;
+    const int lt = threadIdx.x & 255, half = threadIdx.x >> 8;   // thread inside its group of 256, group
 
     // sentinel = max(z over the whole predict call) + 1 (:105); one frame's points in per_frame mode
     if (threadIdx.x < 64) {
@@ -448,8 +465,8 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
         }
     };
     auto load4 = [&](const uint2 *pbase, int st, unsigned (&pk)[8], int &x, int &y) {
-        y = (st / a.stx) * kSrcTH + (threadIdx.x >> 4);
-        x = (st % a.stx) * kSrcTW + (threadIdx.x & 15) * 4;
+        y = (st / a.stx) * kSrcTH + (lt >> 4);
+        x = (st % a.stx) * kSrcTW + (lt & 15) * 4;
 #pragma unroll
         for (int k = 0; k < 8; ++k) pk[k] = 0u;      // valid bit clear: nothing to splat
         if (st < 0 || y >= a.H || x >= a.W) return;
@@ -473,14 +490,15 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
     if (cnt <= (unsigned)kListCap) {
         if (threadIdx.x < cnt) ent[threadIdx.x] = a.lists[dslot * kListCap + threadIdx.x];
         __syncthreads();
-        for (int li = 0; li < (int)cnt; li += kFlight) {
+        for (int li = 0; li < (int)cnt; li += kFlight * kRHalves) {
             unsigned pk[kFlight][8];
             int xs[kFlight], ys[kFlight];
             unsigned long long eb[kFlight];
 #pragma unroll
             for (int j = 0; j < kFlight; ++j) {
-                const unsigned e = li + j < (int)cnt ? ent[li + j] : 0u;
-                const int tt = (int)(e >> kIdFrameShift), st = li + j < (int)cnt ? (int)(e & ((1u << kIdFrameShift) - 1u)) : -1;
+                const int le = li + j * kRHalves + half;
+                const unsigned e = le < (int)cnt ? ent[le] : 0u;
+                const int tt = (int)(e >> kIdFrameShift), st = le < (int)cnt ? (int)(e & ((1u << kIdFrameShift) - 1u)) : -1;
                 const int tl = a.per_frame ? g : tt;
                 eb[j] = (unsigned long long)tt * N;
                 load4(a.proj + ((long long)b * a.T + tl) * N, st, pk[j], xs[j], ys[j]);
@@ -501,8 +519,8 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < kScanBatches; ++j) {
-                const int s = s0 + j * kScan + threadIdx.x;
-                if (s < ntile) {
+                const int s = s0 + j * kScan + lt;
+                if (s < ntile && half == 0) {
                     const int4 bb = boxes[s];
                     if (bb.x <= dx1 && bb.z >= dx0 && bb.y <= dy1 && bb.w >= dy0) list[atomicAdd(&list_n, 1)] = (unsigned short)(s - s0);
                 }
@@ -511,11 +529,14 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
             const int n_hit = list_n;
             n_hits_total += n_hit;
             RPROBE(4);
-            for (int li = 0; li < n_hit; li += 4) {
+            for (int li = 0; li < n_hit; li += 4 * kRHalves) {
                 unsigned pk[4][8];
                 int xs[4], ys[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) load4(pbase, li + j < n_hit ? s0 + list[li + j] : -1, pk[j], xs[j], ys[j]);
+                for (int j = 0; j < 4; ++j) {
+                    const int le = li + j * kRHalves + half;
+                    load4(pbase, le < n_hit ? s0 + list[le] : -1, pk[j], xs[j], ys[j]);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) splat4(pk[j], xs[j], ys[j], ebase);
             }
@@ -536,8 +557,8 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(SplatArgs a) {
     const int C = a.C;
     const unsigned Pu = (unsigned)P;
 #pragma unroll
-    for (int it = 0; it < kDstTH * kDstTW / 4 / kThreads; ++it) {
-        const int i4 = it * kThreads + threadIdx.x;
+    for (int it = 0; it < kDstTH * kDstTW / 4 / kRThreads; ++it) {
+        const int i4 = it * kRThreads + threadIdx.x;
         const int y = dy0 + i4 / (kDstTW / 4), x = dx0 + (i4 % (kDstTW / 4)) * 4;
         if (y >= a.H || x >= a.W) continue;
         const long long n0 = (long long)y * a.W + x;
@@ -680,7 +701,7 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     }
     {
         pf::ProfScope ps(s, "pf::raster_kernel(pf::SplatArgs)", 0, dst_px * (2.0 * seg_channels + 4.0));
-        hipLaunchKernelGGL(pf::raster_kernel, dim3(L.dtx * L.dty, G, B), dim3(pf::kThreads), 0, s, a);
+        hipLaunchKernelGGL(pf::raster_kernel, dim3(L.dtx * L.dty, G, B), dim3(pf::kRThreads), 0, s, a);
         PF_LAUNCH_CHECK("raster_kernel");
     }
     return PF_OK;
