@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void stem_onehot_v3_kernel(StemArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stem, 2 x 2 outputs per lane (u8 labels, in-register depth hop: the configuration of the fused forecast model).
+// Stem, 2 x 2 outputs per lane (u8 labels; HOP_D: in-register depth hop - the fused forecast model - else depth + mask planes).
 // stem_onehot_v3_kernel is 82 % vector-ALU-busy (PMC) and most of its instructions are not arithmetic on the accumulators:
 // a lane evaluates the label -> row and depth -> hop -> normalise chain for all 9 x T taps of ITS output pixel, although a
 // stride-2 3x3 window shares 5 of its 9 columns/rows with the neighbouring outputs - every input pixel goes through the
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void stem_onehot_v3_kernel(StemArgs a) {
 // rounded for every value the hop chain can produce, which launch_stem() proves by trying all 65 281 of them on the host
 // (stem_fast_div_exact) before it selects this variant.
 // (134 registers = 3 waves per SIMD; capped at 128 for 4 waves it measures the same 342 us with 5 spills)
-template <int T, bool HOP_LUT, bool FAST_DIV>
+template <int T, bool HOP_D, bool HOP_LUT, bool FAST_DIV>
 __global__ __launch_bounds__(256) void stem_onehot_v4_kernel(StemArgs a, float inv_std) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [tap][t][n_cls + 1][16]
     __shared__ uint8_t lut[256];
@@ -329,9 +329,10 @@ __global__ __launch_bounds__(256) void stem_onehot_v4_kernel(StemArgs a, float i
     const unsigned N = (unsigned)a.H * (unsigned)a.W;
     const uint8_t *seg8 = reinterpret_cast<const uint8_t *>(a.seg) + (size_t)b * T * N;
     const float *depth = a.depth + (size_t)b * T * N;
+    const uint8_t *mask = HOP_D ? nullptr : a.mask + (size_t)b * T * N;
     const int ix0 = 2 * ox0;                               // multiple of 4: window columns ix0 - 1 .. ix0 + 3
     const bool left_ok = ix0 > 0;
-    struct Row { unsigned lab4[T], labl[T]; f32x4v dep4[T]; float depl[T]; bool ok; };
+    struct Row { unsigned lab4[T], labl[T], msk4[T], mskl[T]; f32x4v dep4[T]; float depl[T]; bool ok; };
     auto issue = [&](int r, Row &p) {
         const int iy = 2 * oy0 - 1 + r;                    // <= H - 1 for r <= 4
         p.ok = iy >= 0;
@@ -344,6 +345,8 @@ __global__ __launch_bounds__(256) void stem_onehot_v4_kernel(StemArgs a, float i
             const unsigned il = left_ok ? idx - 1u : idx;
             p.labl[t] = seg8[il];
             p.depl[t] = depth[il];
+            p.msk4[t] = HOP_D ? 0u : *reinterpret_cast<const unsigned *>(mask + idx);
+            p.mskl[t] = HOP_D ? 0u : (unsigned)mask[il];
         }
     };
     f32x2v acc[2][2][8];
@@ -377,16 +380,22 @@ __global__ __launch_bounds__(256) void stem_onehot_v4_kernel(StemArgs a, float i
             const bool okc = cur.ok && (c > 0 || left_ok);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                int cls = c == 0 ? (int)cur.labl[t] : (int)((cur.lab4[t] >> (8 * (c - 1))) & 255u);
+                int cls = c == 0 ? (int)cur.labl[t] : (int)((cur.lab4[t] >> (8 * (c == 0 ? 0 : c - 1))) & 255u);
                 float d = c == 0 ? cur.depl[t] : cur.dep4[t][c == 0 ? 0 : c - 1];
                 if (HOP_LUT) cls = lut[cls & 255];
                 // labels >= n_cls contribute nothing (bg_model.py:54-57): they, and taps outside the image, read the zero row
                 const int rowi = (okc && (unsigned)cls < (unsigned)a.n_cls) ? cls : a.n_cls;
-                const float q = rintf(fminf(fmaxf(d + 1.f, 0.f), 255.f) * 256.f);  // export :119-124
-                d = q / 256.f - 1.f;                                                // load bg_dataset.py:225
-                const bool mk = d > 0.f;
-                d = mk ? fminf(fmaxf(d, a.min_depth), a.max_depth) : -1.f;           // :227-228,:166-170
-                const float m = mk ? 1.f : 0.f;
+                float m;
+                if (HOP_D) {
+                    const float q = rintf(fminf(fmaxf(d + 1.f, 0.f), 255.f) * 256.f);  // export :119-124
+                    d = q / 256.f - 1.f;                                                // load bg_dataset.py:225
+                    const bool mk = d > 0.f;
+                    d = mk ? fminf(fmaxf(d, a.min_depth), a.max_depth) : -1.f;           // :227-228,:166-170
+                    m = mk ? 1.f : 0.f;
+                } else {
+                    const unsigned mb = c == 0 ? cur.mskl[t] : (cur.msk4[t] >> (8 * (c == 0 ? 0 : c - 1))) & 255u;
+                    m = mb ? 1.f : 0.f;
+                }
                 float qn;
                 if (FAST_DIV) {
                     const float x = d - mean_;
@@ -793,18 +802,20 @@ int launch_stem(const StemArgs &a, hipStream_t s) {
                  ipx * ((a.seg_is_i64 ? 8 : 1) + 4 + ((a.hop & PF_HOP_DEPTH_U16) ? 0 : 1)) + opx * 16 * 4);
     const dim3 grid((a.Wout + 63) / 64, (a.Hout + 3) / 4, a.B);
     static const bool no_v4 = getenv("PF_STEM_V3") != nullptr;            // A/B switch: one output per lane
-    const bool v4 = v3 && !no_v4 && !a.seg_is_i64 && (a.hop & PF_HOP_DEPTH_U16) && (a.W & 3) == 0 && (a.H & 3) == 0 &&
-                    a.Wout * 2 == a.W && a.Hout * 2 == a.H;
+    const bool v4 = v3 && !no_v4 && !a.seg_is_i64 && (a.W & 3) == 0 && (a.H & 3) == 0 && a.Wout * 2 == a.W && a.Hout * 2 == a.H;
     if (v4) {
         const size_t lds4 = (size_t)9 * a.T * (a.n_cls + 1) * 16 * sizeof(float);
-        const bool fast = stem_fast_div_exact(a.depth_mean, a.depth_std, a.min_depth, a.max_depth);
+        const bool hd = (a.hop & PF_HOP_DEPTH_U16) != 0, hl = (a.hop & PF_HOP_TRAINID_LUT) != 0;
+        // the reciprocal form of the division is exact only on the value set of the hop (proven per parameter set)
+        const bool fast = hd && stem_fast_div_exact(a.depth_mean, a.depth_std, a.min_depth, a.max_depth);
         const float inv_std = 1.0f / a.depth_std;
         const dim3 grid4((a.Wout + 127) / 128, (a.Hout + 7) / 8, a.B);
-        const bool hl = (a.hop & PF_HOP_TRAINID_LUT) != 0;
-        if (hl && fast) hipLaunchKernelGGL((stem_onehot_v4_kernel<3, true, true>), grid4, dim3(256), lds4, s, a, inv_std);
-        else if (hl) hipLaunchKernelGGL((stem_onehot_v4_kernel<3, true, false>), grid4, dim3(256), lds4, s, a, inv_std);
-        else if (fast) hipLaunchKernelGGL((stem_onehot_v4_kernel<3, false, true>), grid4, dim3(256), lds4, s, a, inv_std);
-        else hipLaunchKernelGGL((stem_onehot_v4_kernel<3, false, false>), grid4, dim3(256), lds4, s, a, inv_std);
+        const int variant = (hd ? 4 : 0) | (hl ? 2 : 0) | (fast ? 1 : 0);
+#define PF_STEM4(V, HD, HL, FD) \
+        if (variant == V) hipLaunchKernelGGL((stem_onehot_v4_kernel<3, HD, HL, FD>), grid4, dim3(256), lds4, s, a, inv_std);
+        PF_STEM4(0, false, false, false) PF_STEM4(2, false, true, false)
+        PF_STEM4(4, true, false, false) PF_STEM4(5, true, false, true) PF_STEM4(6, true, true, false) PF_STEM4(7, true, true, true)
+#undef PF_STEM4
     } else if (v3) {
         const size_t lds3 = (size_t)9 * a.T * (a.n_cls + 1) * kStemRow * sizeof(float);
         const int variant = (a.seg_is_i64 ? 4 : 0) | ((a.hop & PF_HOP_DEPTH_U16) ? 2 : 0) | ((a.hop & PF_HOP_TRAINID_LUT) ? 1 : 0);
