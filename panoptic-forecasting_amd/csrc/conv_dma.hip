@@ -87,8 +87,12 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wk = wave / WM;
-    const int tileY = blockIdx.x / a.tilesX, tileX = blockIdx.x - tileY * a.tilesX;
-    const int tile0 = blockIdx.y * NT, b = blockIdx.z;   // first cout tile of this workgroup
+    // XCD-aware order of tiles and cout groups (conv_mfma.h).  Stride-2 base.2: a 72-float row segment of a 32-pixel-wide
+    // tile touches 3-4 128-B lines for 2.25 lines of data; neighbours on the same XCD re-read them from its L2
+    int tid_lin, cgroup;
+    xcd_tile_order(a.tilesX * a.tilesY, tid_lin, cgroup);
+    const int tileY = tid_lin / a.tilesX, tileX = tid_lin - tileY * a.tilesX;
+    const int tile0 = cgroup * NT, b = blockIdx.z;   // first cout tile of this workgroup
     const int iy0 = tileY * C::TH * STRIDE - KS / 2, ix0 = tileX * C::TW * STRIDE - C::APRON;
 
     f32x4 acc[C::MP][NT];
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
     }
 
     // vector-ALU remainder: this lane's pixel inside the tile and its accumulators
-    const bool do_rem = RV > 0 && (int)blockIdx.y == (int)gridDim.y - 1;
+    const bool do_rem = RV > 0 && cgroup == (int)gridDim.y - 1;
     const int v_mt = wm * C::MP + (lane >> 4), v_ty = v_mt / C::TWT, v_tx = (v_mt % C::TWT) * 16 + (lane & 15);
     float accv[RV > 0 ? RV : 1];
 #pragma unroll

@@ -103,6 +103,30 @@ float split_host_f32(unsigned short h);
 // 2^k with max|w| * 2^k in [2^14, 2^15) (1 for an all-zero tensor)
 float split_weight_scale(const float *w, size_t n);
 
+// Workgroup -> (pixel tile, cout group) for the grids dim3(pixel tiles, cout groups, B) of the fast kernels.  Workgroups are
+// dispatched in linear id order (x fastest) to the 8 XCDs round-robin, and each XCD has its own L2.  With a tile count that
+// is a multiple of 8, id % 8 names the XCD and id / 8 the position in that XCD's queue; the queue is laid out as
+//     XCD x  <-  a contiguous band of tiles;  consecutive positions = the cout groups of ONE tile, then the next tile
+// so that (a) the halo rows / partially used 128-B lines neighbouring tiles share and (b) the whole input tile that the
+// cout groups of a tile share (a 1x1 conv with Cout = 119 at NT = 2 is four workgroups reading the same pixels) are read
+// from HBM once and then from that XCD's L2.  In plain (x, y) order the cout groups of a tile are a whole image of
+// workgroups apart and every one of them streams the input from HBM again.
+__device__ __forceinline__ void xcd_tile_order(int ntiles_xy, int &tile_lin, int &group) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if ((ntiles_xy & 7) != 0) {
+        tile_lin = (int)blockIdx.x;
+        group = (int)blockIdx.y;
+        return;
+    }
+    const int ngroups = (int)gridDim.y;
+    const int lin = (int)blockIdx.x + ntiles_xy * (int)blockIdx.y;
+    const int xcd = lin & 7, pos = lin >> 3;
+    const int t = pos / ngroups;
+    group = pos - t * ngroups;
+    tile_lin = xcd * (ntiles_xy >> 3) + t;
+#endif
+}
+
 // Tiling choice for one conv (depends on shape only; fixed at plan time for the weight packing).
 struct ConvTiling {
     int ks, stride;

@@ -107,10 +107,10 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntl = a.tilesX * a.tilesY;   // XCD-aware tile order (see conv_split.hip)
-    const int tid_lin = (ntl & 7) == 0 ? (int)(blockIdx.x & 7) * (ntl >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int tid_lin, cgroup;   // XCD-aware order of tiles and cout groups (conv_mfma.h)
+    xcd_tile_order(a.tilesX * a.tilesY, tid_lin, cgroup);
     const int tileY = tid_lin / a.tilesX, tileX = tid_lin - tileY * a.tilesX;
-    const int tile0 = blockIdx.y * NT, b = blockIdx.z;
+    const int tile0 = cgroup * NT, b = blockIdx.z;
     const int iy0 = tileY * C::TH - 1, ix0 = tileX * C::TW - 2;
     const size_t plane_bytes = (size_t)a.Hin * a.Win * 8;
     auto abuf = [&](int i) { return smem_raw + i * C::ABUF; };
@@ -399,8 +399,10 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tileY = blockIdx.x / a.tilesX, tileX = blockIdx.x - tileY * a.tilesX;
-    const int tile0 = blockIdx.y * NT, b = blockIdx.z;
+    int tid_lin, cgroup;   // XCD-aware order: the cout groups of a tile run back to back on one XCD and share its L2 (conv_mfma.h)
+    xcd_tile_order(a.tilesX * a.tilesY, tid_lin, cgroup);
+    const int tileY = tid_lin / a.tilesX, tileX = tid_lin - tileY * a.tilesX;
+    const int tile0 = cgroup * NT, b = blockIdx.z;
     const size_t plane_bytes = (size_t)a.Hin * a.Win * 8;
     auto wbuf = [&](int i) { return smem_raw + i * C::WBUF; };
     const int g = lane >> 4;

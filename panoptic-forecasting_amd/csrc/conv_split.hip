@@ -63,12 +63,12 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own L2; giving every
-    // XCD a contiguous band of tiles keeps the halo rows/columns neighbouring tiles share inside one L2
-    const int ntl = a.tilesX * a.tilesY;
-    const int tid_lin = (ntl & 7) == 0 ? (int)(blockIdx.x & 7) * (ntl >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    // XCD-aware order of tiles and cout groups (xcd_tile_order, conv_mfma.h): workgroup ids are dealt round-robin to the 8
+    // XCDs (id % 8), each with its own L2; every XCD gets a contiguous band of tiles, the cout groups of a tile back to back
+    int tid_lin, cgroup;
+    xcd_tile_order(a.tilesX * a.tilesY, tid_lin, cgroup);
     const int tileY = tid_lin / a.tilesX, tileX = tid_lin - tileY * a.tilesX;
-    const int tile0 = blockIdx.y * NT, b = blockIdx.z;
+    const int tile0 = cgroup * NT, b = blockIdx.z;
     const int iy0 = tileY * C::TH - 1, ix0 = tileX * C::TW - 4;
     auto abuf = [&](int) { return smem_raw; };
     auto wbuf = [&](int i) { return smem_raw + C::ABUF + i * C::WBUF; };
@@ -312,8 +312,10 @@ __global__ __launch_bounds__(256) void conv_split1_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tileY = blockIdx.x / a.tilesX, tileX = blockIdx.x - tileY * a.tilesX;
-    const int tile0 = blockIdx.y * NT, b = blockIdx.z;
+    int tid_lin, cgroup;
+    xcd_tile_order(a.tilesX * a.tilesY, tid_lin, cgroup);
+    const int tileY = tid_lin / a.tilesX, tileX = tid_lin - tileY * a.tilesX;
+    const int tile0 = cgroup * NT, b = blockIdx.z;
     auto abuf = [&](int) { return smem_raw; };
     auto wbuf = [&](int i) { return smem_raw + C::ABUF + i * C::WBUF; };
 
