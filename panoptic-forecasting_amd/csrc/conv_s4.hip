@@ -731,7 +731,8 @@ int launch_conv_s4(const ConvArgs &a, int ks, int nt, int wide, int B, hipStream
         }
         if (nt == 1) return launch_s4_cfg<1, 32>(a, B, s);
         if (nt == 2) return launch_s4_cfg<2, 32>(a, B, s);
-        return launch_s4_cfg<3, 32>(a, B, s);
+        if (nt == 3) return launch_s4_cfg<3, 32>(a, B, s);
+        return launch_s4_cfg<4, 32>(a, B, s);   // 4 cout tiles per pixel fragment read from LDS (2 workgroups per CU)
     }
     nt = nt > 4 ? 4 : nt;
     const bool fused = a.pool || a.res || a.no_bias;
