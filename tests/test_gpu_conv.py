@@ -435,6 +435,41 @@ def test_packed_activation_block(h, w, b, nt, wide, force_conv):
     net.close()
 
 
+@pytest.mark.parametrize('h,w,b', [(16, 64, 2), (24, 40, 1)])
+def test_s4_four_cout_tiles(h, w, b, force_conv):
+    """conv_s4_kernel<4, 32> (the table's shape for the 52-cout layers at B=16: one pixel fragment feeds four cout tiles):
+    couts 52 and 70 = 4 and 5 tiles (a second, partial cout group), against float64 torch at the split tolerance."""
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    from panoptic_forecasting_amd import lib as pflib
+    S = arch.Src
+    g = torch.Generator().manual_seed(h + w)
+    x = torch.randn(b, 12, h, w, generator=g) * torch.exp(torch.randn(b, 12, 1, 1, generator=g))
+    spec = MiniSpec(12)
+    t0 = spec.conv('t0', [S(0, 0, 12)], 20, 3)
+    c1 = spec.conv('c1', [S(t0, 0, 20)], 52, 3)
+    c2 = spec.conv('c2', [S(c1, 0, 52), S(t0, 0, 20)], 70, 3)
+    spec.conv('c3', [S(c2, 0, 70)], 11, 3, relu=False)
+    shapes = [('t0', 12, 20), ('c1', 20, 52), ('c2', 72, 70), ('c3', 70, 11)]
+    P = {n: (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5, torch.randn(co, generator=g)) for n, ci, co in shapes}
+    force_conv(5, 4, 0, 0)
+    pflib.profile(True)
+    net = MiniNet(spec, P).run(x.cuda())
+    labels = [r['label'] for r in pflib.profile_results()]
+    pflib.profile(False)
+    assert any('conv_s4_kernel<4, 32>' in l for l in labels), labels
+    D = {k: (v[0].double(), v[1].double()) for k, v in P.items()}
+    t0r = F.relu(F.conv2d(x.double(), *D['t0'], padding=1))
+    c1r = F.relu(F.conv2d(t0r, *D['c1'], padding=1))
+    c2r = F.relu(F.conv2d(torch.cat([c1r, t0r], 1), *D['c2'], padding=1))
+    c3r = F.conv2d(c2r, *D['c3'], padding=1)
+    for name, r, scale in [('c1', c1r, 1), ('c2', c2r, 2), ('c3', c3r, 3)]:
+        r = r.float()
+        err = (net.tensor(name).cpu() - r).abs().max().item()
+        assert err <= scale * _tol_split(r), (name, err, _tol_split(r))
+    net.close()
+
+
 def test_packed_activations_off_is_fp32_layout(force_conv):
     """pf_set_option('packed_acts', 0): the same network, no S4 kernel launched, same results within the split tolerance."""
     from helpers import MiniNet

@@ -3,7 +3,8 @@
 that with two kernels at once, where the idle gaps are and which kernels stretch when they share the chip.
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o t -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-legs
-    python tools/graph_timeline.py gpurun_out/tl/*/t_kernel_trace.csv [steps_to_analyse]
+    python tools/graph_timeline.py gpurun_out/tl/*/t_kernel_trace.csv [steps_to_analyse [sub_batches_per_step [skip_last_sub_batches]]]
+The trace ends with the eager per-kernel timing pass of bench.py (--profile-steps sub-batch forwards): skip those.
 """
 import csv
 import sys
@@ -15,7 +16,7 @@ def short(n):
     return n[:60]
 
 
-def main(path, last_steps=4):
+def main(path, last_steps=4, per_step=2, skip_last=0):
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
@@ -23,14 +24,21 @@ def main(path, last_steps=4):
     rows.sort()
     # a step of the default bench = 2 sub-batches: find the last `last_steps` steps by counting bin_kernel launches (one per sub-batch)
     bins = [i for i, r in enumerate(rows) if 'bin_kernel' in r[2]]
-    per_step = 2
     need = last_steps * per_step
     if len(bins) < need + per_step:
         print('not enough steps in the trace (%d bin_kernel launches)' % len(bins))
         return
-    first = bins[-need]
+    if len(bins) < need + per_step + skip_last:
+        print('not enough steps in the trace (%d bin_kernel launches)' % len(bins))
+        return
+    first = bins[-need - skip_last]
     # the memset before the first bin_kernel belongs to the step too; good enough to start at the bin kernel
-    sel = rows[first:]
+    sel = rows[first:bins[-skip_last]] if skip_last else rows[first:]
+    # the selection ends with the last head kernel of the replayed steps (what follows is the metric exchange / the memset of
+    # the next forward)
+    heads = [i for i, r in enumerate(sel) if 'head_' in r[2]]
+    if heads:
+        sel = sel[:heads[-1] + 1]
     t0, t1 = sel[0][0], max(r[1] for r in sel)
     span = t1 - t0
     ev = []
@@ -72,4 +80,4 @@ def main(path, last_steps=4):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4)
+    main(sys.argv[1], *[int(a) for a in sys.argv[2:5]])
