@@ -88,10 +88,19 @@ struct S4Cfg {
     static constexpr int IW = TW + 4, IH = TH + 2;                        // halo tile, 2-pixel apron left/right (16-B pieces)
     static constexpr int ROWP = IW / 2, PIECES = IH * ROWP;               // 16-B pieces per (term, entry) plane
     static constexpr int NDMA = (PIECES + 63) / 64;                       // DMA instructions per plane (one wave per plane)
-    static constexpr int PLANE = NDMA * 64 * 16;                          // bytes
+    // COLREG (the <2, 32> shape): the collected-tap block (a third of a flush round's weights, used once in four rounds) does
+    // NOT pass through LDS - its fragments are loaded straight into registers right before the flush products - and the
+    // planes hold exactly their pieces: 38.5 KB instead of 48 KB per workgroup = 4 workgroups per CU instead of 3 (with the
+    // register count capped at 128: 6 spilled).  Resident waves are what these kernels are short of
+    // (profiles/r02_experiments.md: taking one workgroup per CU away costs 16-52 %); the other shapes cannot reach
+    // their next workgroup this way (<1, 32> would need 102 registers: 16 spills in the main loop, +35 %) and keep the
+    // third block in LDS, where it costs no exposed load
+    static constexpr bool COLREG = NT == 2 && TW_ == 32;
+    static constexpr int PLANE = COLREG ? PIECES * 16 : NDMA * 64 * 16;   // bytes (lanes past the last piece are masked off)
     static constexpr int ABUF = 4 * PLANE;                                // [term][entry] per stage
     static constexpr int WBLK = 2 * 64 * 16;                              // one instruction's weights of one cout tile: [term][lane][8 fp16]
-    static constexpr int WBUF = NT * 3 * WBLK;                            // [nt][block: instr 0, instr 1, collected tap][term][lane]
+    static constexpr int BPT = COLREG ? 2 : 3;                            // blocks per cout tile in LDS: instr 0, instr 1[, collected tap]
+    static constexpr int WBUF = NT * BPT * WBLK;                          // [nt][block][term][lane]
     static constexpr int WPIECES = WBUF / 16, NITW = (WPIECES + 255) / 256;
     static constexpr size_t LDS_BYTES = 2 * (size_t)ABUF + 2 * (size_t)WBUF;
 };
@@ -101,7 +110,7 @@ __host__ __device__ inline int s4_blocks_before(int r) { return 2 * r + r / 4; }
 __host__ __device__ inline int s4_blocks_total(int rounds) { return 2 * rounds + (rounds + 3) / 4; }
 
 template <int NT, int TW_>
-__global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT == 2) ? 3 : 2) void conv_s4_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : 2) void conv_s4_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = S4Cfg<NT, TW_>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -134,10 +143,10 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT 
     // the packed stream (blocks of a round are consecutive there)
     const int nblocks = s4_blocks_total(a.nchunks);
     unsigned woff[C::NITW];
-    bool wcol[C::NITW];                    // piece of the collected-tap block: fetched in flush rounds only
+    bool wcol[C::NITW];                    // piece of the collected-tap block (BPT = 3 only): fetched in flush rounds only
 #pragma unroll
     for (int it = 0; it < C::NITW; ++it) {
-        const int p = it * 256 + tid, n = p / (3 * 2 * 64), rem = p - n * (3 * 2 * 64);
+        const int p = it * 256 + tid, n = p / (C::BPT * 2 * 64), rem = p - n * (C::BPT * 2 * 64);
         woff[it] = (p < C::WPIECES && tile0 + n < a.ntiles) ? ((unsigned)(tile0 + n) * (unsigned)nblocks * (2 * 64) + (unsigned)rem) * 16u : kS4Oob;
         wcol[it] = rem >= 2 * 2 * 64;
     }
@@ -181,8 +190,9 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT 
     };
     auto is_flush = [&](int r) { return (r & 3) == 3 || r == nrounds - 1; };
     auto issue_part = [&](int r, int stage, int j) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (s4_lds_ptr_t)(abuf(stage) + wave * C::PLANE + j * 1024), 16,
-                                                 areal ? poff[j] : kS4Oob, asoff, 0, 0);
+        if (j * 64 + lane < C::PIECES)   // the plane holds exactly its pieces: lanes past the last one write nothing
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (s4_lds_ptr_t)(abuf(stage) + wave * C::PLANE + j * 1024), 16,
+                                                     areal ? poff[j] : kS4Oob, asoff, 0, 0);
         unsigned char *wdst = wbuf(stage);
         const bool flush = is_flush(r);
 #pragma unroll
@@ -226,13 +236,7 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT 
         };
         auto mtile_off = [&](int mm) { return ((mm / C::MTR) * C::IW + (mm % C::MTR) * 16) * 8; };
         // the three products of one block of weights with 4 M-tiles; `slot0` numbers the MFMA groups for the DMA parts
-        auto products = [&](int blk, int m0, const s4_h8 (&fh)[4], const s4_h8 (&fm)[4], int slot0, bool dma) {
-            s4_h8 wh[NT], wm[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                wh[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * 3 + blk) * 2 + 0) * 64 + lane) * 16);
-                wm[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * 3 + blk) * 2 + 1) * 64 + lane) * 16);
-            }
+        auto mfmas = [&](const s4_h8 (&wh)[NT], const s4_h8 (&wm)[NT], int m0, const s4_h8 (&fh)[4], const s4_h8 (&fm)[4], int slot0, bool dma) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -252,6 +256,15 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT 
                     acc[m0 + m][n] = PF_MFMA_SPLIT(wh[n], fh[m], acc[m0 + m][n]);
             if (dma) issue_slot(round, more, slot0 + 2);
         };
+        auto products = [&](int blk, int m0, const s4_h8 (&fh)[4], const s4_h8 (&fm)[4], int slot0, bool dma) {
+            s4_h8 wh[NT], wm[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                wh[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * C::BPT + blk) * 2 + 0) * 64 + lane) * 16);
+                wm[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * C::BPT + blk) * 2 + 1) * 64 + lane) * 16);
+            }
+            mfmas(wh, wm, m0, fh, fm, slot0, dma);
+        };
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -268,6 +281,22 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT 
             for (int m = 0; m < C::MP; ++m) frag(ab + aoff_col + mtile_off(m), col_h[m], col_m[m]);
         }
         if (is_flush(round)) {
+            // the collected-tap block of this flush round (third block of the round in the packed stream).  COLREG: global ->
+            // registers (L2-resident; the fragment registers of the two full instructions are dead here); else from LDS
+            s4_h8 cwh[NT], cwm[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if (C::COLREG) {
+                    const bool real = tile0 + n < a.ntiles;   // uniform
+                    const char *wp = reinterpret_cast<const char *>(a.wpk) +
+                                     ((size_t)(real ? tile0 + n : 0) * nblocks + s4_blocks_before(round) + 2) * C::WBLK + lane * 16;
+                    cwh[n] = real ? *reinterpret_cast<const s4_h8 *>(wp) : zero8;
+                    cwm[n] = real ? *reinterpret_cast<const s4_h8 *>(wp + 64 * 16) : zero8;
+                } else {
+                    cwh[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * 3 + 2) * 2 + 0) * 64 + lane) * 16);
+                    cwm[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * 3 + 2) * 2 + 1) * 64 + lane) * 16);
+                }
+            }
 #pragma unroll
             for (int hf = 0; hf < HALVES; ++hf) {
                 s4_h8 fh[4], fm[4];
@@ -276,7 +305,7 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT == 1) ? 4 : (TW_ == 32 && NT 
                     fh[m] = col_h[hf * 4 + m];
                     fm[m] = col_m[hf * 4 + m];
                 }
-                products(2, hf * 4, fh, fm, 0, false);
+                mfmas(cwh, cwm, hf * 4, fh, fm, 0, false);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll

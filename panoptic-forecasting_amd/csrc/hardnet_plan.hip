@@ -400,8 +400,10 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.w = p->dev_weights + p->conv[i].raw_off;
             a.wdep = p->dev_weights + p->conv[i].dep_off;
             a.woh = p->conv[i].has_oh ? p->dev_weights + p->conv[i].oh_off : nullptr;
-            a.probe = getenv("PF_PROBE") ? probe_buffer() : nullptr;
-            a.dbg_plane_pad = getenv("PF_DBG_PLANE_PAD") ? atoi(getenv("PF_DBG_PLANE_PAD")) : 0;
+            static const bool stem_probe = getenv("PF_PROBE") != nullptr;     // read once, not per forward
+            static const int stem_plane_pad = getenv("PF_DBG_PLANE_PAD") ? atoi(getenv("PF_DBG_PLANE_PAD")) : 0;
+            a.probe = stem_probe ? probe_buffer() : nullptr;
+            a.dbg_plane_pad = stem_plane_pad;
             a.bias = p->dev_weights + p->conv[i].bias_off;
             a.lut = p->dev_lut;
             a.dst = tptr(o.dst);

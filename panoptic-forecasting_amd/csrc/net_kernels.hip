@@ -794,15 +794,16 @@ int launch_stem(const StemArgs &a, hipStream_t s) {
     const bool batched = a.T == 3 && a.wdep && !generic;
     static const bool no_v3 = getenv("PF_STEM_BATCHED") != nullptr;       // A/B switch: the previous form
     const bool v3 = batched && a.woh && !no_v3 && (unsigned long long)a.T * a.H * a.W < (1ull << 32);
+    static const bool no_v4 = getenv("PF_STEM_V3") != nullptr;            // A/B switch: one output per lane
+    const bool v4 = v3 && !no_v4 && !a.seg_is_i64 && (a.W & 3) == 0 && (a.H & 3) == 0 && a.Wout * 2 == a.W && a.Hout * 2 == a.H;
     const char *label = !batched ? "pf::stem_onehot_kernel(pf::StemArgs)"
+                        : v4 ? "pf::stem_onehot_v4_kernel(pf::StemArgs, float)"
                         : v3 ? "pf::stem_onehot_v3_kernel(pf::StemArgs)"
                         : a.seg_is_i64 ? "void pf::stem_onehot_batched_kernel<3, true>(pf::StemArgs)"
                                        : "void pf::stem_onehot_batched_kernel<3, false>(pf::StemArgs)";
     ProfScope ps(s, label, 2.0 * opx * 16 * a.T * (a.n_cls + 1) * 9,
                  ipx * ((a.seg_is_i64 ? 8 : 1) + 4 + ((a.hop & PF_HOP_DEPTH_U16) ? 0 : 1)) + opx * 16 * 4);
     const dim3 grid((a.Wout + 63) / 64, (a.Hout + 3) / 4, a.B);
-    static const bool no_v4 = getenv("PF_STEM_V3") != nullptr;            // A/B switch: one output per lane
-    const bool v4 = v3 && !no_v4 && !a.seg_is_i64 && (a.W & 3) == 0 && (a.H & 3) == 0 && a.Wout * 2 == a.W && a.Hout * 2 == a.H;
     if (v4) {
         const size_t lds4 = (size_t)9 * a.T * (a.n_cls + 1) * 16 * sizeof(float);
         const bool hd = (a.hop & PF_HOP_DEPTH_U16) != 0, hl = (a.hop & PF_HOP_TRAINID_LUT) != 0;
@@ -853,7 +854,7 @@ int launch_upsample(const float *src, float *dst, int planes, int Hin, int Win, 
 
 int launch_head(const HeadArgs &a, hipStream_t s) {
     const double opx = (double)a.B * a.Hout * a.Wout;
-    ProfScope ps(s, "pf::head_kernel(pf::HeadArgs)", 0, 4.0 * a.B * a.C * a.Hin * a.Win + opx * (a.out_is_i64 ? 8 : 1) +
+    ProfScope ps(s, "pf::head_col_kernel(pf::HeadArgs)", 0, 4.0 * a.B * a.C * a.Hin * a.Win + opx * (a.out_is_i64 ? 8 : 1) +
                                                           (a.out_logits ? opx * a.C * 4 : 0));
     const float sw = a.Wout > 1 ? (float)(a.Win - 1) / (float)(a.Wout - 1) : 0.f;
     const float shh = a.Hout > 1 ? (float)(a.Hin - 1) / (float)(a.Hout - 1) : 0.f;

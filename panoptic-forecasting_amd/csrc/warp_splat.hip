@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
     const int ntile = a.stx * a.sty;
 
     RPROBE(0);
-    int n_hits_total = 0;
+    [[maybe_unused]] int n_hits_total = 0;   // PF_PROBE builds report it
     for (int i = threadIdx.x; i < kDstTH * kDstTW; i += kRThreads) zb[i] = kEmpty;
     const int lt = threadIdx.x & 255, half = threadIdx.x >> 8;   // thread inside its group of 256, group
 
@@ -682,7 +682,8 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     a.stx = L.stx; a.sty = L.sty; a.dtx = L.dtx; a.dty = L.dty;
     a.probe = nullptr;
 #if PF_PROBE
-    a.probe = getenv("PF_PROBE") ? pf::probe_buffer() : nullptr;
+    static const bool splat_probe = getenv("PF_PROBE") != nullptr;   // read once, not per call
+    a.probe = splat_probe ? pf::probe_buffer() : nullptr;
 #endif
     hipStream_t s = (hipStream_t)stream;
     const int G = a.per_frame ? T : 1;
