@@ -88,14 +88,15 @@ struct S4Cfg {
     static constexpr int IW = TW + 4, IH = TH + 2;                        // halo tile, 2-pixel apron left/right (16-B pieces)
     static constexpr int ROWP = IW / 2, PIECES = IH * ROWP;               // 16-B pieces per (term, entry) plane
     static constexpr int NDMA = (PIECES + 63) / 64;                       // DMA instructions per plane (one wave per plane)
-    // COLREG (the <2, 32> shape): the collected-tap block (a third of a flush round's weights, used once in four rounds) does
-    // NOT pass through LDS - its fragments are loaded straight into registers right before the flush products - and the
-    // planes hold exactly their pieces: 38.5 KB instead of 48 KB per workgroup = 4 workgroups per CU instead of 3 (with the
-    // register count capped at 128: 6 spilled).  Resident waves are what these kernels are short of
-    // (profiles/r02_experiments.md: taking one workgroup per CU away costs 16-52 %); the other shapes cannot reach
-    // their next workgroup this way (<1, 32> would need 102 registers: 16 spills in the main loop, +35 %) and keep the
-    // third block in LDS, where it costs no exposed load
-    static constexpr bool COLREG = NT == 2 && TW_ == 32;
+    // COLREG (the <2, 32> and <3, 32> shapes): the collected-tap block (a third of a flush round's weights, used once in four
+    // rounds) does NOT pass through LDS - its fragments are loaded straight into registers right before the flush products -
+    // and the planes hold exactly their pieces: 38.5 instead of 48 KB (NT = 2) / 46.5 instead of 60 KB (NT = 3) per workgroup
+    // = 4 instead of 3 / 3 instead of 2 workgroups per CU, with the register count capped by the launch bounds (128: 6 values,
+    // 168: 8 values parked in scratch across the main loop).  Resident waves are what these kernels are short of
+    // (profiles/r02_experiments.md: taking one workgroup per CU away costs 16-52 %; giving one: -3.6 % / -14 %).  The other
+    // shapes cannot reach their next workgroup this way (<1, 32> would need 102 registers: 16 spills in the main loop, +35 %;
+    // <4, 32> and the 8x64 shapes stay at 2) and keep the third block in LDS, where it costs no exposed load
+    static constexpr bool COLREG = (NT == 2 || NT == 3) && TW_ == 32;
     static constexpr int PLANE = COLREG ? PIECES * 16 : NDMA * 64 * 16;   // bytes (lanes past the last piece are masked off)
     static constexpr int ABUF = 4 * PLANE;                                // [term][entry] per stage
     static constexpr int WBLK = 2 * 64 * 16;                              // one instruction's weights of one cout tile: [term][lane][8 fp16]
@@ -110,7 +111,7 @@ __host__ __device__ inline int s4_blocks_before(int r) { return 2 * r + r / 4; }
 __host__ __device__ inline int s4_blocks_total(int rounds) { return 2 * rounds + (rounds + 3) / 4; }
 
 template <int NT, int TW_>
-__global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : 2) void conv_s4_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT == 3) ? 3 : 2) void conv_s4_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = S4Cfg<NT, TW_>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
