@@ -470,6 +470,41 @@ def test_s4_four_cout_tiles(h, w, b, force_conv):
     net.close()
 
 
+@pytest.mark.parametrize('force', [(0, 0, 0, 0), (5, 1, 0, 0), (5, 2, 0, 0), (5, 3, 0, 0), (1, 4, 1, 0), (1, 2, 2, 0), (4, 1, 0, 0), (4, 2, 1, 0)],
+                         ids=lambda f: 'k%d_%d_%d_%d' % f)
+def test_xcd_tile_order_with_many_cout_groups(force, force_conv):
+    """A tile count that is a multiple of 8 (64x128 image: 8x4 tiles of 8x32) switches every conv kernel to the XCD-aware
+    workgroup order (xcd_tile_order, conv_mfma.h: id % 8 = XCD band, the cout groups of a tile back to back); couts of 70 /
+    90 / 40 give 2-5 cout groups per tile at the forced shapes.  3x3, 1x1 and the stride-2 conv against float64 torch."""
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    S = arch.Src
+    g = torch.Generator().manual_seed(force[0] * 7 + force[1])
+    b, h, w = 2, 64, 128
+    x = torch.randn(b, 12, h, w, generator=g) * torch.exp(torch.randn(b, 12, 1, 1, generator=g))
+    spec = MiniSpec(12)
+    t0 = spec.conv('t0', [S(0, 0, 12)], 20, 3)
+    c1 = spec.conv('c1', [S(t0, 0, 20)], 70, 3)
+    c2 = spec.conv('c2', [S(c1, 0, 70), S(t0, 0, 20)], 90, 1)
+    c3 = spec.conv('c3', [S(c2, 0, 90)], 40, 3, stride=2)
+    spec.conv('c4', [S(c3, 0, 40)], 11, 3, relu=False)
+    shapes = [('t0', 12, 20, 3), ('c1', 20, 70, 3), ('c2', 90, 90, 1), ('c3', 90, 40, 3), ('c4', 40, 11, 3)]
+    P = {n: (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5, torch.randn(co, generator=g)) for n, ci, co, k in shapes}
+    force_conv(*force)
+    net = MiniNet(spec, P).run(x.cuda())
+    D = {k: (v[0].double(), v[1].double()) for k, v in P.items()}
+    t0r = F.relu(F.conv2d(x.double(), *D['t0'], padding=1))
+    c1r = F.relu(F.conv2d(t0r, *D['c1'], padding=1))
+    c2r = F.relu(F.conv2d(torch.cat([c1r, t0r], 1), *D['c2']))
+    c3r = F.relu(F.conv2d(c2r, *D['c3'], padding=1, stride=2))
+    c4r = F.conv2d(c3r, *D['c4'], padding=1)
+    for name, r, scale in [('c1', c1r, 1), ('c2', c2r, 2), ('c3', c3r, 3), ('c4', c4r, 4)]:
+        r = r.float()
+        err = (net.tensor(name).cpu() - r).abs().max().item()
+        assert err <= scale * _tol_split(r), (name, err, _tol_split(r))
+    net.close()
+
+
 def test_packed_activations_off_is_fp32_layout(force_conv):
     """pf_set_option('packed_acts', 0): the same network, no S4 kernel launched, same results within the split tolerance."""
     from helpers import MiniNet
