@@ -187,8 +187,13 @@ class Workload:
     one captured hipGraph.  The low-resolution layers of one sub-batch (small grids, latency-bound) and its memory-bound
     splat/stem kernels overlap the matrix-bound high-resolution layers of another."""
 
-    def __init__(self, sd, B, S, dev, seed0, term, use_graph=True, stagger=False, **model_kw):
+    def __init__(self, sd, B, S, dev, seed0, term, use_graph=True, stagger=False, free_run_ms=None, **model_kw):
         self.stagger = stagger
+        # free_run_ms (experiment, --free-run MS): one hipGraph PER sub-batch, each replayed on its own stream with no join
+        # between steps; sub-batch i starts i * MS late (a spin kernel inside the timed region), so that the streams run
+        # out of phase instead of in lockstep.  K steps still enqueue K forwards of every sub-batch; the clock stops when
+        # the last stream has drained
+        self.free_run_ms = free_run_ms if (free_run_ms is not None and use_graph and S > 1) else None
         if B % S:
             raise SystemExit('--batch must be a multiple of --streams')
         self.B, self.S, self.use_graph = B, S, use_graph
@@ -205,6 +210,31 @@ class Workload:
         self.out = self.step()          # builds the plans, sizes the workspaces
         torch.cuda.synchronize()
         self.run = self.step
+        if self.free_run_ms is not None:
+            self.graphs = []
+            streams = [torch.cuda.current_stream()] + self.side
+            for i in range(S):
+                st = torch.cuda.Stream()
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    for _ in range(2):
+                        self.models[i].predict(self.subs[i], None)
+                torch.cuda.current_stream().wait_stream(st)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.out[i] = self.models[i].predict(self.subs[i], None)
+                self.graphs.append(g)
+            # spin-kernel cycles per millisecond
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            torch.cuda._sleep(10000000)
+            e1.record()
+            torch.cuda.synchronize()
+            self.cyc_per_ms = 10000000 / e0.elapsed_time(e1)
+            self.streams = streams
+            self.run = None
+            return
         if use_graph:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -249,7 +279,35 @@ class Workload:
             cur.wait_stream(self.side[i - 1])
         return outs
 
+    def timed_free_run(self, steps, warmup, dev, barrier):
+        cur = torch.cuda.current_stream()
+
+        def go(n, offset):
+            for i in range(1, self.S):
+                self.streams[i].wait_stream(cur)
+                if offset:
+                    with torch.cuda.stream(self.streams[i]):
+                        torch.cuda._sleep(int(i * self.free_run_ms * self.cyc_per_ms))
+            for _ in range(n):
+                for i in range(self.S):
+                    with torch.cuda.stream(self.streams[i]):
+                        self.graphs[i].replay()
+            for i in range(1, self.S):
+                cur.wait_stream(self.streams[i])
+        go(warmup, False)
+        if barrier and pfdist.is_dist():
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        go(steps, True)
+        torch.cuda.synchronize()
+        if barrier and pfdist.is_dist():
+            torch.distributed.barrier()
+        return pfdist.max_over_ranks(time.perf_counter() - t0, dev) if barrier else time.perf_counter() - t0
+
     def timed(self, steps, warmup, dev, barrier=False):
+        if self.free_run_ms is not None:
+            return self.timed_free_run(steps, warmup, dev, barrier)
         for _ in range(warmup):
             self.run()
         if barrier and pfdist.is_dist():
@@ -368,6 +426,8 @@ def parse_args(argv=None):
                     '(0 = one per 16 frames of the batch)')
     ap.add_argument('--stagger', type=int, default=0, help='1: sub-batch i + 1 of a step starts when the warp/splat of '
                     'sub-batch i is done (software pipeline inside the step) instead of all sub-batches starting together')
+    ap.add_argument('--free-run', type=float, default=None, metavar='MS', help='experiment: one hipGraph per sub-batch on its '
+                    'own stream, no join between steps, sub-batch i starts i * MS late (streams out of phase)')
     ap.add_argument('--term', choices=['short', 'mid'], default='short',
                     help="short = BASELINE configs[1] (dt=3, the headline); mid = configs[2] (dt=9, predicted odometry)")
     ap.add_argument('--dry-run', action='store_true', help='rendezvous + the sharded metric exchange only (gloo, no GPU '
@@ -429,7 +489,8 @@ def main():
     S = max(1, min(args.streams, B)) if args.streams > 0 else max(1, B // SUB_BATCH)
     use_graph = not args.no_graph
     head_kw = {'split_f16': 0} if args.fp32_mfma_only else {}
-    wl = Workload(sd, B, S, dev, seed0=rank * B, term=args.term, use_graph=use_graph, stagger=bool(args.stagger), **head_kw)
+    wl = Workload(sd, B, S, dev, seed0=rank * B, term=args.term, use_graph=use_graph, stagger=bool(args.stagger),
+                  free_run_ms=args.free_run, **head_kw)
     elapsed = wl.timed(args.steps, args.warmup, dev, barrier=True)
     frames = world * B * args.steps
     value = frames / elapsed
@@ -526,7 +587,8 @@ def main():
                 'config': {'workload': ('configs[1]: bg short-term forecast, 3 frames in, dt=3' if args.term == 'short' else
                                         'configs[2]: bg mid-term forecast, 3 frames in, dt=9, predicted-odometry ego chain') +
                                        ', 1024x2048, random-init calibrated weights; step = 3 warp/splats + HarDNet + upsample/argmax',
-                           'frames_per_gpu_per_step': B, 'streams': S, 'launch': 'hipGraph replay' if use_graph else 'eager',
+                           'frames_per_gpu_per_step': B, 'streams': S, 'launch': ('hipGraph per sub-batch on free-running streams, offset %g ms' % args.free_run) if (args.free_run is not None and use_graph and S > 1)
+                           else ('hipGraph replay' if use_graph else 'eager'),
                            'sharding': 'batch over %d rank(s), no data-path collective' % world,
                            'world': joined, 'device': torch.cuda.get_device_name(local),
                            'backend': 'nccl (RCCL)' if pfdist.is_dist() else 'single process'},
