@@ -11,7 +11,7 @@
 //
 //   bin_kernel     one workgroup per 16x64 SOURCE tile: exact-order fp32 projection (this file is built with
 //                  -ffp-contract=off; every product/sum rounded separately, IEEE divides) — four pixels per lane in
-//                  lockstep on the packed fp32 pipe with exact shortcuts for affine cameras (project4_fast), the full (project4_full)
+//                  lockstep on the packed fp32 pipe with exact shortcuts for affine cameras (project4_fast), the full
 //                  scalar chain otherwise — stored as 8 B per point {bits(z), packed bins}; block max(z) partial; the
 //                  bounding box of the destination bins its VALID points reach; a byte mark per bin reached by an
 //                  INVALID point (plain stores of the constant 1 - no atomics needed); optional result2d.  The tile then
@@ -119,14 +119,35 @@ __device__ __forceinline__ float dot4(const float *m, float a, float b, float c,
     return acc;
 }
 
-// the same (uniform) pointer as a value the optimiser cannot trace back: loads through it are not merged with earlier
-// loads of the same addresses, and stay scalar loads
-typedef const float __attribute__((address_space(1))) *GlobalF;
-__device__ __forceinline__ GlobalF relaunder(const float *p) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return (GlobalF)(((unsigned long long)hi << 32) | lo);
+struct Camera {
+    float Kinv[9], E[16], Tm[16], Einv[16], K[9];
+    bool affine;   // uniform: K^-1 and K end in (0,0,1); E, T, E^-1 end in (0,0,0,1)
+};
+
+__device__ __forceinline__ void load_camera(const SplatArgs &a, int b, int t, Camera &c) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        c.Kinv[i] = a.Kinv[b * 9 + i];
+        c.K[i] = a.K[b * 9 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        c.E[i] = a.E[b * 16 + i];
+        c.Einv[i] = a.Einv[b * 16 + i];
+        c.Tm[i] = a.Tt[((long long)b * a.T_total + t) * 16 + i];
+    }
+    // combined without short-circuit: an && chain over loaded values compiles to dependent scalar-load round trips
+    int ok = 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ok &= (int)(c.Kinv[6 + i] == (i == 2 ? 1.0f : 0.0f)) & (int)(c.K[6 + i] == (i == 2 ? 1.0f : 0.0f));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float want = i == 3 ? 1.0f : 0.0f;
+        ok &= (int)(c.E[12 + i] == want) & (int)(c.Tm[12 + i] == want) & (int)(c.Einv[12 + i] == want);
+    }
+    c.affine = ok != 0;
 }
 
 struct Proj {
@@ -151,6 +172,30 @@ __device__ __forceinline__ void bins(float u, float hi, int &b0, int &b1) {
     const float fl = floorf(u);
     b0 = to_bin(fl, hi);
     b1 = b0 + (int)((u > 0.0f) & (u < hi) & (u != fl));
+}
+
+// pc_transform_model.py:54-114 for one pixel.  Used by BOTH kernels so they agree bit for bit.
+__device__ __forceinline__ Proj project(const Camera &c, int x, int y, float d, bool m, float Wf, float Hf) {
+    const float u = (float)x, v = (float)y;
+    const float r0 = dot3(c.Kinv + 0, u, v, 1.0f), r1 = dot3(c.Kinv + 3, u, v, 1.0f), r2 = dot3(c.Kinv + 6, u, v, 1.0f);
+    const float c0 = __fmul_rn(r0, d), c1 = __fmul_rn(r1, d), c2 = __fmul_rn(r2, d);                    // :55-59
+    const float v0 = dot4(c.E + 0, c0, c1, c2, 1.0f), v1 = dot4(c.E + 4, c0, c1, c2, 1.0f),
+                v2 = dot4(c.E + 8, c0, c1, c2, 1.0f), v3 = dot4(c.E + 12, c0, c1, c2, 1.0f);           // :63
+    const float w0 = dot4(c.Tm + 0, v0, v1, v2, v3), w1 = dot4(c.Tm + 4, v0, v1, v2, v3),
+                w2 = dot4(c.Tm + 8, v0, v1, v2, v3), w3 = dot4(c.Tm + 12, v0, v1, v2, v3);             // :68
+    const float e0 = dot4(c.Einv + 0, w0, w1, w2, w3), e1 = dot4(c.Einv + 4, w0, w1, w2, w3),
+                e2 = dot4(c.Einv + 8, w0, w1, w2, w3), e3 = dot4(c.Einv + 12, w0, w1, w2, w3);         // :71
+    const float px = __fdiv_rn(e0, e3), py = __fdiv_rn(e1, e3), z = __fdiv_rn(e2, e3);                // :72-73
+    const float q0 = dot3(c.K + 0, px, py, z), q1 = dot3(c.K + 3, px, py, z), q2 = dot3(c.K + 6, px, py, z);  // :74
+    const float uu = __fdiv_rn(q0, q2), vv = __fdiv_rn(q1, q2);                                       // :75-78
+    Proj p;
+    p.z = z;
+    const bool inb = (uu >= 0.0f) && (uu < Wf) && (vv >= 0.0f) && (vv < Hf);                          // :83-86
+    p.valid = m && (z > 0.0f) && inb;                                                                 // :87-89
+    // :106-114 floor/ceil then clamp
+    bins(uu, Wf - 1.0f, p.x0, p.x1);
+    bins(vv, Hf - 1.0f, p.y0, p.y1);
+    return p;
 }
 
 // ---- the same chain for four consecutive pixels of a row on the packed fp32 pipe, for `affine` cameras.
@@ -192,121 +237,30 @@ __device__ __forceinline__ Proj finish(float uu, float vv, float z, bool m, floa
     return p;
 }
 
-// Scalar registers are what this kernel runs out of (102 per wave; the camera is 66 scalars, every packed operand a scalar
-// PAIR, and the arguments stay live to the end): each spilled scalar costs a v_writelane / v_readlane pair on the vector
-// pipe.  So the fast chain keeps only the rows it uses (48 scalars; the last rows are read once for the `affine` flag), and
-// the full chain - the rare branch, but the allocator sizes the whole kernel for it - fetches its own copy matrix by matrix
-// (`after`: the address of a matrix is picked between two equal pointers by a value of the stage before, so that the
-// scalar loads cannot be hoisted into one 66-register block).  62 -> 31 spilled scalars, 141 -> 70 lane moves per wave,
-// bin_kernel 586 -> 570 us per 16 frames (same-box A/B).  Staging the FAST chain the same way (no spills left in it) measured
-// no gain: the three dependent scalar-load round trips cost what the lane moves did (profiles/r02_experiments.md).
-__device__ __forceinline__ GlobalF after(GlobalF p, GlobalF p_same, float v) {
-    // p_same == p (relaunder): whichever is picked, the address is the same - but it is not known before v is
-    const int bits = __builtin_amdgcn_readfirstlane(__float_as_int(v));
-    return bits == 0x7fc12345 ? p_same : p;
-}
-template <int N>
-__device__ __forceinline__ void fetch_rows(GlobalF p, float (&m)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) m[i] = p[i];
-}
-// uniform: K^-1 and K end in (0,0,1); E, T, E^-1 end in (0,0,0,1)
-__device__ __forceinline__ bool camera_affine(GlobalF pKinv, GlobalF pE, GlobalF pT, GlobalF pEinv, GlobalF pK) {
-    int ok = 1;   // combined without short-circuit: an && chain over loaded values compiles to dependent scalar-load round trips
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float want = i == 2 ? 1.0f : 0.0f;
-        ok &= (int)(pKinv[6 + i] == want) & (int)(pK[6 + i] == want);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float want = i == 3 ? 1.0f : 0.0f;
-        ok &= (int)(pE[12 + i] == want) & (int)(pT[12 + i] == want) & (int)(pEinv[12 + i] == want);
-    }
-    return ok != 0;
-}
-__device__ __forceinline__ bool project4_fast(GlobalF pKinv, GlobalF pE, GlobalF pT, GlobalF pEinv, GlobalF pK, int x, int y,
-                                                const float (&d)[4], const bool (&m)[4], float Wf, float Hf, Proj (&p)[4]) {
-    float Kinv[6], E[12];
-    fetch_rows(pKinv, Kinv);
-    fetch_rows(pE, E);
+__device__ __forceinline__ bool project4_fast(const Camera &c, int x, int y, const float (&d)[4], const bool (&m)[4], float Wf, float Hf,
+                                              Proj (&p)[4]) {
     const f32x2 v = f32x2{(float)y, (float)y};
     const f32x2 ua = f32x2{(float)x, (float)(x + 1)}, ub = f32x2{(float)(x + 2), (float)(x + 3)};
     const f32x2 da = f32x2{d[0], d[1]}, db = f32x2{d[2], d[3]};
-    const f32x2 r0a = pk_dot2c(Kinv + 0, ua, v), r0b = pk_dot2c(Kinv + 0, ub, v);
-    const f32x2 r1a = pk_dot2c(Kinv + 3, ua, v), r1b = pk_dot2c(Kinv + 3, ub, v);
+    const f32x2 r0a = pk_dot2c(c.Kinv + 0, ua, v), r0b = pk_dot2c(c.Kinv + 0, ub, v);
+    const f32x2 r1a = pk_dot2c(c.Kinv + 3, ua, v), r1b = pk_dot2c(c.Kinv + 3, ub, v);
     const f32x2 c0a = r0a * da, c1a = r1a * da, c0b = r0b * db, c1b = r1b * db;                   // r2 == 1: c2 = d
-    float Tm[12];
-    fetch_rows(pT, Tm);
     f32x2 va[3], vb[3], wa[3], wb[3], ea[3], eb[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { va[i] = pk_dot3c(E + 4 * i, c0a, c1a, da); vb[i] = pk_dot3c(E + 4 * i, c0b, c1b, db); }
-    float Einv[12];
-    fetch_rows(pEinv, Einv);
+    for (int i = 0; i < 3; ++i) { va[i] = pk_dot3c(c.E + 4 * i, c0a, c1a, da); vb[i] = pk_dot3c(c.E + 4 * i, c0b, c1b, db); }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { wa[i] = pk_dot3c(Tm + 4 * i, va[0], va[1], va[2]); wb[i] = pk_dot3c(Tm + 4 * i, vb[0], vb[1], vb[2]); }
-    float K[6];
-    fetch_rows(pK, K);
+    for (int i = 0; i < 3; ++i) { wa[i] = pk_dot3c(c.Tm + 4 * i, va[0], va[1], va[2]); wb[i] = pk_dot3c(c.Tm + 4 * i, vb[0], vb[1], vb[2]); }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { ea[i] = pk_dot3c(Einv + 4 * i, wa[0], wa[1], wa[2]); eb[i] = pk_dot3c(Einv + 4 * i, wb[0], wb[1], wb[2]); }
+    for (int i = 0; i < 3; ++i) { ea[i] = pk_dot3c(c.Einv + 4 * i, wa[0], wa[1], wa[2]); eb[i] = pk_dot3c(c.Einv + 4 * i, wb[0], wb[1], wb[2]); }
     if (!(finite2(ea[0]) && finite2(ea[1]) && finite2(ea[2]) && finite2(eb[0]) && finite2(eb[1]) && finite2(eb[2]))) return false;
     // e3 == 1: px = e0, py = e1, z = e2;  q2 == z
-    const f32x2 q0a = pk_dot3(K + 0, ea[0], ea[1], ea[2]), q0b = pk_dot3(K + 0, eb[0], eb[1], eb[2]);
-    const f32x2 q1a = pk_dot3(K + 3, ea[0], ea[1], ea[2]), q1b = pk_dot3(K + 3, eb[0], eb[1], eb[2]);
+    const f32x2 q0a = pk_dot3(c.K + 0, ea[0], ea[1], ea[2]), q0b = pk_dot3(c.K + 0, eb[0], eb[1], eb[2]);
+    const f32x2 q1a = pk_dot3(c.K + 3, ea[0], ea[1], ea[2]), q1b = pk_dot3(c.K + 3, eb[0], eb[1], eb[2]);
     p[0] = finish(__fdiv_rn(q0a.x, ea[2].x), __fdiv_rn(q1a.x, ea[2].x), ea[2].x, m[0], Wf, Hf);
     p[1] = finish(__fdiv_rn(q0a.y, ea[2].y), __fdiv_rn(q1a.y, ea[2].y), ea[2].y, m[1], Wf, Hf);
     p[2] = finish(__fdiv_rn(q0b.x, eb[2].x), __fdiv_rn(q1b.x, eb[2].x), eb[2].x, m[2], Wf, Hf);
     p[3] = finish(__fdiv_rn(q0b.y, eb[2].y), __fdiv_rn(q1b.y, eb[2].y), eb[2].y, m[3], Wf, Hf);
     return true;
-}
-
-// ---- pc_transform_model.py:54-114, the full chain, for the four pixels of a lane: non-affine cameras and lanes with
-// non-finite intermediates.  Matrix by matrix (see above): it must not need more scalar registers than the fast chain
-__device__ __forceinline__ void project4_full(GlobalF pKinv, GlobalF pE, GlobalF pT, GlobalF pEinv, GlobalF pK, int x, int y,
-                                              const float (&d)[4], const bool (&m)[4], float Wf, float Hf, Proj (&p)[4]) {
-    float c[4][3], vv[4][4], w[4][4], e[4][4];
-    {
-        float Kinv[9];
-        fetch_rows(relaunder((const float *)pKinv), Kinv);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float u = (float)(x + k), v = (float)y;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) c[k][i] = __fmul_rn(dot3(Kinv + 3 * i, u, v, 1.0f), d[k]);                  // :55-59
-        }
-    }
-    {
-        float E[16];
-        fetch_rows(after(relaunder((const float *)pE), relaunder((const float *)pE), c[3][2]), E);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) vv[k][i] = dot4(E + 4 * i, c[k][0], c[k][1], c[k][2], 1.0f);                 // :63
-    }
-    {
-        float Tm[16];
-        fetch_rows(after(relaunder((const float *)pT), relaunder((const float *)pT), vv[3][3]), Tm);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w[k][i] = dot4(Tm + 4 * i, vv[k][0], vv[k][1], vv[k][2], vv[k][3]);          // :68
-    }
-    {
-        float Einv[16];
-        fetch_rows(after(relaunder((const float *)pEinv), relaunder((const float *)pEinv), w[3][3]), Einv);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) e[k][i] = dot4(Einv + 4 * i, w[k][0], w[k][1], w[k][2], w[k][3]);            // :71
-    }
-    float K[9];
-    fetch_rows(after(relaunder((const float *)pK), relaunder((const float *)pK), e[3][3]), K);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float px = __fdiv_rn(e[k][0], e[k][3]), py = __fdiv_rn(e[k][1], e[k][3]), z = __fdiv_rn(e[k][2], e[k][3]);   // :72-73
-        const float q0 = dot3(K + 0, px, py, z), q1 = dot3(K + 3, px, py, z), q2 = dot3(K + 6, px, py, z);           // :74
-        p[k] = finish(__fdiv_rn(q0, q2), __fdiv_rn(q1, q2), z, m[k], Wf, Hf);                                        // :75-114
-    }
 }
 
 // 4 consecutive pixels of a row (x multiple of 4): vector loads when the row allows it
@@ -340,9 +294,8 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
     float d[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     bool m[4] = {false, false, false, false};
     if (y < a.H && x < a.W) load4(a, in_base, x, y, d, m);
-    const GlobalF pKinv = (GlobalF)a.Kinv + b * 9, pK = (GlobalF)a.K + b * 9, pE = (GlobalF)a.E + b * 16, pEinv = (GlobalF)a.Einv + b * 16,
-                  pT = (GlobalF)a.Tt + ((long long)b * a.T_total + t) * 16;
-    const bool affine = camera_affine(pKinv, pE, pT, pEinv, pK);
+    Camera cam;
+    load_camera(a, b, t, cam);
     const int g = a.per_frame ? tl : 0, G = a.per_frame ? a.T : 1;
     uint8_t *mark = a.inv_mark + ((long long)b * G + g) * N;
     long long *r2d = a.out_r2d ? a.out_r2d + ((long long)b * a.T + tl) * N * 2 : nullptr;
@@ -354,10 +307,9 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
         uint2 *pj = a.proj + ((long long)b * a.T + tl) * N + (long long)y * a.W + x;
         unsigned pk[8];
         Proj p4[4];
-        if (!(affine && project4_fast(pKinv, pE, pT, pEinv, pK, x, y, d, m, Wf, Hf, p4))) {
-            // the full chain fetches its own copy of the camera, through pointers the optimiser cannot match with the staged
-            // loads of the fast chain (nothing of the camera stays live for this rare branch)
-            project4_full(pKinv, pE, pT, pEinv, pK, x, y, d, m, Wf, Hf, p4);
+        if (!(cam.affine && project4_fast(cam, x, y, d, m, Wf, Hf, p4))) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p4[k] = project(cam, x + k, y, d[k], m[k], Wf, Hf);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

@@ -1,9 +1,8 @@
-mkdir -p gpurun_out/s7p
-for i in 1 2; do
-for v in default fr0 fr2 fr4 fr6; do
-  case $v in default) A="";; fr0) A="--free-run 0";; fr2) A="--free-run 2";; fr4) A="--free-run 4";; fr6) A="--free-run 6";; esac
-  python bench.py --no-cpu-baseline --no-legs --profile-steps 1 $A > gpurun_out/s7p/bench_${v}_$i.json 2> gpurun_out/s7p/bench_${v}_$i.err
-done; done
-python bench.py --no-cpu-baseline --no-legs --profile-steps 1 --batch 48 --streams 3 > gpurun_out/s7p/bench_b48_default.json 2>/dev/null
-python bench.py --no-cpu-baseline --no-legs --profile-steps 1 --batch 48 --streams 3 --free-run 2.7 > gpurun_out/s7p/bench_b48_fr.json 2>/dev/null
-python bench.py --no-cpu-baseline --no-legs --profile-steps 1 --batch 32 --streams 4 --free-run 1 > gpurun_out/s7p/bench_b32s4_fr.json 2>/dev/null
+mkdir -p gpurun_out/s8b
+python -m pytest tests/test_gpu_warp_splat.py -x -q > gpurun_out/s8b/splat_tests.log 2>&1
+BASE=$PWD/panoptic-forecasting_amd/csrc/ab/libpfhip_base.so
+for i in 1 2 3; do
+  PF_LIBPFHIP=$BASE python tools/bench_splat.py > gpurun_out/s8b/splat_base_$i.json 2>/dev/null
+  python tools/bench_splat.py > gpurun_out/s8b/splat_new_$i.json 2>/dev/null
+done
+tail -2 gpurun_out/s8b/splat_tests.log; cat gpurun_out/s8b/splat_*.json
