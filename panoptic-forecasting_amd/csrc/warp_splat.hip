@@ -70,7 +70,8 @@ constexpr int kScan = 256;                // bounding boxes tested per thread-pa
 constexpr int kScanBatches = 8;           // (the list holds kScan * kScanBatches = 2048 tile ids)
 constexpr int kListCap = 64;              // source-tile ids per destination-tile list written by bin_kernel (typical fill 6-12)
 constexpr int kFlight = PF_RASTER_FLIGHT;  // source tiles whose projections a group of 256 raster threads keeps in flight
-constexpr int kIdFrameShift = 20;         // list entry = (frame inside the z-buffer group) << 20 | source tile
+constexpr int kIdFrameShift = 20;         // list entry = (frame inside the z-buffer group) << 20 | source tile  (in the raster workgroup's LDS
+                                          // copy: | source tile row << 10 | column; both < 1024 as bins have 13 bits)
 constexpr int kZSlots = 64;               // atomicMax slots per z-buffer group (spreads the memory-side atomics)
 
 struct SplatArgs {
@@ -493,31 +494,37 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
     //      collected first (one barrier pair per 256 boxes) and then consumed four at a time: their 32-B projection
     //      records are all in flight before the first goes through the LDS atomics - the loop was
     //      a chain of ~2 us load latencies, one per hit (tools/probe_splat.py).
-    auto splat4 = [&](const unsigned (&pk)[8], int x, int y, unsigned long long ebase) {
+    // (the kernel is bound by vector-instruction issue - 87 % busy at 8 waves per SIMD, profiles/r02_k_pmc.json - and this is
+    //  its inner loop: everything in 32 bits - e < 4*T*N < 2^32 is checked at launch - and one unsigned compare per range:
+    //  bins are clamped to the image, so "inside the destination tile" is  bin - tile origin < tile size)
+    auto splat4 = [&](const unsigned (&pk)[8], int x, int y, unsigned ebase) {
+        const unsigned e_first = ebase + (unsigned)y * (unsigned)a.W + (unsigned)x;
+        const unsigned Pu1 = (unsigned)P;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned f = pk[2 * k + 1];
             if (!((f >> 28) & 1u)) continue;   // invalid points were handled by the byte marks
-            const int px0 = (int)(f & 8191u), py0 = (int)((f >> 13) & 8191u);
-            const int px1 = px0 + (int)((f >> 26) & 1u), py1 = py0 + (int)((f >> 27) & 1u);
+            const unsigned rx0 = (f & 8191u) - (unsigned)dx0, ry0 = ((f >> 13) & 8191u) - (unsigned)dy0;
+            const unsigned fx = (f >> 26) & 1u, fy = (f >> 27) & 1u;
+            const unsigned rx1 = rx0 + fx, ry1 = ry0 + fy;
             // replicas r = 0:(x0,y0) 1:(x0,y1) 2:(x1,y0) 3:(x1,y1); e = r*P + t*N + n  (:112).  A replica
             // on the bin of a lower replica of the same point can never win the tie-break: skip it.
-            const unsigned long long e0 = ebase + (unsigned long long)((long long)y * a.W + x + k);
+            const bool in_x0 = rx0 < (unsigned)kDstTW, in_x1 = rx1 < (unsigned)kDstTW && fx != 0u;
+            const bool in_y0 = ry0 < (unsigned)kDstTH, in_y1 = ry1 < (unsigned)kDstTH && fy != 0u;
+            const unsigned e0 = e_first + (unsigned)k;
             const unsigned long long khi = (unsigned long long)pk[2 * k] << 32;
-            const bool in_x0 = px0 >= dx0 && px0 <= dx1, in_x1 = px1 >= dx0 && px1 <= dx1 && px1 != px0;
-            const bool in_y0 = py0 >= dy0 && py0 <= dy1, in_y1 = py1 >= dy0 && py1 <= dy1 && py1 != py0;
-            if (in_x0 && in_y0) atomicMin(&zb[(py0 - dy0) * kDstTW + (px0 - dx0)], khi | e0);
-            if (in_x0 && in_y1) atomicMin(&zb[(py1 - dy0) * kDstTW + (px0 - dx0)], khi | (e0 + (unsigned long long)P));
-            if (in_x1 && in_y0) atomicMin(&zb[(py0 - dy0) * kDstTW + (px1 - dx0)], khi | (e0 + 2ull * P));
-            if (in_x1 && in_y1) atomicMin(&zb[(py1 - dy0) * kDstTW + (px1 - dx0)], khi | (e0 + 3ull * P));
+            if (in_x0 && in_y0) atomicMin(&zb[ry0 * kDstTW + rx0], khi | e0);
+            if (in_x0 && in_y1) atomicMin(&zb[ry1 * kDstTW + rx0], khi | (e0 + Pu1));
+            if (in_x1 && in_y0) atomicMin(&zb[ry0 * kDstTW + rx1], khi | (e0 + 2u * Pu1));
+            if (in_x1 && in_y1) atomicMin(&zb[ry1 * kDstTW + rx1], khi | (e0 + 3u * Pu1));
         }
     };
-    auto load4 = [&](const uint2 *pbase, int st, unsigned (&pk)[8], int &x, int &y) {
-        y = (st / a.stx) * kSrcTH + (lt >> 4);
-        x = (st % a.stx) * kSrcTW + (lt & 15) * 4;
+    auto load4 = [&](const uint2 *pbase, int stx, int sty, unsigned (&pk)[8], int &x, int &y) {   // source tile column, row (< 0: none)
+        y = sty * kSrcTH + (lt >> 4);
+        x = stx * kSrcTW + (lt & 15) * 4;
 #pragma unroll
         for (int k = 0; k < 8; ++k) pk[k] = 0u;      // valid bit clear: nothing to splat
-        if (st < 0 || y >= a.H || x >= a.W) return;
+        if (stx < 0 || y >= a.H || x >= a.W) return;
         const uint2 *pj = pbase + (long long)y * a.W + x;
         if ((a.W & 3) == 0) {
             const uint4 q0 = reinterpret_cast<const uint4 *>(pj)[0], q1 = reinterpret_cast<const uint4 *>(pj)[1];
@@ -536,20 +543,25 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
     const long long dslot = ((long long)b * G + g) * ndst + dtile;
     const unsigned cnt = a.count[dslot];
     if (cnt <= (unsigned)kListCap) {
-        if (threadIdx.x < cnt) ent[threadIdx.x] = a.lists[dslot * kListCap + threadIdx.x];
+        if (threadIdx.x < cnt) {
+            // source tile -> (row, column) once per entry here: a division by the tiles per row inside the loop below costs
+            // every lane ~25 vector instructions per listed tile, in a kernel bound by vector issue
+            const unsigned e = a.lists[dslot * kListCap + threadIdx.x], st = e & ((1u << kIdFrameShift) - 1u), row = st / (unsigned)a.stx;
+            ent[threadIdx.x] = (e & ~((1u << kIdFrameShift) - 1u)) | (row << 10) | (st - row * (unsigned)a.stx);
+        }
         __syncthreads();
         for (int li = 0; li < (int)cnt; li += kFlight * kRHalves) {
             unsigned pk[kFlight][8];
             int xs[kFlight], ys[kFlight];
-            unsigned long long eb[kFlight];
+            unsigned eb[kFlight];
 #pragma unroll
             for (int j = 0; j < kFlight; ++j) {
                 const int le = li + j * kRHalves + half;
                 const unsigned e = le < (int)cnt ? ent[le] : 0u;
-                const int tt = (int)(e >> kIdFrameShift), st = le < (int)cnt ? (int)(e & ((1u << kIdFrameShift) - 1u)) : -1;
+                const int tt = (int)(e >> kIdFrameShift), sx = le < (int)cnt ? (int)(e & 1023u) : -1, sy = (int)((e >> 10) & 1023u);
                 const int tl = a.per_frame ? g : tt;
-                eb[j] = (unsigned long long)tt * N;
-                load4(a.proj + ((long long)b * a.T + tl) * N, st, pk[j], xs[j], ys[j]);
+                eb[j] = (unsigned)tt * (unsigned)N;
+                load4(a.proj + ((long long)b * a.T + tl) * N, sx, sy, pk[j], xs[j], ys[j]);
             }
 #pragma unroll
             for (int j = 0; j < kFlight; ++j) splat4(pk[j], xs[j], ys[j], eb[j]);
@@ -560,7 +572,7 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
         const int tl = a.per_frame ? g : tt;     // local frame index
         const int4 *boxes = a.bbox + ((long long)b * a.T + tl) * ntile;
         const uint2 *pbase = a.proj + ((long long)b * a.T + tl) * N;
-        const unsigned long long ebase = (unsigned long long)tt * N;
+        const unsigned ebase = (unsigned)tt * (unsigned)N;
         for (int s0 = 0; s0 < ntile; s0 += kScan * kScanBatches) {
             __syncthreads();
             if (threadIdx.x == 0) list_n = 0;
@@ -583,7 +595,8 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int le = li + j * kRHalves + half;
-                    load4(pbase, le < n_hit ? s0 + list[le] : -1, pk[j], xs[j], ys[j]);
+                    const int st = le < n_hit ? s0 + list[le] : -1;
+                    load4(pbase, st < 0 ? -1 : st % a.stx, st < 0 ? 0 : st / a.stx, pk[j], xs[j], ys[j]);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) splat4(pk[j], xs[j], ys[j], ebase);
