@@ -617,22 +617,28 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
     const long long seg_base = ((long long)b * a.T_total + a.t_first + (a.per_frame ? g : 0)) * N;
     const int C = a.C;
     const unsigned Pu = (unsigned)P;
+    // uniform bases + 32-bit lane offsets (N < 2^30): one address register per access instead of a 64-bit sum each
+    const uint8_t *segp = a.seg + seg_base * C;
+    float *outd = a.out_depth + out_base;
+    uint8_t *outs = a.out_seg + out_base * C;
 #pragma unroll
     for (int it = 0; it < kDstTH * kDstTW / 4 / kRThreads; ++it) {
         const int i4 = it * kRThreads + threadIdx.x;
         const int y = dy0 + i4 / (kDstTW / 4), x = dx0 + (i4 % (kDstTW / 4)) * 4;
         if (y >= a.H || x >= a.W) continue;
-        const long long n0 = (long long)y * a.W + x;
-        unsigned long long key[4];
-        long long src[4];
+        const unsigned n0 = (unsigned)y * (unsigned)a.W + (unsigned)x;
+        unsigned zbits[4], src[4];
+        bool empty[4];
         uint8_t mk[4], sg[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            key[k] = zb[i4 * 4 + k];
-            unsigned e = (unsigned)key[k];               // e = r*P + t*N + n with r < 4: strip the corner replica
+            const unsigned long long key = zb[i4 * 4 + k];
+            zbits[k] = (unsigned)(key >> 32);
+            empty[k] = zbits[k] == 0xFFFFFFFFu;          // kEmpty; a valid point's z > 0 is never the all-ones pattern
+            unsigned e = (unsigned)key;                  // e = r*P + t*N + n with r < 4: strip the corner replica
             e -= e >= 2u * Pu ? 2u * Pu : 0u;
             e -= e >= Pu ? Pu : 0u;
-            src[k] = key[k] != kEmpty ? seg_base + (long long)e : seg_base;     // always a readable address
+            src[k] = empty[k] ? 0u : e;                  // always a readable address
         }
         if ((a.W & 3) == 0) {
             const uchar4 mv = *reinterpret_cast<const uchar4 *>(mark + n0);
@@ -642,23 +648,23 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
             for (int k = 0; k < 4; ++k) mk[k] = x + k < a.W ? mark[n0 + k] : (uint8_t)0;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sg[k] = C == 1 ? a.seg[src[k]] : (uint8_t)0;
+        for (int k = 0; k < 4; ++k) sg[k] = C == 1 ? segp[src[k]] : (uint8_t)0;
         float dep[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             // empty bin: won by an invalid point (:105,:133) -> max+1, or never touched (:136-138) -> -1
-            dep[k] = key[k] != kEmpty ? __uint_as_float((unsigned)(key[k] >> 32)) : (mk[k] ? sentinel : -1.0f);
-            if (key[k] == kEmpty) sg[k] = 0;
+            dep[k] = !empty[k] ? __uint_as_float(zbits[k]) : (mk[k] ? sentinel : -1.0f);
+            if (empty[k]) sg[k] = 0;
         }
         if ((a.W & 3) == 0) {
-            *reinterpret_cast<float4 *>(a.out_depth + out_base + n0) = make_float4(dep[0], dep[1], dep[2], dep[3]);
-            if (C == 1) *reinterpret_cast<uchar4 *>(a.out_seg + out_base + n0) = make_uchar4(sg[0], sg[1], sg[2], sg[3]);
+            *reinterpret_cast<float4 *>(outd + n0) = make_float4(dep[0], dep[1], dep[2], dep[3]);
+            if (C == 1) *reinterpret_cast<uchar4 *>(outs + n0) = make_uchar4(sg[0], sg[1], sg[2], sg[3]);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (x + k < a.W) {
-                    a.out_depth[out_base + n0 + k] = dep[k];
-                    if (C == 1) a.out_seg[out_base + n0 + k] = sg[k];
+                    outd[n0 + k] = dep[k];
+                    if (C == 1) outs[n0 + k] = sg[k];
                 }
         }
         if (C != 1) {
@@ -666,7 +672,7 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
             for (int k = 0; k < 4; ++k)
                 if (x + k < a.W)
                     for (int c = 0; c < C; ++c)
-                        a.out_seg[(out_base + n0 + k) * C + c] = key[k] != kEmpty ? a.seg[src[k] * C + c] : (uint8_t)0;
+                        outs[(size_t)(n0 + k) * C + c] = !empty[k] ? segp[(size_t)src[k] * C + c] : (uint8_t)0;
         }
     }
     RPROBE(2);

@@ -1,8 +1,9 @@
-mkdir -p gpurun_out/s8c
-python -m pytest tests/test_gpu_warp_splat.py -x -q > gpurun_out/s8c/splat_tests.log 2>&1
-BASE=$PWD/panoptic-forecasting_amd/csrc/ab/libpfhip_base.so
-for i in 1 2 3; do
-  PF_LIBPFHIP=$BASE python tools/bench_splat.py > gpurun_out/s8c/splat_base_$i.json 2>/dev/null
-  python tools/bench_splat.py > gpurun_out/s8c/splat_new_$i.json 2>/dev/null
+mkdir -p gpurun_out/s8e
+D=$PWD/panoptic-forecasting_amd/csrc/ab
+for i in 1 2; do
+  for v in base v3 v4; do
+    PF_LIBPFHIP=$D/libpfhip_$v.so python tools/bench_splat.py > gpurun_out/s8e/splat_${v}_$i.json 2>/dev/null
+  done
+  python tools/bench_splat.py > gpurun_out/s8e/splat_v2_$i.json 2>/dev/null
 done
-tail -2 gpurun_out/s8c/splat_tests.log; cat gpurun_out/s8c/splat_*.json
+for f in gpurun_out/s8e/splat_*.json; do echo -n "$f "; cat $f; done
