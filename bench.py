@@ -7,7 +7,10 @@ One "step" = one pass of the hot path over one batch of synthetic, HBM-resident 
 Ranks are independent (sequences shard by batch); the only collective is the end-of-run all-gather of
 the PQ accumulators.  Prints ONE JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-graph] [--no-cpu-baseline] [--no-legs]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--replays R] [--no-graph] [--no-cpu-baseline] [--no-legs]
+
+A step visits the rank's resident synthetic batch R times (``--replays``, default 4: 4 x 32 = 128 forecast frames per GPU per
+step), so that the driver's 20 steps time about a second instead of a quarter of one; ``config`` states it.
 
 ``--gpus N`` with N > 1 and no launcher environment (WORLD_SIZE unset) re-executes this file under
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` — one rank per GPU over
@@ -18,7 +21,10 @@ At N=1 the same line also carries (driver-timed, same process):
     by_batch   frames/s of ONE stream at B = 1, 2, 4 frames per step (SURVEY.md 8d Config 2; the reference loop batches 2)
     fp32_only  the headline workload with every convolution on the fp32 MFMA (no two-term fp16 operands) + its parity
     roofline   dominant kernel (live hipEvent timing) + ``step``: whole-step algorithmic bytes / kernel time, per stage
-    cpu_baseline  the oracle pipeline on all host cores
+    cpu_baseline  the oracle pipeline on the host cores: at the best torch thread count of a short sweep (`value`) and on all of
+                  them (`value_all_cores`)
+    range_overflow  false = no forward of the timed region met an activation outside the range of the fp16-pair path
+                  (PF_STATUS_RANGE, include/pfhip.h); a true here would invalidate the run and bench.py exits non-zero
 """
 import argparse
 import glob
@@ -68,7 +74,10 @@ def model_params(**model_kw):
                    'final_h': H, 'final_w': W, 'emulate_disk_hop': True, 'seg_is_label_id': True,
                    # every frame gets the sentinel the reference gives it at batch size 1 (outputs independent of how the
                    # frames are batched and sharded; the reference's batch-global max couples the samples of a call)
-                   'per_sample_sentinel': True}}
+                   'per_sample_sentinel': True,
+                   # the status word of every workspace is read ONCE after the timed region (range_overflow in the JSON
+                   # line) instead of with every predict (a stream synchronisation per call)
+                   'on_range_overflow': 'ignore'}}
     p['model'].update(model_kw)
     return p
 
@@ -152,26 +161,22 @@ def _oracle_splats(seed, term):
     return torch.stack([r[0] for r in res], 1).long(), torch.stack([r[1] for r in res], 1)
 
 
-def cpu_baseline(sd, n_frames, term='short'):
-    """The oracle (CPU port of the reference path) timed on ALL of this box's host cores: the three splats of a frame
-    run on three threads (scalar C, the scatter itself is sequential like pytorch_scatter's CPU loop) and are
-    prefetched one frame ahead while torch-CPU runs the network of the current frame on os.cpu_count() threads."""
+def _cpu_sample(sd, n_frames, term, budget_s, seed0=0):
+    """frames/s of the oracle pipeline at the CURRENT torch thread count: the three splats of a frame run on three
+    threads (scalar C, the scatter itself is sequential like pytorch_scatter's CPU loop) and are prefetched one frame ahead
+    while torch-CPU runs the network of the current frame."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import hardnet_ref
-    from oracle import warp_splat as ow
-    ncpu = os.cpu_count() or 1
-    torch.set_num_threads(ncpu)
-    ow.lib()
     last = None
     pre = ThreadPoolExecutor(1)
     t0 = time.perf_counter()
-    nxt = pre.submit(_oracle_splats, 0, term)
+    nxt = pre.submit(_oracle_splats, seed0, term)
     done = 0
     for f in range(n_frames):
         seg, dep = nxt.result()
-        more = f + 1 < n_frames and time.perf_counter() - t0 <= CPU_BUDGET_S
+        more = f + 1 < n_frames and time.perf_counter() - t0 <= budget_s
         if more:
-            nxt = pre.submit(_oracle_splats, f + 1, term)
+            nxt = pre.submit(_oracle_splats, seed0 + f + 1, term)
         last = hardnet_ref.bg_predict(sd, {'seg': seg, 'depth': dep, 'depth_mask': dep > 0}, final_size=(H, W))
         done = f + 1
         if not more:
@@ -179,7 +184,46 @@ def cpu_baseline(sd, n_frames, term='short'):
     dt = time.perf_counter() - t0
     pre.shutdown()
     # the generation of synthetic inputs is inside the loop but is <3 % of it
-    return done / dt, dt, last, done, ncpu
+    return done / dt, dt, last, done
+
+
+def cpu_baseline(sd, n_frames, term='short'):
+    """The oracle (CPU port of the reference path) timed on this box's host cores.  torch's intra-op pool is swept over
+    {32, 64, 128, os.cpu_count()} threads on one warm network forward each (all 256 hardware threads of a 2-socket box
+    thrash: round 2 measured 2.1 s per frame there against 1.25 s on 8 cores); the sample is timed at the best setting
+    (`value`) and, when that is not all cores, again on all of them (`value_all_cores`, what BASELINE.md asks for).
+    The last frame of the sample (seed n_done - 1) is the parity reference of the GPU path."""
+    from oracle import hardnet_ref
+    from oracle import warp_splat as ow
+    ncpu = os.cpu_count() or 1
+    ow.lib()
+    seg, dep = _oracle_splats(0, term)
+    x = {'seg': seg, 'depth': dep, 'depth_mask': dep > 0}
+    sweep = {}
+    for n in sorted({min(n, ncpu) for n in (32, 64, 128, ncpu)}):
+        torch.set_num_threads(n)
+        if not sweep:
+            hardnet_ref.bg_predict(sd, x, final_size=(H, W))       # warm-up (allocator, oneDNN primitives)
+        t0 = time.perf_counter()
+        hardnet_ref.bg_predict(sd, x, final_size=(H, W))
+        sweep[n] = time.perf_counter() - t0
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    fps, secs, last, done = _cpu_sample(sd, n_frames, term, CPU_BUDGET_S * (1.0 if best == ncpu else 0.6))
+    res = {'value': fps, 'unit': 'frames/s', 'cores': min(ncpu, best + T), 'kind': 'port', 'cpu_model': cpu_model_name(),
+           'threads_best': best, 'host_threads': ncpu, 'value_all_cores': fps,
+           'network_s_per_frame_by_threads': {str(k): round(v, 3) for k, v in sweep.items()},
+           'sample': '%d forecast frames @%dx%d in %.1f s: per frame 3 C-oracle splats on 3 threads (prefetched one frame '
+                     'ahead) + torch-CPU HarDNet with torch.set_num_threads(%d) = the fastest of a {32, 64, 128, %d}-thread '
+                     'sweep on one warm frame' % (done, H, W, secs, best, ncpu)}
+    if best != ncpu:
+        torch.set_num_threads(ncpu)
+        fps_all, secs_all, _, done_all = _cpu_sample(sd, n_frames, term, CPU_BUDGET_S * 0.4, seed0=100)
+        res['value_all_cores'] = fps_all
+        res['sample'] += '; value_all_cores: %d frames in %.1f s with torch.set_num_threads(%d = os.cpu_count())' % (
+            done_all, secs_all, ncpu)
+        torch.set_num_threads(best)
+    return res, last, done
 
 
 class Workload:
@@ -301,25 +345,33 @@ class Workload:
         t0 = time.perf_counter()
         go(steps, True)
         torch.cuda.synchronize()
+        self.local_s = time.perf_counter() - t0
         if barrier and pfdist.is_dist():
             torch.distributed.barrier()
         return pfdist.max_over_ranks(time.perf_counter() - t0, dev) if barrier else time.perf_counter() - t0
 
-    def timed(self, steps, warmup, dev, barrier=False):
+    def timed(self, steps, warmup, dev, barrier=False, replays=1):
+        """Seconds for `steps` steps (max over ranks when `barrier`), each step = `replays` passes over the resident batch.
+        self.local_s keeps this rank's own time between the two synchronisations."""
         if self.free_run_ms is not None:
-            return self.timed_free_run(steps, warmup, dev, barrier)
-        for _ in range(warmup):
+            return self.timed_free_run(steps * replays, warmup * replays, dev, barrier)
+        for _ in range(warmup * replays):
             self.run()
         if barrier and pfdist.is_dist():
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(steps * replays):
             self.run()
         torch.cuda.synchronize()
+        self.local_s = time.perf_counter() - t0
         if barrier and pfdist.is_dist():
             torch.distributed.barrier()
         return pfdist.max_over_ranks(time.perf_counter() - t0, dev) if barrier else time.perf_counter() - t0
+
+    def range_overflow(self):
+        """True if any forward since the last check raised PF_STATUS_RANGE in its workspace (include/pfhip.h)"""
+        return any(bool(m.bg.range_status() & 1) for m in self.models)
 
     def outputs(self):
         return {k: torch.cat([o[k] for o in self.out]) for k in self.out[0]}
@@ -415,6 +467,8 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='forecast frames per GPU per step (the reference export loop '
                     'batches 2; throughput saturates around 32-48 frames in flight as two or three concurrent sub-batches of 16)')
+    ap.add_argument('--replays', type=int, default=4, help='passes over the resident batch per step: a step is '
+                    '--replays x --batch forecast frames per GPU (20 steps then time about a second)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-legs', action='store_true', help='skip the by_batch / fp32_only legs (N=1 only)')
@@ -462,9 +516,12 @@ def main():
         acc[:, 1] = rank + 1           # every rank contributes a different count
         allacc = pfdist.gather_accumulators(acc)
         ok = allacc.shape[0] == world and float(allacc[:, 0, 1].sum()) == world * (world + 1) / 2
+        per_rank = pfdist.gather_objects({'rank': rank, 'ms_per_step': 0.0, 'device': 'cpu:%d' % local})
+        ok = ok and [r['rank'] for r in per_rank] == list(range(world)) and len({r['device'] for r in per_rank}) == world
         if rank == 0:
             print(json.dumps({'metric': 'forecast frames/sec @1024x2048, 3-in->dt=3 bg', 'value': None, 'unit': 'frames/s',
                               'n_gpus': joined, 'dry_run': True, 'backend': 'gloo', 'gather_ok': bool(ok),
+                              'per_rank_ms': [r['ms_per_step'] for r in per_rank], 'devices': [r['device'] for r in per_rank],
                               'sharding': 'batch over %d rank(s), no data-path collective' % world}))
         if pfdist.is_dist():
             torch.distributed.barrier()
@@ -491,9 +548,16 @@ def main():
     head_kw = {'split_f16': 0} if args.fp32_mfma_only else {}
     wl = Workload(sd, B, S, dev, seed0=rank * B, term=args.term, use_graph=use_graph, stagger=bool(args.stagger),
                   free_run_ms=args.free_run, **head_kw)
-    elapsed = wl.timed(args.steps, args.warmup, dev, barrier=True)
-    frames = world * B * args.steps
+    R = max(1, args.replays)
+    elapsed = wl.timed(args.steps, args.warmup, dev, barrier=True, replays=R)
+    frames = world * B * R * args.steps
     value = frames / elapsed
+    overflow = wl.range_overflow()
+    # every rank's own step time and device identity: a straggler, or two ranks on one device, shows in the N > 1 line
+    ident = pfdist.device_identity(local)
+    per_rank = pfdist.gather_objects({'rank': rank, 'ms_per_step': 1e3 * wl.local_s / args.steps, 'device': ident})
+    if len({r['device'] for r in per_rank}) != len(per_rank):
+        raise SystemExit('bench.py: %d ranks share devices: %s' % (len(per_rank), [r['device'] for r in per_rank]))
 
     # ---- sharded metric exchange: PQ accumulators of this rank's forecasts vs a synthetic ground truth
     out = wl.outputs()   # the sub-batch outputs are concatenated outside the timed region
@@ -521,10 +585,7 @@ def main():
     ref = None
     n_done = 0
     if single and not args.no_cpu_baseline:
-        fps, secs, ref, n_done, ncpu = cpu_baseline(sd, args.cpu_frames, args.term)
-        cpu = {'value': fps, 'unit': 'frames/s', 'cores': ncpu, 'kind': 'port', 'cpu_model': cpu_model_name(),
-               'sample': '%d forecast frames @%dx%d in %.1f s: per frame 3 C-oracle splats on 3 threads (prefetched one frame '
-                         'ahead) + torch-CPU HarDNet with torch.set_num_threads(%d = os.cpu_count())' % (n_done, H, W, secs, ncpu)}
+        cpu, ref, n_done = cpu_baseline(sd, args.cpu_frames, args.term)
 
     def parity_of(sub, model_kw):
         """Full-size parity of the LAST cpu frame (seed n_done-1) against the HIP path, computed inside the SAME
@@ -552,20 +613,21 @@ def main():
         torch.cuda.empty_cache()
         # SURVEY.md 8d Config 2: B in {1, 2, 4} frames per step on ONE stream (B=1 is the latency configuration)
         by_batch = {}
-        leg_steps = max(args.steps, 30)
+        leg_steps = max(args.steps, 30) * 16        # 480 steps: the B = 1 leg times about half a second
         for b in (1, 2, 4):
             leg = Workload(sd, b, 1, dev, seed0=0, term=args.term, use_graph=use_graph, **head_kw)
             dt = leg.timed(leg_steps, args.warmup, dev)
             by_batch[str(b)] = {'value': b * leg_steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / leg_steps,
                                 'steps': leg_steps, 'streams': 1}
+            overflow = overflow or leg.range_overflow()
             del leg
             torch.cuda.empty_cache()
         if not args.fp32_mfma_only:
             # fp32-instruction configuration: no two-term fp16 operands anywhere (fp32 MFMA / fp32 VALU only)
             leg = Workload(sd, B, S, dev, seed0=0, term=args.term, use_graph=use_graph, split_f16=0)
-            dt = leg.timed(args.steps, args.warmup, dev)
-            fp32_only = {'value': B * args.steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / args.steps,
-                         'frames_per_gpu_per_step': B, 'streams': S, 'dtype': 'f32'}
+            dt = leg.timed(args.steps, args.warmup, dev, replays=R)
+            fp32_only = {'value': B * R * args.steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / args.steps,
+                         'frames_per_gpu_per_step': B * R, 'streams': S, 'dtype': 'f32'}
             recs = profile_records(lambda: leg.models[0].predict(leg.subs[0], None), args.profile_steps)
             r32 = roofline_of(recs, args.profile_steps, B // S, 'one sub-batch, eager, hipEvents')
             fp32_only['roofline'] = {k: r32[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'avg_launch_us',
@@ -582,16 +644,24 @@ def main():
         line = {'metric': 'forecast frames/sec @1024x2048, 3-in->dt=%d bg' % (3 if args.term == 'short' else 9), 'value': value, 'unit': 'frames/s',
                 'n_gpus': joined, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                'dtype': 'f32' if args.fp32_mfma_only else 'f32 (storage, accumulation, strided/low-res convs: fp32 MFMA; tuned 3x3 and 1x1 layers: '
-                         'operands split into two fp16 terms hi+mid (22 significand bits), 3 products on the fp16 MFMA, fp32 accumulate)', 'data': 'synthetic',
+                'dtype': 'f32' if args.fp32_mfma_only else
+                         'f32 (accumulation, strided / low-resolution convs: fp32 MFMA; tuned 3x3 and 1x1 layers: every fp32 operand '
+                         'as two round-to-nearest fp16 terms hi + mid, |x - hi - mid| <= 2^-23 |x| + 2^-25 for |x| <= 65504 (fp32 '
+                         'rounding itself: 2^-24; proven in tests/test_host_logic.py::test_split_operand_bound), 3 products on '
+                         'the fp16 MFMA (the dropped mid*mid <= 2^-22 of a product), fp32 accumulate; |x| > 65504 raises '
+                         'PF_STATUS_RANGE and the forward is re-run on fp32 MFMA: see range_overflow)', 'data': 'synthetic',
+                'range_overflow': bool(overflow),
                 'config': {'workload': ('configs[1]: bg short-term forecast, 3 frames in, dt=3' if args.term == 'short' else
                                         'configs[2]: bg mid-term forecast, 3 frames in, dt=9, predicted-odometry ego chain') +
                                        ', 1024x2048, random-init calibrated weights; step = 3 warp/splats + HarDNet + upsample/argmax',
-                           'frames_per_gpu_per_step': B, 'streams': S, 'launch': ('hipGraph per sub-batch on free-running streams, offset %g ms' % args.free_run) if (args.free_run is not None and use_graph and S > 1)
+                           'frames_per_gpu_per_step': B * R, 'resident_frames_per_gpu': B, 'passes_per_step': R, 'streams': S, 'launch': ('hipGraph per sub-batch on free-running streams, offset %g ms' % args.free_run) if (args.free_run is not None and use_graph and S > 1)
                            else ('hipGraph replay' if use_graph else 'eager'),
                            'sharding': 'batch over %d rank(s), no data-path collective' % world,
                            'world': joined, 'device': torch.cuda.get_device_name(local),
                            'backend': 'nccl (RCCL)' if pfdist.is_dist() else 'single process'},
+                'per_rank_ms': [r['ms_per_step'] for r in per_rank],
+                'per_rank_ms_min_max': [min(r['ms_per_step'] for r in per_rank), max(r['ms_per_step'] for r in per_rank)],
+                'devices': [r['device'] for r in per_rank],
                 'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity, 'by_batch': by_batch, 'fp32_only': fp32_only,
                 'pq_gather_check': {'pq_vs_last_input_labels': pq_synth, 'ranks_gathered': int(allacc.shape[0]),
                                     'note': 'random-init weights: value is meaningless, it exercises the sharded PQ all-gather'}}
@@ -599,6 +669,9 @@ def main():
     if pfdist.is_dist():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if overflow:
+        raise SystemExit('bench.py: PF_STATUS_RANGE was raised inside the timed region: the fp16-pair path met |x| > 65504; '
+                         'the number above is not a valid measurement')
 
 
 if __name__ == '__main__':

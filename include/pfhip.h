@@ -91,6 +91,20 @@ int pf_hardnet_plan_create(const void *blob_host, size_t bytes, int in_ch, int n
 void pf_hardnet_plan_destroy(pf_plan *plan);
 int pf_hardnet_workspace(const pf_plan *plan, int B, int H, int W, size_t *bytes);
 
+/* Status of a forward.  The first 4 bytes of a forward's workspace are a status word: cleared when the forward starts,
+ * bits raised by its kernels, final once the stream has run the forward.
+ *   PF_STATUS_RANGE  a tensor that feeds the two-term fp16 operand path (option "split_f16") held a value with
+ *                    |x| > 65504 (or NaN): fp16 pairs cannot represent it, so the outputs of THIS forward are not to be
+ *                    used.  The reference's fp32 Conv2d (hardnet.py:16-25) has no such limit: re-run the forward with
+ *                    plan option "split_f16" = 0 (what BGModel does by default, bg_model.py `on_range_overflow`) or fail.
+ *                    Never raised by fp32-only plans.  FC-HarDNet activations behind folded BatchNorm are O(1..100).
+ * A caller that manages streams itself reads the word with its outputs (it is ordinary device memory); pf_hardnet_status
+ * is the convenience form: it copies the word to the host and SYNCHRONISES `stream` (the only call of this library that
+ * waits for the device). */
+#define PF_STATUS_RANGE 1u
+#define PF_WS_STATUS_OFFSET 0
+int pf_hardnet_status(const void *ws, unsigned *status, void *stream);
+
 /* hop_flags: emulate the reference's on-disk hop between the two tasks on the fly */
 #define PF_HOP_NONE 0
 #define PF_HOP_TRAINID_LUT 1 /* seg ids -> trainIds (export_cityscapes_segmentation_results.py:34-38) */
@@ -176,7 +190,8 @@ int pf_panoptic_max_ids(void);
  *   logits [B,C,Hin,Win] f32 (the network's orig_size_logits, C = 11 or 19)   labels [B,out_h,out_w] i64 or u8
  *   out3 (device) = { sum over valid pixels of -log softmax(logits)[label], #valid pixels, #pixels with argmax == label }
  *   => loss = out3[0]/out3[1], accuracy = out3[2]/out3[1].  Deterministic (fixed-order fp64 reduction).
- * Workspace: pf_seg_loss_workspace(B, out_h, out_w).  The backward pass / training step is not built.
+ * Workspace: pf_seg_loss_workspace(B, out_h, out_w).  (The training step - this loss with its backward pass - is
+ * pf_train_forward_backward below.)
  */
 int pf_seg_loss_workspace(int B, int out_h, int out_w, size_t *bytes);
 int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void *labels, int labels_i64, int out_h,
@@ -192,8 +207,12 @@ int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void 
  *                   the split kernels (conv_split, conv_s4) for stride-1 3x3 and 1x1 layers: every fp32 operand split into
  *                   two fp16 terms hi + mid (22 significand bits; weights pre-scaled by an exact power of two per conv),
  *                   three products on v_mfma_f32_16x16x32_f16, fp32 accumulation - single layers within 2e-5*(1+max|ref|)
- *                   of fp64 like the fp32 kernels, whole-network logits within 1e-4 either way; activations beyond
- *                   +-65504 lose precision and saturate at +-131008; 0 = every convolution on fp32 MFMA / fp32 VALU;
+ *                   of fp64 like the fp32 kernels, whole-network logits within 1e-4 either way.  Operand bound: both terms
+ *                   are rounded to nearest even, |x - hi - mid| <= 2^-23 |x| (+ 2^-25 absolute below 0.25) for |x| <= 65504
+ *                   (fp32 itself: 2^-24); beyond 65504 the forward raises PF_STATUS_RANGE (above) instead of clamping;
+ *                   0 = every convolution on fp32 MFMA / fp32 VALU;
+ *   "range_guard"   (default 1) the PF_STATUS_RANGE checks of the split path (a compare per stored value); 0 removes them;
+ *   "profile_tag_ops" (default 0; process-wide only) pf_profile_* records carry one label per op of the table (tools/);
  *   "valu_remainder" (default 1) trailing cout % 16 <= 8 channels of a conv_dma layer on the vector ALU. */
 int pf_set_option(const char *name, int value);
 /* The same options per plan: a plan copies the process-wide values when it is created; this call changes them for
@@ -250,10 +269,11 @@ int pf_hardnet_tensor_view(const pf_plan *plan, const char *name, int B, int H, 
                            size_t *ws_offset, int *channels, int *h, int *w);
 /* Copy tensor `name` of the LAST forward of this plan out of its workspace as fp32 NCHW [B,channels,h,w].  Intermediate
  * tensors may live in the packed-pair layout of conv_s4.hip (plan option "packed_acts", on by default): two fp16 terms
- * hi = fp16(x), mid = fp16(x - hi) per element in [B][2][ceil(C/4)][H][W][4] order - this call undoes it. */
+ * hi = fp16(x), mid = fp16(x - hi) (round to nearest even) per element in [B][2][ceil(C/4)][H][W][4] order - this call undoes it. */
 int pf_hardnet_tensor_read(const pf_plan *plan, const char *name, int B, int H, int W, const void *ws, float *dst, void *stream);
-/* fp32 NCHW <-> packed-pair layout (dst of pf_s4_pack: 16 * B * ceil(C/4) * H * W bytes); tests and tensor taps */
-int pf_s4_pack(const float *src, void *dst, int B, int C, int H, int W, void *stream);
+/* fp32 NCHW <-> packed-pair layout (dst of pf_s4_pack: 16 * B * ceil(C/4) * H * W bytes); tests and tensor taps.
+ * status (nullable, device word): PF_STATUS_RANGE is raised when an element is not representable (|x| > 65504, NaN). */
+int pf_s4_pack(const float *src, void *dst, int B, int C, int H, int W, unsigned *status, void *stream);
 int pf_s4_unpack(const void *src, float *dst, int B, int C, int H, int W, void *stream);
 /* Dense-equivalent FLOPs of one forward at (H,W) per sample (2*Cout*Hout*Wout*Cin*k*k summed). */
 int pf_hardnet_flops(const pf_plan *plan, int H, int W, double *flops);

@@ -21,7 +21,9 @@ from .pc_transform_model import _as_u8
 
 # params['model'] key -> option name of pf_hardnet_plan_set_option
 PLAN_OPTIONS = {'split_f16': 'split_f16', 'split_bf16': 'split_f16', 'fuse_pool': 'fuse_pool', 'fuse_upsample': 'fuse_upsample',
-                'use_tuned_table': 'use_tuned_table', 'valu_remainder': 'valu_remainder', 'conv_table_batch': 'table_batch'}
+                'use_tuned_table': 'use_tuned_table', 'valu_remainder': 'valu_remainder', 'conv_table_batch': 'table_batch',
+                'range_guard': 'range_guard'}
+PF_STATUS_RANGE = 1   # include/pfhip.h
 
 
 class _Node(nn.Module):
@@ -111,6 +113,16 @@ class BGModel(BaseModel):
         # for batches of n, so a frame's logits do not depend on the size of the batch it arrives in.
         self.plan_options = {c_name: int(params['model'][key]) for key, c_name in PLAN_OPTIONS.items()
                              if params['model'].get(key) is not None}
+        # What to do when a forward on the two-term fp16 operand path met an activation it cannot represent (|x| > 65504;
+        # include/pfhip.h PF_STATUS_RANGE - the reference's fp32 Conv2d, hardnet.py:16-25, has no such limit):
+        #   'rerun' (default) run that forward again on the fp32 matrix instructions (split_f16 = 0) and return its outputs;
+        #   'raise'  raise PfError;  'ignore'  return whatever the kernels produced (range_status() still tells).
+        # The check reads one word back with the outputs (a stream synchronisation per predict); under hipGraph capture it
+        # is skipped and the caller reads range_status() after the replay (bench.py does).
+        self.on_range_overflow = params['model'].get('on_range_overflow', 'rerun')
+        if self.on_range_overflow not in ('rerun', 'raise', 'ignore'):
+            raise ValueError("model.on_range_overflow must be 'rerun', 'raise' or 'ignore'")
+        self.range_reruns = 0
         self._plan = None
         self._ws = None
         self._norm = None
@@ -160,9 +172,35 @@ class BGModel(BaseModel):
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
         return self._ws
 
+    def range_status(self):
+        """Status word of the last forward in this model's workspace (synchronises): PF_STATUS_RANGE set = that forward
+        met |activation| > 65504 on the fp16-pair path and its outputs must not be used."""
+        if self._ws is None:
+            return 0
+        return int(self._ws[:4].view(torch.int32).item())
+
     # ---- device forward ---------------------------------------------------------------------
     def run(self, inps, depths, depth_masks, want_logits=True, want_orig=True, hop_flags=0, seg_dtype=torch.int64):
-        """One ``pf_bg_forward`` / ``pf_hardnet_forward_dense`` call -> (seg, logits|None, orig|None)."""
+        """``pf_bg_forward`` / ``pf_hardnet_forward_dense`` -> (seg, logits|None, orig|None), with the range check of the
+        fp16-pair path (``on_range_overflow``)."""
+        out = self._run_once(inps, depths, depth_masks, want_logits, want_orig, hop_flags, seg_dtype)
+        if (self.on_range_overflow == 'ignore' or self.plan_options.get('split_f16', 1) == 0
+                or self.plan_options.get('range_guard', 1) == 0 or torch.cuda.is_current_stream_capturing()):
+            return out
+        if not (self.range_status() & PF_STATUS_RANGE):
+            return out
+        if self.on_range_overflow == 'raise':
+            raise _lib.PfError('bg forward: an activation exceeded 65504, the range of the two-term fp16 operand path '
+                               "(PF_STATUS_RANGE); run with model.split_f16 = 0 or on_range_overflow = 'rerun'")
+        L, plan = _lib.load(), self._get_plan()
+        self.range_reruns += 1
+        _lib.check(L.pf_hardnet_plan_set_option(plan, b'split_f16', 0), 'pf_hardnet_plan_set_option')
+        try:
+            return self._run_once(inps, depths, depth_masks, want_logits, want_orig, hop_flags, seg_dtype)
+        finally:
+            _lib.check(L.pf_hardnet_plan_set_option(plan, b'split_f16', 1), 'pf_hardnet_plan_set_option')
+
+    def _run_once(self, inps, depths, depth_masks, want_logits, want_orig, hop_flags, seg_dtype):
         L = _lib.load()
         plan = self._get_plan()
         fused = bool(self.convert2onehot and self.use_depth_inps and inps.dim() == 4)

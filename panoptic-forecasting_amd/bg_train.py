@@ -127,6 +127,47 @@ class BGTrainer:
                 sd[key[:-len('running_var')] + 'num_batches_tracked'] = torch.tensor(self.steps, dtype=torch.long)
         return sd
 
+    # ---- optimizer state in torch.optim.SGD's own format ------------------------------------------
+    def optimizer_state_dict(self):
+        """What ``opt.state_dict()`` of the reference's optimizer holds at this point (train.py:130-136: ``torch.optim.SGD`` over
+        the parameters with ``requires_grad``, in ``model.parameters()`` order; saved at train.py:285): the reference's
+        ``opt.load_state_dict(train_params['optimizer'])`` (train.py:148) accepts it.  Built by a real ``torch.optim.SGD`` on
+        views of the momentum arena, so the dictionary has exactly the fields of the installed torch."""
+        host = self.momentum_buf.detach().cpu()
+        by_key = {key: (off, shape, n) for key, off, shape, n in self.trainable_layout()}
+        params, bufs = [], []
+        for key in reference_parameter_order(list(by_key)):
+            off, shape, n = by_key[key]
+            params.append(torch.nn.Parameter(torch.empty(shape)))
+            bufs.append(host[off:off + n].reshape(shape).clone())
+        opt = torch.optim.SGD(params, lr=self.lr, momentum=self.mom, weight_decay=self.wd)
+        if self.steps > 0 and self.mom != 0.:
+            for p, b in zip(params, bufs):
+                opt.state[p]['momentum_buffer'] = b
+        return opt.state_dict()
+
+    def load_optimizer_state_dict(self, st):
+        """Accepts ``torch.optim.SGD.state_dict()`` of the reference loop (or of ``optimizer_state_dict``) and the flat
+        ``{'momentum_buffer': tensor}`` form this driver wrote in round 2."""
+        if 'momentum_buffer' in st and 'state' not in st:
+            self.momentum_buf.copy_(st['momentum_buffer'])
+            return
+        by_key = {key: (off, shape, n) for key, off, shape, n in self.trainable_layout()}
+        order = reference_parameter_order(list(by_key))
+        ids = [i for g in st['param_groups'] for i in g['params']]
+        if len(ids) != len(order):
+            raise _lib.PfError('optimizer state has %d parameters, the bg network has %d trainable tensors' % (len(ids), len(order)))
+        host = torch.zeros(self.n, dtype=torch.float32)
+        for i, key in zip(ids, order):
+            buf = st['state'].get(i, {}).get('momentum_buffer')
+            if buf is None:
+                continue
+            off, shape, n = by_key[key]
+            if tuple(buf.shape) != tuple(shape):
+                raise _lib.PfError('optimizer state %d (%s): shape %s, expected %s' % (i, key, tuple(buf.shape), shape))
+            host[off:off + n] = buf.detach().float().cpu().reshape(-1)
+        self.momentum_buf.copy_(host)
+
     def named_grads(self):
         """{state_dict key: gradient tensor (view into the flat array)} for the trainable entries."""
         out = {}
@@ -237,6 +278,21 @@ class BGTrainer:
         return out
 
 
+def reference_parameter_order(keys):
+    """The trainable state_dict keys in the order of the reference's ``model.parameters()``: ``hardnet`` registers ``base``,
+    ``transUpBlocks`` (no parameters), ``denseBlocksUp``, ``conv1x1_up``, ``finalConv`` in that order (hardnet.py:274-327), a
+    ConvLayer holds ``conv.weight, norm.weight, norm.bias`` (hardnet.py:16-25).  Pinned by the ``keys`` array of fixture G6."""
+    group = {'base': 0, 'denseBlocksUp': 1, 'conv1x1_up': 2, 'finalConv': 3}
+    leaf = {'conv.weight': 0, 'norm.weight': 1, 'norm.bias': 2, 'weight': 0, 'bias': 1}
+
+    def rank(key):
+        parts = key.split('.')          # model.base.4.layers.1.conv.weight
+        nums = tuple(int(q) for q in parts if q.isdigit())
+        tail = '.'.join(q for q in parts[2:] if not q.isdigit() and q != 'layers')
+        return (group[parts[1]], nums, leaf[tail])
+    return sorted(keys, key=rank)
+
+
 class TrainStepFunction(torch.autograd.Function):
     """Autograd bridge.  forward = the fused device step (forward + loss + backward in one C call; the gradients are then
     already in ``trainer.grad``); backward hands them to autograd scaled by the incoming ``grad_output`` (the reference
@@ -248,12 +304,19 @@ class TrainStepFunction(torch.autograd.Function):
     def forward(ctx, trainer, inputs, labels, *params):
         out = trainer.forward_backward(inputs, labels)
         ctx.trainer = trainer
+        # the gradients of THIS forward live in the shared arena until the next forward overwrites them: backward() checks
+        trainer._fwd_generation = getattr(trainer, '_fwd_generation', 0) + 1
+        ctx.generation = trainer._fwd_generation
         ctx.mark_non_differentiable(out['accuracy'])
         return out['loss'].clone(), out['accuracy']
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_acc):
         tr = ctx.trainer
+        if ctx.generation != tr._fwd_generation:
+            raise RuntimeError('BGModel.loss (training mode): backward() of a loss whose gradients were overwritten by a later '
+                               'loss() call on the same model - call backward() after each loss() (the fused step keeps one '
+                               'gradient arena), e.g. loss_a.backward(); loss_b.backward() instead of (loss_a + loss_b).backward()')
         scaled = tr.grad * grad_loss           # one pass over the flat array; the per-parameter results are views of it
         grads = []
         for _, off, shape, n in tr.trainable_layout():

@@ -340,6 +340,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
                     if (co >= a.Cout) break;
                     float v = accv[r] + a.bias[co];
                     if (a.relu) v = fmaxf(v, 0.f);
+                    range_commit(a.status, fabsf(v));
                     a.dst[((size_t)b * a.dst_ctotal + a.dst_choff + co) * ((size_t)a.Hout * a.Wout) + (size_t)oy * a.Wout + ox] = v;
                 }
             }

@@ -42,6 +42,8 @@ struct ConvArgs {
     int src_begin, src_end;      // input ranges to accumulate (whole conv: 0, n_src)
     int chunk_begin, chunk_end;  // = src_chunk0[src_begin], src_chunk0[src_end] (filled at launch)
     long long *probe;        // PF_PROBE builds only: in-kernel timestamps of workgroup 0 / wave 0 (else nullptr)
+    unsigned *status;        // range guard of the two-term operand split (below): word 0 of the forward's workspace, or
+                             // nullptr (fp32-only plans, training): epilogues OR PF_STATUS_RANGE into it when they store |v| > 65504
     int accum;               // generic kernel (conv_mfma.hip) only: dst += result (gradient accumulation of the training path)
     float acc_scale;         // split kernels (conv_split.hip, conv_s4.hip) only: their weights are packed as fp16 terms of
                              // w * 2^k (k per conv, split_weight_scale()); the raw sums are multiplied by 2^-k (exact)
@@ -61,15 +63,22 @@ struct ConvArgs {
 };
 
 // ---- the two-term operand split of conv_split.hip / conv_s4.hip ------------------------------------------------------
-// Every fp32 operand x of a convolution is fed to the 16-bit matrix pipe as x ~= hi + mid with TWO fp16 TERMS:
-//     hi = fp16(x),  mid = fp16(x - hi)          (x - hi is exact in fp32)
-// 11 + 11 significand bits: |x - hi - mid| <= 2^-21 |x| (and never more than one fp16 subnormal step, 6e-8, for small
-// |x|), against 2^-17 |x| for a pair of bf16 terms at the same storage, the same instruction rate
-// (v_mfma_f32_16x16x32_f16) and the same three products hi*hi + hi*mid + mid*hi.  The price is fp16's range, paid this way:
-//   * activations: both conversions round toward zero (v_cvt_pkrtz_f16_f32, two values per instruction), which SATURATES
-//     at +-65504 instead of producing inf: hi + mid is x to 2^-21 up to |x| = 65504, to 2^-11 up to 131008 (hi is pinned
-//     at 65504 there and mid carries the rest), and clamps beyond (FC-HarDNet activations behind folded BatchNorm are
-//     O(1..100); the split kernels' results stay finite for any finite input);
+// Every fp32 operand x of a convolution is fed to the 16-bit matrix pipe as x ~= hi + mid with TWO fp16 TERMS, both
+// rounded to nearest even:
+//     hi = fp16_rne(x),  mid = fp16_rne(x - hi)          (x - hi is exact in fp32)
+// Operand bound (proved in tests/test_host_logic.py::test_split_operand_bound by exhausting every fp32 exponent, checked
+// bit for bit against the device in tests/test_gpu_conv.py::test_s4_layout_round_trip): |x - hi| <= half an fp16 ulp of x,
+// so the residual needs at most 12 significand bits below hi's last one and mid (11 bits, nearest) leaves
+//     |x - hi - mid| <= 2^-23 |x|                      for 2^-2 <= |x| <= 65504   (fp32's own rounding: 2^-24)
+//     |x - hi - mid| <= 2^-25  (half an fp16 subnormal step: absolute)   for |x| < 2^-2
+// against 2^-21 |x| for the round-toward-zero pair of round 2 and 2^-17 |x| for a pair of bf16 terms, at the same storage,
+// the same instruction rate (v_mfma_f32_16x16x32_f16) and the same three products hi*hi + hi*mid + mid*hi; the dropped
+// product mid*mid is <= 2^-22 of a product.  The price is fp16's range:
+//   * activations: |x| > 65504 cannot be represented.  It is never silent: every kernel that produces a tensor a split
+//     kernel may read (the conv epilogues, the stem, the layout packer) compares what it stores against 65504 and raises
+//     bit PF_STATUS_RANGE of the forward's status word (ConvArgs::status = word 0 of the workspace; range_acc / range_commit
+//     below); the caller re-runs that forward on the fp32 matrix instructions or fails (pfhip.h: pf_hardnet_status,
+//     bg_model.py: on_range_overflow).  FC-HarDNet activations behind folded BatchNorm are O(1..100);
 //   * weights: packed on the host (round to nearest even) after an exact per-conv scaling by 2^k that puts max|w| into
 //     [2^14, 2^15) - small weights keep both terms in fp16's normal range - and the kernels multiply their raw sums
 //     by 2^-k (ConvArgs::acc_scale) before the bias: exact, so the scaling is invisible in the result.
@@ -78,14 +87,24 @@ typedef _Float16 split_t;
 typedef split_t split_x2 __attribute__((ext_vector_type(2)));
 typedef split_t split_x4 __attribute__((ext_vector_type(4)));
 typedef split_t split_x8 __attribute__((ext_vector_type(8)));
-// two values at a time: {hi0, hi1}, {mid0, mid1}
+constexpr float kSplitMaxAbs = 65504.f;   // largest |x| the pair represents (to 2^-23)
+// two values at a time: {hi0, hi1}, {mid0, mid1}; v_cvt_pk_f16_f32 (gfx950) rounds to nearest even, two values per issue
 __device__ __forceinline__ void split_terms2(float x0, float x1, split_x2 &hi, split_x2 &mid) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef __fp16 rtz2 __attribute__((ext_vector_type(2)));
-    const rtz2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    const rtz2 m = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
-    hi = __builtin_bit_cast(split_x2, h);
-    mid = __builtin_bit_cast(split_x2, m);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 x = {x0, x1};
+    hi = __builtin_convertvector(x, split_x2);
+    mid = __builtin_convertvector(x - __builtin_convertvector(hi, f32x2), split_x2);
+#endif
+}
+// range guard: m = running max |v| of what a lane stores; one compare + (never taken) branch at the end.  NaN cannot arise
+// from finite guarded inputs (products <= 65504 * 2^15, K <= a few thousand: the fp32 accumulators cannot overflow)
+__device__ __forceinline__ float range_acc(float m, float a, float b, float c, float d) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(d)));
+}
+__device__ __forceinline__ void range_commit(unsigned *status, float m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (status != nullptr && !(m <= kSplitMaxAbs)) atomicOr(status, 1u);   // PF_STATUS_RANGE
 #endif
 }
 template <typename V4>   // any 4-float vector type
@@ -208,7 +227,10 @@ size_t s4_packed_floats(const S4Range *r, int n_src, int cout, int ks, int pad_s
 void pack_conv_weights_s4(const float *w_oihw, int cin, int cout, int ks, const S4Range *r, int n_src, int pad_sources, float *out);
 int launch_conv_s4(const ConvArgs &a, int ks, int nt, int wide, int B, hipStream_t stream);
 // layout conversion (tests, tensor taps): fp32 NCHW <-> S4
-int launch_s4_pack(const float *src, void *dst, int B, int C, int H, int W, hipStream_t stream);
+// status (nullable, device): PF_STATUS_RANGE is raised when an element exceeds what the pair represents (|x| > 65504)
+int launch_s4_pack(const float *src, void *dst, int B, int C, int H, int W, unsigned *status, hipStream_t stream);
+// raises PF_STATUS_RANGE in *status if any of the n floats at x is not |x| <= 65504 (NaN included)
+int launch_range_check(const float *x, size_t n, unsigned *status, hipStream_t stream);
 int launch_s4_unpack(const void *src, float *dst, int B, int C, int H, int W, hipStream_t stream);
 
 // Kernel/shape choice for one stride-1 conv (conv_select.cpp): kind 1 = conv_dma (p0 = WM, p1 = NT),

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 v[r] += bias;
                 if (a.relu) v[r] = fmaxf(v[r], 0.f);
             }
+            range_commit(a.status, range_acc(0.f, v[0], v[1], v[2], v[3]));   // conv_mfma.h: range guard of the operand split
             float *p = dplane + (size_t)oy * a.Wout + ox;
             if (ox + 3 < a.Wout && (a.Wout & 3) == 0) {
                 if (a.accum) v += *reinterpret_cast<const f32x4 *>(p);

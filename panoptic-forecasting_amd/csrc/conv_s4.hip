@@ -322,6 +322,7 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
         const size_t hw = (size_t)a.Hout * a.Wout;
         const size_t term = (size_t)a.dst_c4 * hw * 8;
         const bool mis = (a.dst_choff & 2) != 0;   // the range starts in the middle of a group (uniform)
+        float vmax = 0.f;                          // range guard of the operand split (conv_mfma.h)
 #pragma unroll
         for (int m = 0; m < C::MP; ++m) {
             const int mt = wave * C::MP + m;
@@ -339,9 +340,7 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
                     v[r] = v[r] * a.acc_scale + bias4[n][r];   // acc_scale = 2^-k of the weight scaling: exact
                     if (a.relu) v[r] = fmaxf(v[r], 0.f);
                 }
-#ifdef S4_EXP_NOSTORE
-                if (v[0] != 12345.678f) continue;
-#endif
+                vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
                 if (a.dst_fmt) {
                     s4_h4 hi, mid;
                     split_terms4(v, hi, mid);
@@ -374,6 +373,7 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
                 }
             }
         }
+        range_commit(a.status, vmax);
     }
     S4_PROBE(59);
 #endif
@@ -589,6 +589,7 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
         const size_t hw = (size_t)Ho * Wo, term = (size_t)a.dst_c4 * hw * 8;
         const bool mis = (a.dst_choff & 2) != 0;
         typedef split_x2 h2;
+        float vmax = 0.f;   // range guard of the operand split (conv_mfma.h)
         // finished values of pixel (rr, q), cout tile n
         auto finish = [&](int rr, int q, int n, const int (&o0)[2], const int (&o1)[2], const float (&lx1)[2], float hy1) {
             s4_f32x4 v = acc[rr * 2 + q][n];
@@ -604,6 +605,7 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
                 }
                 if (a.relu) v[r] = fmaxf(v[r], 0.f);
             }
+            vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
             return v;
         };
         // store 4 channels (couts co..co+3) of ONE output pixel at element offset pix
@@ -703,6 +705,7 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        range_commit(a.status, vmax);
     }
 #endif
 }
@@ -850,19 +853,42 @@ void pack_conv_weights_s4(const float *w, int cin, int cout, int ks, const S4Ran
 }
 
 // ------------------------------------------------------------------------------------------------ layout conversion
-__global__ void s4_pack_kernel(const float *src, unsigned short *dst, int B, int C, int H, int W) {
+__global__ void s4_pack_kernel(const float *src, unsigned short *dst, int B, int C, int H, int W, unsigned *status) {
     const size_t hw = (size_t)H * W, c4 = (C + 3) / 4, n = (size_t)B * c4 * hw;
+    bool bad = false;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t px = i % hw, g = (i / hw) % c4, b = i / (hw * c4);
         for (int r = 0; r < 4; ++r) {
             const int c = (int)g * 4 + r;
             const float x = c < C ? src[((size_t)b * C + c) * hw + px] : 0.f;
+            bad = bad || !(fabsf(x) <= kSplitMaxAbs);
             split_x2 h, m;
             split_terms2(x, 0.f, h, m);
             dst[(((b * 2 + 0) * c4 + g) * hw + px) * 4 + r] = __builtin_bit_cast(unsigned short, h[0]);
             dst[(((b * 2 + 1) * c4 + g) * hw + px) * 4 + r] = __builtin_bit_cast(unsigned short, m[0]);
         }
     }
+    if (bad && status) atomicOr(status, 1u);   // PF_STATUS_RANGE
+}
+// the range guard for tensors no kernel of this library produced (dense network inputs)
+__global__ void range_check_kernel(const float *x, size_t n, unsigned *status) {
+    bool bad = false;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const s4_f32x4 v = reinterpret_cast<const s4_f32x4 *>(x)[i];
+        bad = bad || !(fabsf(v[0]) <= kSplitMaxAbs) || !(fabsf(v[1]) <= kSplitMaxAbs) || !(fabsf(v[2]) <= kSplitMaxAbs) ||
+              !(fabsf(v[3]) <= kSplitMaxAbs);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) bad = bad || !(fabsf(x[n4 * 4 + threadIdx.x]) <= kSplitMaxAbs);
+    if (bad) atomicOr(status, 1u);   // PF_STATUS_RANGE
+}
+int launch_range_check(const float *x, size_t n, unsigned *status, hipStream_t s) {
+    if (!status || n == 0) return PF_OK;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(PF_EINVAL, "range check: input is not 16-B aligned");
+    const size_t blocks = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(range_check_kernel, dim3((unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048)), dim3(256), 0, s, x, n, status);
+    PF_LAUNCH_CHECK("range_check_kernel");
+    return PF_OK;
 }
 __global__ void s4_unpack_kernel(const unsigned short *src, float *dst, int B, int C, int H, int W) {
     const size_t hw = (size_t)H * W, c4 = (C + 3) / 4, n = (size_t)B * C * hw;
@@ -873,8 +899,8 @@ __global__ void s4_unpack_kernel(const unsigned short *src, float *dst, int B, i
         dst[i] = (float)__builtin_bit_cast(split_t, h) + (float)__builtin_bit_cast(split_t, m);
     }
 }
-int launch_s4_pack(const float *src, void *dst, int B, int C, int H, int W, hipStream_t s) {
-    hipLaunchKernelGGL(s4_pack_kernel, dim3(1024), dim3(256), 0, s, src, (unsigned short *)dst, B, C, H, W);
+int launch_s4_pack(const float *src, void *dst, int B, int C, int H, int W, unsigned *status, hipStream_t s) {
+    hipLaunchKernelGGL(s4_pack_kernel, dim3(1024), dim3(256), 0, s, src, (unsigned short *)dst, B, C, H, W, status);
     PF_LAUNCH_CHECK("s4_pack_kernel");
     return PF_OK;
 }

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a) {
                 if (co >= a.Cout) continue;
                 float v = acc[r][j][h] + a.bias[co];
                 if (a.relu) v = fmaxf(v, 0.f);
+                range_commit(a.status, fabsf(v));   // conv_mfma.h: range guard of the operand split
                 dst[(size_t)co * opl + (size_t)oy * a.Wout] = v;
             }
         }

@@ -53,13 +53,16 @@ struct pf_plan {
     // (pf_set_option) when the plan is created and read only by forwards of this plan
     int opt_fuse_pool = 1, opt_fuse_upsample = 1, opt_valu_rem = 1, opt_split = 1, opt_use_tuned = 1;
     int opt_table_batch = 0;   // > 0: per-layer kernel choice as if the batch were this (batch-invariant numerics)
+    int opt_range_guard = 1;   // kernels raise PF_STATUS_RANGE in the workspace's status word when they store |v| > 65504 while
+                               // two-term fp16 operands are in use (conv_mfma.h); 0 = no checks (the clamp-free fp32 path needs none)
     int opt_packed_acts = 1;   // tensors whose producers and consumers all support it live in the S4 layout (conv_s4.hip)
     // formats of the last forward (pf_hardnet_tensor_read): 1 = S4
     mutable std::vector<uint8_t> last_fmt;
 };
 
 namespace pf {
-int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_split = 1, g_opt_packed_acts = 1;
+int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_split = 1, g_opt_packed_acts = 1, g_opt_tag_ops = 0;
+int g_opt_range_guard = 1;
 extern int g_opt_use_tuned;
 }
 
@@ -71,6 +74,8 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "valu_remainder")) g_opt_valu_rem = value;
     else if (!strcmp(name, "split_f16") || !strcmp(name, "split_bf16")) g_opt_split = value;   // (round-1 name kept)
     else if (!strcmp(name, "packed_acts")) g_opt_packed_acts = value;
+    else if (!strcmp(name, "range_guard")) g_opt_range_guard = value;
+    else if (!strcmp(name, "profile_tag_ops")) g_opt_tag_ops = value;
     else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);
     return PF_OK;
 }
@@ -83,6 +88,7 @@ extern "C" int pf_hardnet_plan_set_option(pf_plan *p, const char *name, int valu
     else if (!strcmp(name, "valu_remainder")) p->opt_valu_rem = value;
     else if (!strcmp(name, "split_f16") || !strcmp(name, "split_bf16")) p->opt_split = value;
     else if (!strcmp(name, "packed_acts")) p->opt_packed_acts = value;
+    else if (!strcmp(name, "range_guard")) p->opt_range_guard = value;
     else if (!strcmp(name, "table_batch")) p->opt_table_batch = value < 0 ? 0 : value;
     else return fail(PF_EINVAL, "pf_hardnet_plan_set_option: unknown option '%s'", name);
     return PF_OK;
@@ -133,10 +139,12 @@ int propagate_dims(const pf_plan *p, int H, int W, std::vector<Dims> &d) {
     return PF_OK;
 }
 
-// workspace: every tensor except the network input gets its own 256-B aligned region
+// workspace: 256 B of status words (word 0 = PF_STATUS_* bits of the last forward, pfhip.h), then every tensor except the
+// network input in its own 256-B aligned region
+constexpr size_t kStatusBytes = 256;
 int layout(const pf_plan *p, int B, const std::vector<Dims> &d, std::vector<size_t> &off, size_t &total) {
     off.assign(p->tensors.size(), (size_t)-1);
-    size_t cur = 0;
+    size_t cur = kStatusBytes;
     const uint32_t input = p->ops[0].src[0].tensor;
     for (size_t t = 0; t < p->tensors.size(); ++t) {
         if (t == input || d[t].h == 0) continue;
@@ -144,7 +152,7 @@ int layout(const pf_plan *p, int B, const std::vector<Dims> &d, std::vector<size
         // channels padded to whole groups of 4: the same region holds the tensor as fp32 NCHW or in the S4 layout
         cur += align_up((size_t)B * ((p->tensors[t].channels + 3) / 4 * 4) * d[t].h * d[t].w * sizeof(float), 256);
     }
-    total = cur ? cur : 256;
+    total = cur;
     return PF_OK;
 }
 
@@ -163,8 +171,12 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         return t == input ? const_cast<float *>(dense_x) : reinterpret_cast<float *>((char *)ws + off[t]);
     };
 
-    static const bool tag_ops = getenv("PF_PROFILE_OPS") != nullptr;
+    const bool tag_ops = g_opt_tag_ops != 0;      // pf_set_option("profile_tag_ops", 1): per-op labels in pf_profile_* records (tools/)
     const bool fuse = p->opt_fuse_pool != 0;      // option "fuse_pool"
+    // range guard of the two-term operand split (conv_mfma.h): the status word is cleared by every forward; producers of
+    // tensors a split kernel may read raise PF_STATUS_RANGE in it.  fp32-only plans clamp nothing and check nothing
+    PF_HIP_CHECK(hipMemsetAsync(ws, 0, kStatusBytes, s));
+    unsigned *status = (p->opt_split && p->opt_range_guard) ? reinterpret_cast<unsigned *>(ws) : nullptr;
 
     // ---- tensor formats.  The op loop below runs twice: a dry pass records every launch (which tensors it reads and
     // writes, whether its kernel can read / write the S4 layout of conv_s4.hip), the formats are then decided - a tensor is
@@ -216,7 +228,8 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         a.src_begin = 0;
         a.src_end = a.n_src;
         a.acc_scale = 1.0f;
-        static const bool probe_on = getenv("PF_PROBE") != nullptr;
+        a.status = status;
+        static const bool probe_on = ab_env("PF_PROBE") != nullptr;
         a.probe = probe_on ? probe_buffer() : nullptr;
     };
     // need: bit 1 = even tile rows (pooling epilogue), bit 2 = fused stage (not available on the generic path)
@@ -372,7 +385,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                2 * in.h <= out.h + 1 && 2 * in.w <= out.w + 1;   // >= ~2x upsampling: the residual window of a tile stays small
     };
 
-    static const bool sync_ops = getenv("PF_SYNC_OPS") != nullptr;   // debugging: localise a faulting launch
+    static const bool sync_ops = ab_env("PF_SYNC_OPS") != nullptr;   // debugging: localise a faulting launch
     cand[input] = 0;
     for (int pass = 0; pass < 2; ++pass) {
     dry = pass == 0;
@@ -400,11 +413,12 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.w = p->dev_weights + p->conv[i].raw_off;
             a.wdep = p->dev_weights + p->conv[i].dep_off;
             a.woh = p->conv[i].has_oh ? p->dev_weights + p->conv[i].oh_off : nullptr;
-            static const bool stem_probe = getenv("PF_PROBE") != nullptr;     // read once, not per forward
-            static const int stem_plane_pad = getenv("PF_DBG_PLANE_PAD") ? atoi(getenv("PF_DBG_PLANE_PAD")) : 0;
+            static const bool stem_probe = ab_env("PF_PROBE") != nullptr;     // read once, not per forward
+            static const int stem_plane_pad = ab_env("PF_DBG_PLANE_PAD") ? atoi(ab_env("PF_DBG_PLANE_PAD")) : 0;
             a.probe = stem_probe ? probe_buffer() : nullptr;
             a.dbg_plane_pad = stem_plane_pad;
             a.bias = p->dev_weights + p->conv[i].bias_off;
+            a.status = status;
             a.lut = p->dev_lut;
             a.dst = tptr(o.dst);
             a.Hout = out.h;
@@ -417,6 +431,10 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         } else if (o.kind == OP_STEM || o.kind == OP_CONV) {
             if (o.src[0].tensor == input && !dense_x)
                 return fail(PF_EINVAL, "network input is consumed by a generic conv: use pf_hardnet_forward_dense");
+            // a caller-provided dense input has no producer kernel that could have checked its range
+            if (o.src[0].tensor == input && !dry && status &&
+                (rc = launch_range_check(dense_x, (size_t)B * p->tensors[input].channels * in.h * in.w, status, s)))
+                return rc;
             // conv + AvgPool2d(2,2): pool in the conv epilogue, the full-resolution tensor is never written
             const BlobOp *pool = nullptr;
             if (fuse && i + 1 < p->ops.size() && p->ops[i + 1].kind == OP_POOL && o.stride == 1 && o.k == 1 && (in.w & 3) == 0 &&
@@ -545,6 +563,7 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
     pf_plan *p = new pf_plan();
     p->opt_fuse_pool = g_opt_fuse_pool; p->opt_fuse_upsample = g_opt_fuse_upsample; p->opt_valu_rem = g_opt_valu_rem;
     p->opt_split = g_opt_split; p->opt_use_tuned = g_opt_use_tuned; p->opt_packed_acts = g_opt_packed_acts;
+    p->opt_range_guard = g_opt_range_guard;
     p->hdr = h;
     p->tensors.resize(h.n_tensors);
     p->ops.resize(h.n_ops);
@@ -599,8 +618,8 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
         }
         // trailing couts that may run on the vector ALU beside the MFMA tiles (conv_dma.hip); env knobs for A/B runs:
         // PF_VALU_MAX = largest such group (default 8: beyond that the padded MFMA tile measured faster; 0 disables), PF_VALU_PEEL = 1 also peels a full tile of cout % 16 == 0
-        static const int valu_max = getenv("PF_VALU_MAX") ? atoi(getenv("PF_VALU_MAX")) : 8;
-        static const bool valu_peel = getenv("PF_VALU_PEEL") ? atoi(getenv("PF_VALU_PEEL")) != 0 : false;
+        static const int valu_max = ab_env("PF_VALU_MAX") ? atoi(ab_env("PF_VALU_MAX")) : 8;
+        static const bool valu_peel = ab_env("PF_VALU_PEEL") ? atoi(ab_env("PF_VALU_PEEL")) != 0 : false;
         const int split = (o.k == 3 && o.stride == 1) ? dma_valu_split((int)o.cout, valu_peel) : 0;
         if (split > 0 && split <= valu_max) {
             const int kc = dma_kc(3, 1), rv = dma_rem_rv(split);
@@ -760,6 +779,13 @@ extern "C" int pf_hardnet_forward_dense(const pf_plan *p, const float *x, int B,
                    ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" int pf_hardnet_status(const void *ws, unsigned *status, void *stream) {
+    if (!ws || !status) return fail(PF_EINVAL, "pf_hardnet_status: null argument");
+    PF_HIP_CHECK(hipMemcpyAsync(status, ws, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    PF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return PF_OK;
+}
+
 extern "C" int pf_hardnet_tensor_view(const pf_plan *p, const char *name, int B, int H, int W, size_t *ws_offset,
                                       int *channels, int *h, int *w) {
     if (!p || !name || !ws_offset || !channels || !h || !w) return fail(PF_EINVAL, "pf_hardnet_tensor_view: null");
@@ -797,9 +823,9 @@ extern "C" int pf_hardnet_tensor_read(const pf_plan *p, const char *name, int B,
     return PF_OK;
 }
 
-extern "C" int pf_s4_pack(const float *src, void *dst, int B, int C, int H, int W, void *stream) {
+extern "C" int pf_s4_pack(const float *src, void *dst, int B, int C, int H, int W, unsigned *status, void *stream) {
     if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(PF_EINVAL, "pf_s4_pack: bad argument");
-    return launch_s4_pack(src, dst, B, C, H, W, (hipStream_t)stream);
+    return launch_s4_pack(src, dst, B, C, H, W, status, (hipStream_t)stream);
 }
 extern "C" int pf_s4_unpack(const void *src, float *dst, int B, int C, int H, int W, void *stream) {
     if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(PF_EINVAL, "pf_s4_unpack: bad argument");

@@ -18,6 +18,7 @@ struct StemArgs {
     float *dst;            // [B,16,Hout,Wout]
     float depth_mean, depth_std, min_depth, max_depth;
     int seg_is_i64, hop, B, T, n_cls, H, W, Hout, Wout;
+    unsigned *status;      // range guard of the operand split (conv_mfma.h): |output| > 65504 raises PF_STATUS_RANGE; nullable
     long long *probe;      // PF_PROBE builds only
     int dbg_plane_pad;     // timing experiment only (PF_DBG_PLANE_PAD): extra floats between output planes
 };

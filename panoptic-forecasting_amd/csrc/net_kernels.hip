@@ -88,8 +88,13 @@ __global__ __launch_bounds__(256) void stem_onehot_kernel(StemArgs a) {
     }
     const size_t op = (size_t)a.Hout * a.Wout;
     float *o = a.dst + (size_t)b * 16 * op + (size_t)oy * a.Wout + ox;
+    float vmax = 0.f;   // the output is >= 0 after the ReLU: range guard of the operand split (conv_mfma.h)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[i * op] = fmaxf(acc[i], 0.f);
+    for (int i = 0; i < 16; ++i) {
+        o[i * op] = fmaxf(acc[i], 0.f);
+        vmax = fmaxf(vmax, acc[i]);
+    }
+    range_commit(a.status, vmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -176,8 +181,13 @@ __global__ __launch_bounds__(256) void stem_onehot_batched_kernel(StemArgs a) {
     }
     const size_t op = (size_t)a.Hout * a.Wout;
     float *o = a.dst + (size_t)b * 16 * op + (size_t)oy * a.Wout + ox;
+    float vmax = 0.f;   // the output is >= 0 after the ReLU: range guard of the operand split (conv_mfma.h)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[i * op] = fmaxf(acc[i], 0.f);
+    for (int i = 0; i < 16; ++i) {
+        o[i * op] = fmaxf(acc[i], 0.f);
+        vmax = fmaxf(vmax, acc[i]);
+    }
+    range_commit(a.status, vmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -285,11 +295,14 @@ __global__ __launch_bounds__(256) void stem_onehot_v3_kernel(StemArgs a) {
     }
     const size_t op = (size_t)a.Hout * a.Wout;
     float *o = a.dst + (size_t)b * 16 * op + (size_t)oy * a.Wout + ox;
+    float vmax = 0.f;   // range guard of the operand split (conv_mfma.h)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         o[(2 * i) * op] = fmaxf(acc[i].x, 0.f);
         o[(2 * i + 1) * op] = fmaxf(acc[i].y, 0.f);
+        vmax = fmaxf(vmax, fmaxf(acc[i].x, acc[i].y));
     }
+    range_commit(a.status, vmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -418,6 +431,7 @@ __global__ __launch_bounds__(256) void stem_onehot_v4_kernel(StemArgs a, float i
         cur = nxt;
     }
     const size_t op = (size_t)a.Hout * a.Wout;
+    float vmax = 0.f;   // range guard of the operand split (conv_mfma.h): base.1 reads this tensor through conv_split
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
         float *o = a.dst + (size_t)b * 16 * op + (size_t)(oy0 + dy) * a.Wout + ox0;
@@ -425,8 +439,10 @@ __global__ __launch_bounds__(256) void stem_onehot_v4_kernel(StemArgs a, float i
         for (int i = 0; i < 8; ++i) {
             *reinterpret_cast<f32x2v *>(o + (2 * i) * op) = f32x2v{fmaxf(acc[dy][0][i].x, 0.f), fmaxf(acc[dy][1][i].x, 0.f)};
             *reinterpret_cast<f32x2v *>(o + (2 * i + 1) * op) = f32x2v{fmaxf(acc[dy][0][i].y, 0.f), fmaxf(acc[dy][1][i].y, 0.f)};
+            vmax = range_acc(vmax, acc[dy][0][i].x, acc[dy][1][i].x, acc[dy][0][i].y, acc[dy][1][i].y);
         }
     }
+    range_commit(a.status, vmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -790,11 +806,11 @@ int launch_stem(const StemArgs &a, hipStream_t s) {
         return fail(PF_EUNSUPPORTED, "stem: T=%d n_cls=%d weights exceed LDS budget", a.T, a.n_cls);
     const size_t lds = (size_t)a.T * (a.n_cls + 1) * 9 * 16 * sizeof(float);
     const double ipx = (double)a.B * a.T * a.H * a.W, opx = (double)a.B * a.Hout * a.Wout;
-    static const bool generic = getenv("PF_STEM_GENERIC") != nullptr;   // A/B switch for profiling
+    static const bool generic = ab_env("PF_STEM_GENERIC") != nullptr;   // A/B switch for profiling
     const bool batched = a.T == 3 && a.wdep && !generic;
-    static const bool no_v3 = getenv("PF_STEM_BATCHED") != nullptr;       // A/B switch: the previous form
+    static const bool no_v3 = ab_env("PF_STEM_BATCHED") != nullptr;       // A/B switch: the previous form
     const bool v3 = batched && a.woh && !no_v3 && (unsigned long long)a.T * a.H * a.W < (1ull << 32);
-    static const bool no_v4 = getenv("PF_STEM_V3") != nullptr;            // A/B switch: one output per lane
+    static const bool no_v4 = ab_env("PF_STEM_V3") != nullptr;            // A/B switch: one output per lane
     const bool v4 = v3 && !no_v4 && !a.seg_is_i64 && (a.W & 3) == 0 && (a.H & 3) == 0 && a.Wout * 2 == a.W && a.Hout * 2 == a.H;
     const char *label = !batched ? "pf::stem_onehot_kernel(pf::StemArgs)"
                         : v4 ? "pf::stem_onehot_v4_kernel(pf::StemArgs, float)"
@@ -859,7 +875,7 @@ int launch_head(const HeadArgs &a, hipStream_t s) {
     const float sw = a.Wout > 1 ? (float)(a.Win - 1) / (float)(a.Wout - 1) : 0.f;
     const float shh = a.Hout > 1 ? (float)(a.Hin - 1) / (float)(a.Hout - 1) : 0.f;
     const size_t win = ((size_t)(shh * (kHeadCH - 1)) + 3) * ((size_t)(sw * (kHeadCW - 1)) + 3) * 4;   // window bound of one tile, per channel
-    static const bool no_tile = getenv("PF_HEAD_UNTILED") != nullptr;   // A/B switch
+    static const bool no_tile = ab_env("PF_HEAD_UNTILED") != nullptr;   // A/B switch
     if ((a.C == 11 || a.C == 19) && a.Hin >= 2 && a.Win >= 2 && win * a.C <= 60 * 1024 && !no_tile) {
         const dim3 grid((a.Wout + kHeadCW - 1) / kHeadCW, (a.Hout + kHeadCH - 1) / kHeadCH, a.B);
         static bool attr = false;

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/pfhip.h"
 
@@ -25,6 +26,13 @@ int fail(int code, const char *fmt, ...);
         hipError_t _e = hipGetLastError();                                                   \
         if (_e != hipSuccess) return pf::fail(PF_EHIP, "%s: %s", what, hipGetErrorString(_e)); \
     } while (0)
+
+// A/B and debugging switches read from the environment (PF_STEM_V3, PF_SYNC_OPS, PF_PROBE, ...) exist only in libraries
+// built with -DPF_AB=1 (the probe / A-B targets of the Makefile); the shipped libpfhip.so reads no environment variable
+#ifndef PF_AB
+#define PF_AB 0
+#endif
+static inline const char *ab_env(const char *name) { return PF_AB ? getenv(name) : nullptr; }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

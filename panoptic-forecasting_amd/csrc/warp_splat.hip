@@ -749,7 +749,7 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     a.stx = L.stx; a.sty = L.sty; a.dtx = L.dtx; a.dty = L.dty;
     a.probe = nullptr;
 #if PF_PROBE
-    static const bool splat_probe = getenv("PF_PROBE") != nullptr;   // read once, not per call
+    static const bool splat_probe = ab_env("PF_PROBE") != nullptr;   // read once, not per call
     a.probe = splat_probe ? pf::probe_buffer() : nullptr;
 #endif
     hipStream_t s = (hipStream_t)stream;

@@ -25,7 +25,8 @@ def init_distributed_mode(backend=None, device=None):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        # PF_DIST_BACKEND=gloo: several ranks on ONE GPU (tests on a 1-GPU box); RCCL refuses two ranks per device
+        backend = os.environ.get('PF_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(local)
         device = torch.device('cuda', local)
@@ -54,6 +55,27 @@ def gather_accumulators(acc):
     out = torch.empty((world * acc.shape[0],) + tuple(acc.shape[1:]), dtype=acc.dtype, device=acc.device)
     dist.all_gather_into_tensor(out, acc.contiguous())
     return out.view((world,) + tuple(acc.shape))
+
+
+def gather_objects(obj):
+    """obj of every rank, in rank order, on every rank ([obj] for 1 process)."""
+    if not is_dist():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def device_identity(local):
+    """A string that differs between the physical GPUs of a node (uuid when the runtime reports one, else the PCI address);
+    a CPU-only process (gloo dry runs) reports its rank's host slot."""
+    if not torch.cuda.is_available():
+        return 'cpu:%d' % local
+    p = torch.cuda.get_device_properties(local)
+    uuid = getattr(p, 'uuid', None)
+    if uuid is not None and str(uuid).strip('0-') != '':
+        return str(uuid)
+    return 'pci:%s:%s:%s' % (getattr(p, 'pci_domain_id', '?'), getattr(p, 'pci_bus_id', '?'), getattr(p, 'pci_device_id', local))
 
 
 def max_over_ranks(x, device):

@@ -109,6 +109,7 @@ def export_split(model, dataset, split, params, collate_fn):
     name = params.get('export_name') or 'exported_predictions'
     base = os.path.join(working_dir, name, split)
     rank, world, _ = pfdist.env_rank()
+    full_dataset = dataset           # .split / .background_dir live on the dataset, not on the shard view of it
     if world > 1:
         dataset = torch.utils.data.Subset(dataset, pfdist.shard_indices(len(dataset), rank, world))
     tr = params.get('training', {})
@@ -123,6 +124,10 @@ def export_split(model, dataset, split, params, collate_fn):
                                        convert_to_trainid=bool(params.get('convert_to_trainid')),
                                        is_img=bool(params.get('is_img')), save_depth=bool(params.get('save_depth')),
                                        save_depth_as_png=bool(params.get('save_depth_as_png')))
+    # every rank has written its shard before anyone looks for missing frames (export_results :129-165 runs after the
+    # loop of a single process; here the loop is spread over the ranks): one barrier per split, taken by ALL ranks
+    if pfdist.is_dist():
+        torch.distributed.barrier()
     if params.get('is_img'):
         return written
     cs_dir = params.get('data', {}).get('cityscapes_dir')
@@ -130,9 +135,10 @@ def export_split(model, dataset, split, params, collate_fn):
         print('DID NOT RECEIVE CITYSCAPES DIR. SKIPPING.')
         return written
     if rank == 0:
-        gt_dir = os.path.join(cs_dir, 'gtFine', getattr(dataset, 'split', split))
+        gt_dir = os.path.join(cs_dir, 'gtFine', getattr(full_dataset, 'split', split))
         n = hop_io.fill_missing(base, gt_dir, cities=params.get('data', {}).get('cities'),
-                                background_dir=getattr(dataset, 'background_dir', None), no_convert=bool(params.get('no_convert')))
+                                background_dir=getattr(full_dataset, 'background_dir', None),
+                                no_convert=bool(params.get('no_convert')))
         print('NUM MISSING: ', n)
     return written
 

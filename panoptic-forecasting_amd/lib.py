@@ -27,7 +27,8 @@ SIGNATURES = {
     'pf_hardnet_tensor_view': (_i, [_vp, _c.c_char_p, _i, _i, _i, _c.POINTER(_sz), _c.POINTER(_i),
                                     _c.POINTER(_i), _c.POINTER(_i)]),
     'pf_hardnet_tensor_read': (_i, [_vp, _c.c_char_p, _i, _i, _i, _vp, _vp, _vp]),
-    'pf_s4_pack': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'pf_hardnet_status': (_i, [_vp, _c.POINTER(_c.c_uint), _vp]),
+    'pf_s4_pack': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'pf_s4_unpack': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'pf_hardnet_flops': (_i, [_vp, _i, _i, _c.POINTER(_c.c_double)]),
     'pf_hop_export': (_i, [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),

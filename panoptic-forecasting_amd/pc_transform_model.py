@@ -25,7 +25,12 @@ class InverseCache:
     costs a device->host copy = a stream sync; cameras are per-sequence constants, so ``predict`` pays it once per
     (tensor storage, version) and afterwards enqueues without touching the host (include/pfhip.h: calls only enqueue).
     Entries keep the source tensor alive, so a data_ptr can not be recycled for another matrix while it is a key; an
-    in-place edit bumps ``_version`` and misses."""
+    in-place edit bumps ``_version`` and misses.  Writes that bypass the version counter (``K.data.copy_``, a custom kernel
+    or the C library writing into a staging tensor, numpy-aliased memory) are caught by content: an entry also keeps a
+    device clone of the matrix it inverted, and a hit is honoured only if the tensor still equals it - one tiny device
+    comparison whose result is read on the host, still far cheaper than the copy + LAPACK call it replaces.  Under stream
+    capture nothing may synchronise: the content check is skipped there (a captured graph bakes in the inverse of the
+    matrices it was captured with anyway)."""
 
     def __init__(self, capacity=16):
         self.capacity, self._d = capacity, {}
@@ -33,10 +38,14 @@ class InverseCache:
     def __call__(self, m):
         key = (m.data_ptr(), m._version, tuple(m.shape), m.dtype, str(m.device))
         hit = self._d.get(key)
+        capturing = m.is_cuda and torch.cuda.is_current_stream_capturing()
+        if hit is not None and not capturing and not torch.equal(m, hit[2]):
+            hit = None               # same storage, same version, other numbers
         if hit is None:
+            self._d.pop(key, None)
             if len(self._d) >= self.capacity:
                 self._d.pop(next(iter(self._d)))
-            hit = (m, host_inverse(m))
+            hit = (m, host_inverse(m), m.detach().clone())
             self._d[key] = hit
         return hit[1]
 

@@ -196,7 +196,7 @@ def main(argv=None):
         st = torch.load(train_path, map_location='cpu')
         start_epoch, best_val, best_epoch = st['epoch'], st['best_val_result'], st['best_val_epoch']
         trainer.steps = st['step']
-        trainer.momentum_buf.copy_(st['optimizer']['momentum_buffer'])
+        trainer.load_optimizer_state_dict(st['optimizer'])     # torch.optim.SGD's own format (the reference's) or round 2's flat one
     elif params.get('load_model'):
         trainer.load_state_dict(torch.load(params['load_model'], map_location='cpu'))
     else:
@@ -228,7 +228,7 @@ def main(argv=None):
                 best_val, best_epoch = epoch_loss, epoch
                 save_state(best_path, sd)
             save_state(ckpt, sd)
-            save_state(train_path, {'epoch': epoch + 1, 'optimizer': {'momentum_buffer': trainer.momentum_buf.cpu()},
+            save_state(train_path, {'epoch': epoch + 1, 'optimizer': trainer.optimizer_state_dict(),
                                     'best_val_result': best_val, 'best_val_epoch': best_epoch, 'step': trainer.steps})
             print('EPOCH %d EVAL: train loss %.5f acc %.4f lr %.3g  best %.5f @%d  (%.1f s, %d batches/rank)'
                   % (epoch, train_loss, train_acc, lr, best_val, best_epoch, time.time() - t0, n_batches), flush=True)

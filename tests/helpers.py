@@ -78,6 +78,17 @@ class MiniNet:
     def tensor(self, name):
         return view_tensor(self.plan, self.ws, name, *self.bhw)
 
+    def set_option(self, name, value):
+        _lib.check(_lib.load().pf_hardnet_plan_set_option(self.plan, name.encode(), int(value)), 'pf_hardnet_plan_set_option')
+        return self
+
+    def status(self):
+        """status word of the last forward (include/pfhip.h: PF_STATUS_RANGE = 1), through the C entry point"""
+        st = ctypes.c_uint(0xFFFFFFFF)
+        _lib.check(_lib.load().pf_hardnet_status(self.ws.data_ptr(), ctypes.byref(st), _lib.stream_ptr()), 'pf_hardnet_status')
+        assert st.value == int(self.ws[:4].view(torch.int32).item())
+        return st.value
+
     def close(self):
         _lib.load().pf_hardnet_plan_destroy(self.plan)
 

@@ -102,28 +102,35 @@ def test_fp32_mfma_only_option():
     assert errs[1] <= 1e-4, errs
 
 
-@pytest.mark.parametrize('b,split,tol', [(1, 1, 1e-4), (1, 0, 1e-4), (16, 1, 1e-4), (16, 0, 1e-4), (3, 1, 1e-4)],
-                         ids=['B1_split', 'B1_fp32', 'B16_split', 'B16_fp32', 'B3_nearest_row'])
-def test_full_size_timed_configuration_vs_oracle(b, split, tol):
-    """The configuration bench.py times (1024x2048, the B=1 and B=16 rows of csrc/conv_tuned.inc, split kernels on
-    and off) against the oracle pipeline at its own size: logits of the first and the last frame of the batch, argmax
-    agreement and bit-exact warped inputs.  The per-layer kernel choice is keyed on (shape, B), so the small-size tests
-    above never execute these table rows.  B=3 is not a measured batch size: it takes the rows of the nearest one (4)."""
+@pytest.mark.parametrize('b,split,term', [(1, 1, 'short'), (1, 0, 'short'), (2, 1, 'short'), (4, 1, 'short'), (8, 1, 'short'),
+                                          (16, 1, 'short'), (16, 0, 'short'), (3, 1, 'short'), (16, 1, 'mid'), (2, 1, 'mid')],
+                         ids=['B1_split', 'B1_fp32', 'B2_split', 'B4_split', 'B8_split', 'B16_split', 'B16_fp32', 'B3_nearest_row',
+                              'B16_mid_term', 'B2_mid_term'])
+def test_full_size_timed_configuration_vs_oracle(b, split, term):
+    """Every configuration bench.py times (1024x2048; the B = 1, 2, 4, 8, 16 rows of csrc/conv_tuned.inc and
+    conv_s4_tuned.inc - headline sub-batches of 16 and the by_batch legs - split kernels on and off; `mid` = BASELINE
+    configs[2]: gap_len 9 with the predicted-odometry ego chain, pc_transform_dataset.py:156-186) against the oracle
+    pipeline at its own size: logits of the first and the last frame of the batch, argmax agreement and bit-exact warped
+    inputs.  The per-layer kernel choice is keyed on (shape, B), so the small-size tests above never execute these table
+    rows.  B=3 is not a measured batch size: it takes the rows of the nearest one (4)."""
     from panoptic_forecasting_amd import lib as pflib
     from panoptic_forecasting_amd import synth
     from panoptic_forecasting_amd.registry import build_model
     h, w = 1024, 2048
+    tol = 1e-4
+    kw = dict(gap_len=3) if term == 'short' else dict(gap_len=9, predicted=True)
     sd = _sd()
     m = build_model(_params(h, w, return_logits='orig', split_f16=split, emulate_disk_hop=True, seg_is_label_id=True,
                             per_sample_sentinel=True))
     m.load_state_dict(sd)
-    parts = [synth.make_inputs(b=1, h=h, w=w, seed=40 + i, gap_len=3) for i in range(b)]
+    parts = [synth.make_inputs(b=1, h=h, w=w, seed=40 + i, **kw) for i in range(b)]
     inp = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
     pflib.profile(True)
     out = m.predict({k: v.cuda() for k, v in inp.items()}, None)
     labels = [r['label'] for r in pflib.profile_results()]
     pflib.profile(False)
     assert any('conv_split' in l for l in labels) == bool(split), labels
+    assert m.bg.range_reruns == 0 and m.bg.range_status() == 0
     for i in sorted({0, b - 1}):
         ref, seg_w, dep_w = oracle_pipeline(sd, parts[i], h, w)
         assert torch.equal(torch.from_numpy(synth.ID2TRAINID)[out['warped_seg'][i:i + 1].cpu().long()].long(), seg_w)

@@ -326,44 +326,48 @@ def test_split_fused_pool_and_commuted_upsample(h, w, b, nt, fuse_upsample, forc
 
 
 # ---- packed-pair ("S4") activation layout: conv_s4.hip ---------------------------------------------------------------
-def _f16_toward_zero(x):
-    """fp16(x) rounded toward zero, saturating at +-65504 (v_cvt_pkrtz_f16_f32)"""
-    h = x.clamp(-65504.0, 65504.0).to(torch.float16)
-    over = h.float().abs() > x.abs()
-    bits = h.view(torch.int16) - over.to(torch.int16)      # sign-magnitude: one step toward zero
-    return bits.view(torch.float16)
-
-
 def test_s4_layout_round_trip():
-    """pf_s4_pack / pf_s4_unpack: [B][2][ceil(C/4)][H][W][4] fp16, hi = fp16(x), mid = fp16(x - hi), both rounded toward
-    zero and saturating (conv_mfma.h: split_terms2): hi + mid is x to 2^-21 (one subnormal step for tiny |x|) up to
-    |x| = 65504, to one fp16 step of the mid term (32) up to 131008, and clamps beyond."""
-    import ctypes
+    """pf_s4_pack / pf_s4_unpack: [B][2][ceil(C/4)][H][W][4] fp16, hi = fp16(x), mid = fp16(x - hi), both rounded to
+    nearest even (conv_mfma.h: split_terms2; torch's .half() is the same rounding): bit patterns exact, hi + mid is x to
+    2^-23 |x| + 2^-25 for |x| <= 65504 - and a value outside that range raises PF_STATUS_RANGE instead of clamping."""
     from panoptic_forecasting_amd import lib as pflib
     L = pflib.load()
     g = torch.Generator().manual_seed(3)
     b, c, h, w = 2, 10, 6, 8
     x = (torch.randn(b, c, h, w, generator=g) * torch.exp(2 * torch.randn(b, c, 1, 1, generator=g)))
-    x[0, 0, 0, :8] = torch.tensor([0.0, 1e-7, -3e-5, 65504.0, 65519.0, -70000.0, 131000.0, 1e6])
+    x[0, 0, 0, :8] = torch.tensor([0.0, 1e-7, -3e-5, 65504.0, -65504.0, 0.24999999, 1023.4999, 6.1e-5])
+    x[0, 1, 0, :4] = torch.tensor([2049.0, 2051.0, -4098.0, 1.0 + 2.0 ** -11])     # ties of the hi term: to even
     x = x.cuda()
     c4 = (c + 3) // 4
-    packed = torch.zeros(b, 2, c4, h, w, 4, dtype=torch.float16, device='cuda')
-    pflib.check(L.pf_s4_pack(x.data_ptr(), packed.data_ptr(), b, c, h, w, pflib.stream_ptr()), 'pf_s4_pack')
+    status = torch.zeros(1, dtype=torch.int32, device='cuda')
+
+    def pack(src):
+        packed = torch.zeros(b, 2, c4, h, w, 4, dtype=torch.float16, device='cuda')
+        status.zero_()
+        pflib.check(L.pf_s4_pack(src.data_ptr(), packed.data_ptr(), b, c, h, w, status.data_ptr(), pflib.stream_ptr()), 'pf_s4_pack')
+        return packed
+    packed = pack(x)
     back = torch.empty_like(x)
     pflib.check(L.pf_s4_unpack(packed.data_ptr(), back.data_ptr(), b, c, h, w, pflib.stream_ptr()), 'pf_s4_unpack')
     torch.cuda.synchronize()
+    assert status.item() == 0
     xp = torch.zeros(b, c4 * 4, h, w, device='cuda')
     xp[:, :c] = x
-    hi = _f16_toward_zero(xp)
-    mid = _f16_toward_zero(xp - hi.float())
+    hi = xp.half()
+    mid = (xp - hi.float()).half()
     want = torch.stack([hi, mid], 1).view(b, 2, c4, 4, h, w).permute(0, 1, 2, 4, 5, 3).contiguous()
     assert torch.equal(packed.view(torch.int16), want.view(torch.int16))
     assert torch.equal(back, hi.float()[:, :c] + mid.float()[:, :c])
-    exact = x.abs() <= 65504.0
-    inside = x.abs() <= 131008.0
-    assert ((back - x).abs()[exact] <= 2.0 ** -21 * x.abs()[exact] + 2.0 ** -24).all()
-    assert ((back - x).abs()[inside & ~exact] <= 32.0).all()
-    assert torch.equal(back[~inside], torch.sign(x[~inside]) * 131008.0)
+    err = (back.double() - x.double()).abs()
+    assert (err <= 2.0 ** -23 * x.double().abs() + 2.0 ** -25).all(), (err / x.double().abs().clamp_min(1e-30)).max().item()
+    # out of range: the flag, not a clamp
+    for bad in (65505.0, -70000.0, 131000.0, 1e6, float('inf'), float('nan')):
+        y = x.clone()
+        y[1, 3, 2, 5] = bad
+        pack(y)
+        torch.cuda.synchronize()
+        assert status.item() & 1, bad
+    # (65504, 65520) still rounds to 65504 but is flagged all the same: the guard is |x| <= 65504, not "hi is finite"
 
 
 def _block_net(g, cin0):

@@ -1,0 +1,196 @@
+"""Adversarial cases for the two-term fp16 operand path (conv_split / conv_s4; conv_mfma.h) against float64 torch and the
+oracle: activations far outside O(1) must come out right or be FLAGGED (PF_STATUS_RANGE) - never silently clamped - and a
+cancellation-heavy convolution must stay inside the stated operand bound.  The reference is plain fp32 Conv2d
+(hardnet.py:16-25).  Measured errors are written to gpurun_out/r03_precision.json (copied to profiles/)."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+REPORT = os.path.join(ROOT, 'gpurun_out', 'r03_precision.json')
+
+
+def _report(key, value):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    data = {}
+    if os.path.exists(REPORT):
+        with open(REPORT) as f:
+            data = json.load(f)
+    data[key] = value
+    with open(REPORT, 'w') as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+
+
+@pytest.fixture
+def force_conv():
+    from panoptic_forecasting_amd import lib as pflib
+    L = pflib.load()
+    yield lambda kind, p0, p1, p2: pflib.check(L.pf_debug_force_conv(kind, p0, p1, p2), 'pf_debug_force_conv')
+    L.pf_debug_force_conv(0, 0, 0, 0)
+
+
+@pytest.mark.parametrize('force', [(5, 2, 0, 0), (4, 2, 0, 0), None], ids=['conv_s4', 'conv_split', 'table'])
+@pytest.mark.parametrize('scale', [1.0, 1e3, 1e5, 3e7])
+def test_scaled_activations_through_a_hardblock_are_right_or_flagged(scale, force, force_conv):
+    """The HarDBlock-shaped net of test_gpu_conv.py with its input scaled by 1, 1e3, 1e5, 3e7: activations reach ~5e0 ..
+    ~1e8.  Either every tensor agrees with float64 torch to the split tolerance RELATIVE to its magnitude and the status
+    word is clear, or the status word carries PF_STATUS_RANGE; then the same plan with split_f16 = 0 (fp32 matrix
+    instructions, what BGModel re-runs) must be right and unflagged.  A silently clamped result fails both branches."""
+    from helpers import MiniNet
+    from test_gpu_conv import _block_net, _block_ref
+    g = torch.Generator().manual_seed(11)
+    b, h, w = 1, 24, 40
+    x = torch.randn(b, 12, h, w, generator=g) * scale
+    spec, P = _block_net(g, 12)
+    if force:
+        force_conv(*force)
+    ref = _block_ref(x, P, h, w)
+    peak = max(r.abs().max().item() for r in ref.values())
+    net = MiniNet(spec, P).run(x.cuda())
+    flagged = bool(net.status() & 1)
+
+    def check(tag):
+        worst = 0.0
+        for name, k in [('t0', 1), ('L2', 1), ('out', 2), ('p', 2), ('c6', 3), ('c7', 3), ('c8', 3)]:
+            r = ref[name].float()
+            err = (net.tensor(name).cpu() - r).abs().max().item()
+            tol = k * 2e-5 * (1.0 + r.abs().max().item())
+            assert err <= tol, (tag, name, err, tol)
+            worst = max(worst, err / (1.0 + r.abs().max().item()))
+        return worst
+    # (the first conv reads the caller's fp32 input: the dense-input pre-pass has looked at it too)
+    if max(peak, x.abs().max().item()) > 65504.0:
+        assert flagged, 'activations up to %g were not flagged' % peak
+    if scale == 1.0:
+        assert not flagged
+    rel = None
+    if not flagged:
+        rel = check('split')
+    net.set_option('split_f16', 0).run(x.cuda())
+    assert net.status() == 0, 'the fp32-only plan must never raise PF_STATUS_RANGE'
+    rel32 = check('fp32')
+    _report('hardblock_scale_%g_%s' % (scale, 'table' if not force else 'kind%d' % force[0]),
+            {'peak_activation': peak, 'flagged': flagged, 'max_rel_err_split': rel, 'max_rel_err_fp32_rerun': rel32})
+    net.close()
+
+
+def test_range_flag_catches_a_single_outlier_channel(force_conv):
+    """One output channel with a huge bias pushes ONE value per pixel past 65504 in the middle of the block: flagged."""
+    from helpers import MiniNet
+    from test_gpu_conv import _block_net
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(1, 12, 16, 64, generator=g)
+    spec, P = _block_net(g, 12)
+    force_conv(5, 2, 0, 0)
+    net = MiniNet(spec, P).run(x.cuda())
+    assert net.status() == 0
+    net.close()
+    w, bias = P['L2']
+    bias = bias.clone()
+    bias[7] = 7e4
+    P['L2'] = (w, bias)
+    net = MiniNet(spec, P).run(x.cuda())
+    assert net.status() & 1
+    net.close()
+
+
+@pytest.mark.parametrize('k,cin,cout', [(3, 91, 28), (1, 126, 63), (3, 48, 10)])
+def test_cancellation_heavy_conv_on_both_paths(k, cin, cout, force_conv):
+    """sum |w x| >> |sum w x|: every filter sums to zero over its taps and channels and the input is 1000 + noise, so the
+    common mode (sum |terms| ~ 1000 sum|w|) cancels and only the noise term survives.  Errors of the fp16-pair path and of the
+    fp32-MFMA path against float64, both measured in units of sum|w x| (the quantity rounding errors scale with):
+        fp32 path:  <= K 2^-24            (accumulation only; operands exact)
+        pair path:  <= 2^-21 + K 2^-24    (2^-23 per operand, 2^-22 for the dropped mid*mid product, + accumulation)
+    Worst-case bounds; the measured figures (reported) sit one to two orders below and within a small factor of each other."""
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    g = torch.Generator().manual_seed(k * 100 + cin)
+    b, h, w = 1, 32, 64
+    x = 1000.0 + torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g)
+    wt = wt - wt.mean(dim=(1, 2, 3), keepdim=True)
+    wt = (wt.double() - wt.double().mean(dim=(1, 2, 3), keepdim=True)).float()
+    bias = torch.zeros(cout)
+    ref = F.conv2d(x.double(), wt.double(), None, padding=k // 2)
+    mag = F.conv2d(x.double().abs(), wt.double().abs(), None, padding=k // 2)      # sum |w x| per output
+    K = cin * k * k
+    out = {}
+    for name, force, split in [('pair', (5, 2, 0, 0), 1), ('fp32', None, 0)]:
+        spec = MiniSpec(cin)
+        t0 = spec.conv('id', [arch.Src(0, 0, cin)], cin, 1, relu=False)          # identity 1x1: puts x into the packed layout
+        spec.conv('c', [arch.Src(t0, 0, cin)], cout, k, relu=False)
+        eye = torch.eye(cin).view(cin, cin, 1, 1)
+        if force:
+            force_conv(*force)
+        else:
+            force_conv(0, 0, 0, 0)
+        net = MiniNet(spec, {'id': (eye, torch.zeros(cin)), 'c': (wt, bias)})
+        net.set_option('split_f16', split).run(x.cuda())
+        assert net.status() == 0
+        got = net.tensor('c').cpu().double()
+        out[name] = ((got - ref).abs() / mag).max().item()
+        net.close()
+    interior = (ref.abs() / mag).median().item()
+    assert interior < 5e-3, 'the case is not cancellation-heavy: |sum| / sum|.| = %g' % interior
+    _report('cancellation_k%d_cin%d_cout%d' % (k, cin, cout),
+            {'K': K, 'median_|sum|_over_sum|terms|': interior, 'err_over_sum|terms|_pair': out['pair'],
+             'err_over_sum|terms|_fp32': out['fp32'], 'bound_pair': 2.0 ** -21 + K * 2.0 ** -24, 'bound_fp32': K * 2.0 ** -24})
+    assert out['fp32'] <= K * 2.0 ** -24, out
+    assert out['pair'] <= 2.0 ** -21 + K * 2.0 ** -24, out
+    assert out['pair'] <= 2.0 ** -21, out      # in practice the pair path is inside the OPERAND bound alone
+
+
+def _bg_params(h, w, std, **model_kw):
+    p = {'task': 'bg_forecast', 'no_gpu': False, 'load_model': None, 'load_best_model': False,
+         'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([std])],
+                  'min_depth': 0.1, 'max_depth': 200},
+         'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True, 'final_h': h, 'final_w': w,
+                   'return_logits': 'orig'}}
+    p['model'].update(model_kw)
+    return p
+
+
+def test_whole_network_out_of_range_checkpoint_reruns_in_fp32_or_raises():
+    """A checkpoint whose depth normalisation is unusable for fp16 pairs (depth_std = 2e-4: normalised depths of ~1e5-1e6
+    enter the stem, activations of 1e5+ follow) through the fused model: the default policy re-runs the forward on the fp32
+    matrix instructions and returns what the oracle (torch fp32 on the CPU) returns, to the usual tolerance relative to the
+    logits' magnitude; 'raise' fails loudly; a normal checkpoint never re-runs."""
+    import test_gpu_bg_forecast as t
+    from panoptic_forecasting_amd import lib as pflib
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.registry import build_model
+    h, w = 128, 256
+    sd = dict(t._sd())
+    inp = synth.make_inputs(b=1, h=h, w=w, seed=5, gap_len=3)
+    cuda_inp = {k: v.cuda() for k, v in inp.items()}
+    ok = build_model(_bg_params(h, w, 15.0))
+    ok.load_state_dict(sd)
+    ok.predict(cuda_inp, None)
+    assert ok.bg.range_reruns == 0 and ok.bg.range_status() == 0
+
+    sd_bad = dict(sd)
+    sd_bad['depth_std'] = torch.tensor([2e-4])
+    m = build_model(_bg_params(h, w, 2e-4))
+    m.load_state_dict(sd_bad)
+    out = m.predict(cuda_inp, None)
+    assert m.bg.range_reruns == 1
+    ref, _, _ = t.oracle_pipeline(sd_bad, inp, h, w)
+    scale = ref['orig_size_logits'].abs().max().item()
+    err = (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max().item()
+    assert err <= 1e-4 * (1.0 + scale), (err, scale)
+    assert (out['seg'].cpu().long() == ref['seg']).float().mean().item() >= 0.999
+    _report('whole_network_depth_std_2e-4', {'max_abs_logit': scale, 'err_after_fp32_rerun': err, 'reruns': m.bg.range_reruns})
+
+    r = build_model(_bg_params(h, w, 2e-4, on_range_overflow='raise'))
+    r.load_state_dict(sd_bad)
+    with pytest.raises(pflib.PfError, match='65504'):
+        r.predict(cuda_inp, None)
+    i = build_model(_bg_params(h, w, 2e-4, on_range_overflow='ignore'))
+    i.load_state_dict(sd_bad)
+    i.predict(cuda_inp, None)
+    assert i.bg.range_status() & 1 and i.bg.range_reruns == 0

@@ -112,3 +112,38 @@ def test_pretrained_checkpoint_path_matches_reference(tmp_path):
         assert abs(float((v ** 2).sum()) - s2) <= 1e-9 * max(1.0, abs(s2)), k
     assert np.array_equal(sd['model.base.0.conv.weight'].numpy(), g['stem'])
     assert tuple(sd['model.finalConv.weight'].shape) == tuple(g['final_shape'])
+
+
+def test_split_operand_bound():
+    """The operand bound DESIGN.md / conv_mfma.h / bench.py's `dtype` state for the two-term fp16 split
+    (hi = fp16_rne(x), mid = fp16_rne(x - hi); numpy's float16 cast is the same round-to-nearest-even as v_cvt_pk_f16_f32):
+        |x - hi - mid| <= 2^-23 |x|   for 2^-2 <= |x| <= 65504        |x - hi - mid| <= 2^-25   below
+    Every one of the 2^23 significands is tried at the bottom, in the middle and at the top of the range (the bound depends
+    on the significand pattern, and on the exponent only through fp16's subnormal floor), plus a log-uniform sample."""
+    def err(x):
+        hi = x.astype(np.float16)
+        r = x - hi.astype(np.float32)                    # exact in fp32
+        mid = r.astype(np.float16)
+        return np.abs(x.astype(np.float64) - hi.astype(np.float64) - mid.astype(np.float64))
+
+    man = np.arange(1 << 23, dtype=np.uint32)
+    worst_rel = 0.0
+    for e in (-2, 0, 7, 15):
+        x = ((np.uint32(127 + e) << np.uint32(23)) | man).view(np.float32)
+        x = x[x <= 65504.0]
+        rel = (err(x) / x.astype(np.float64)).max()
+        worst_rel = max(worst_rel, rel)
+        assert rel <= 2.0 ** -23, (e, rel)
+    assert worst_rel > 2.0 ** -24          # the bound is tight to within a factor of two: do not quote a better one
+    for e in (-3, -8, -14, -20, -30):      # hi and/or mid in fp16's subnormal range: absolute bound
+        x = ((np.uint32(127 + e) << np.uint32(23)) | man[::8]).view(np.float32)
+        assert err(x).max() <= 2.0 ** -25, e
+    rng = np.random.default_rng(0)
+    x = (np.exp2(rng.uniform(-30, 16, 1 << 22)) * rng.choice([-1.0, 1.0], 1 << 22)).astype(np.float32)
+    x = x[np.abs(x) <= 65504.0]
+    assert (err(x) <= 2.0 ** -23 * np.abs(x.astype(np.float64)) + 2.0 ** -25).all()
+    # the round-2 scheme (both terms toward zero) for comparison: 2^-21
+    # the largest representable magnitude is 65504 itself; 65520 rounds hi to inf, which is why the kernels guard |x| <= 65504
+    with np.errstate(over='ignore'):
+        assert np.isinf(np.float32(65520.0).astype(np.float16))
+    assert np.float32(65519.0).astype(np.float16) == np.float16(65504.0)

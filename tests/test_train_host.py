@@ -58,3 +58,17 @@ def test_flat_gradient_all_reduce_two_gloo_ranks(tmp_path):
                         '--master-port', '29631', str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count('ok') == 2
+
+
+def test_reference_parameter_order_matches_fixture():
+    """bg_train.reference_parameter_order against the reference's own ``model.parameters()`` order, recorded by
+    tests/golden/make_golden_train.py (``keys`` of fixture G6): index i of a torch.optim.SGD state_dict is that order."""
+    import numpy as np
+    from conftest import GOLDEN
+    from panoptic_forecasting_amd import bg_train, hardnet_arch as arch
+    want = [str(k) for k in np.load(os.path.join(GOLDEN, 'g6_train_64x128.npz'))['keys']]
+    layout, _ = bg_train.param_layout(arch.Spec(36, 11))
+    mine = [key for key, _, _, trainable in layout if trainable]
+    assert sorted(mine) == sorted(want)
+    assert mine != want                      # the op-table order differs (conv1x1_up.i before denseBlocksUp.i) ...
+    assert bg_train.reference_parameter_order(mine) == want   # ... the checkpoint order is the reference's

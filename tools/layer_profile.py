@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-op timing of one bg_forecast step (hipEvents via the library's profiling hooks).
 
-    PF_PROFILE_OPS=1 python tools/layer_profile.py [--batch B] [--steps 5]
+    python tools/layer_profile.py [--batch B] [--steps 5]
 """
 import argparse
 import os
@@ -11,7 +11,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault('PF_PROFILE_OPS', '1')
 import bench  # noqa: E402
 from panoptic_forecasting_amd import lib as pflib  # noqa: E402
 from panoptic_forecasting_amd.registry import build_model  # noqa: E402
@@ -32,6 +31,7 @@ batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
 for _ in range(3):
     model.predict(batch, None)
 torch.cuda.synchronize()
+pflib.check(pflib.load().pf_set_option(b'profile_tag_ops', 1), 'pf_set_option')
 pflib.profile(True)
 for _ in range(args.steps):
     model.predict(batch, None)

@@ -11,7 +11,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ['PF_PROFILE_OPS'] = '1'
 import bench  # noqa: E402
 from panoptic_forecasting_amd import lib as pflib  # noqa: E402
 from panoptic_forecasting_amd.registry import build_model  # noqa: E402
@@ -26,6 +25,7 @@ ap.add_argument('--width', type=int, default=bench.W)
 args = ap.parse_args()
 bench.H, bench.W = args.height, args.width
 L = pflib.load()
+pflib.check(L.pf_set_option(b'profile_tag_ops', 1), 'pf_set_option')   # per-op labels in the profile records
 pflib.check(L.pf_set_option(b'use_tuned_table', 0), 'pf_set_option')   # 'auto' = the cost model alone
 model = build_model(bench.model_params())
 model.load_state_dict(bench.calibrated_state_dict())

@@ -11,7 +11,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ['PF_PROFILE_OPS'] = '1'
 import bench  # noqa: E402
 from panoptic_forecasting_amd import lib as pflib  # noqa: E402
 from panoptic_forecasting_amd.registry import build_model  # noqa: E402
@@ -22,6 +21,7 @@ ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--emit', default=None, help='append the conv_s4 winners as C table rows to this .inc file')
 args = ap.parse_args()
 L = pflib.load()
+pflib.check(L.pf_set_option(b'profile_tag_ops', 1), 'pf_set_option')   # per-op labels in the profile records
 model = build_model(bench.model_params())
 model.load_state_dict(bench.calibrated_state_dict())
 batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
