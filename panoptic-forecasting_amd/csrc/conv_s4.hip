@@ -160,9 +160,13 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
     {
         const int ky[2] = {g >> 1, g < 2 ? 2 : g - 2};
         const int kx[2] = {g & 1, g < 2 ? g : 2};
+        // M-tiles come in PAIRS over a 32-pixel row segment: tile 2j = its even pixels, tile 2j+1 = its odd pixels (lane i of
+        // the pair = pixels 2i, 2i+1), so that a lane's two D fragments are two ADJACENT pixels = one 16-B store per term in
+        // the epilogue instead of two 8-B ones (the epilogue is store-issue-bound: 16 % of a workgroup's life).  Bank-wise
+        // the lane stride of 16 B keeps the two lane groups of a ds_read_b64 pass apart exactly as the stride of 8 B did
 #pragma unroll
-        for (int s = 0; s < 2; ++s) aoff[s] = ((wave * 2 + ky[s]) * C::IW + (lane & 15) + kx[s] + 1) * 8;
-        aoff_col = ((wave * 2 + 2) * C::IW + (lane & 15) + 2 + 1) * 8;
+        for (int s = 0; s < 2; ++s) aoff[s] = ((wave * 2 + ky[s]) * C::IW + 2 * (lane & 15) + kx[s] + 1) * 8;
+        aoff_col = ((wave * 2 + 2) * C::IW + 2 * (lane & 15) + 2 + 1) * 8;
     }
 
     // operand roles are swapped with respect to conv_split.hip (weights = A, pixels = B): the D fragment of lane (g, i) is
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
             h = s4_join(*reinterpret_cast<const s4_h4 *>(p), *reinterpret_cast<const s4_h4 *>(p + C::PLANE));
             md = s4_join(*reinterpret_cast<const s4_h4 *>(p + 2 * C::PLANE), *reinterpret_cast<const s4_h4 *>(p + 3 * C::PLANE));
         };
-        auto mtile_off = [&](int mm) { return ((mm / C::MTR) * C::IW + (mm % C::MTR) * 16) * 8; };
+        auto mtile_off = [&](int mm) { return ((mm / C::MTR) * C::IW + ((mm % C::MTR) >> 1) * 32 + (mm & 1)) * 8; };
         // the three products of one block of weights with 4 M-tiles; `slot0` numbers the MFMA groups for the DMA parts
         auto mfmas = [&](const s4_h8 (&wh)[NT], const s4_h8 (&wm)[NT], int m0, const s4_h8 (&fh)[4], const s4_h8 (&fm)[4], int slot0, bool dma) {
 #pragma unroll
@@ -316,60 +320,80 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
     }
     S4_PROBE(58);
 
-    // ---- epilogue: bias + ReLU; lane (g, i) = couts 4g..4g+3 of pixel i: one packed unit per term, or 4 fp32 NCHW elements
+    // ---- epilogue: bias + ReLU; lane (g, i) holds couts 4g..4g+3 of the pixel pair (2i, 2i+1) of every M-tile pair: one
+    //      16-B unit [2 px][4 ch] per term, or fp32 NCHW pairs
     {
         const int g = lane >> 4, px = lane & 15;
         const size_t hw = (size_t)a.Hout * a.Wout;
         const size_t term = (size_t)a.dst_c4 * hw * 8;
         const bool mis = (a.dst_choff & 2) != 0;   // the range starts in the middle of a group (uniform)
         float vmax = 0.f;                          // range guard of the operand split (conv_mfma.h)
+        typedef split_x2 h2;
+        // one pixel's 4 channels (group tails, ranges that start in the middle of a group)
+        auto store_px = [&](int co, size_t pix, s4_f32x4 v) {
+            s4_h4 hi, mid;
+            split_terms4(v, hi, mid);
+            const int chb = a.dst_choff + co;
+            const bool ok0 = chb < a.dst_limit, ok1 = chb + 2 < a.dst_limit;
+            char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
+            if (!mis) {
+                if (ok1) {
+                    *reinterpret_cast<s4_h4 *>(p) = hi;
+                    *reinterpret_cast<s4_h4 *>(p + term) = mid;
+                } else if (ok0) {
+                    *reinterpret_cast<h2 *>(p) = h2{hi[0], hi[1]};
+                    *reinterpret_cast<h2 *>(p + term) = h2{mid[0], mid[1]};
+                }
+            } else {   // upper half of one group, lower half of the next
+                if (ok0) {
+                    *reinterpret_cast<h2 *>(p + 4) = h2{hi[0], hi[1]};
+                    *reinterpret_cast<h2 *>(p + 4 + term) = h2{mid[0], mid[1]};
+                }
+                if (ok1) {
+                    *reinterpret_cast<h2 *>(p + hw * 8) = h2{hi[2], hi[3]};
+                    *reinterpret_cast<h2 *>(p + hw * 8 + term) = h2{mid[2], mid[3]};
+                }
+            }
+        };
 #pragma unroll
-        for (int m = 0; m < C::MP; ++m) {
+        for (int m = 0; m < C::MP; m += 2) {
             const int mt = wave * C::MP + m;
             const int oy = tileY * C::TH + mt / C::MTR;
-            const int ox = tileX * C::TW + (mt % C::MTR) * 16 + px;
+            const int ox = tileX * C::TW + ((mt % C::MTR) >> 1) * 32 + 2 * px;     // even; ox + 1 < Wout (Wout % 4 == 0)
             if (oy >= a.Hout || ox >= a.Wout) continue;
             const size_t pix = (size_t)oy * a.Wout + ox;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int co = (tile0 + n) * 16 + 4 * g;
                 if (co >= a.Cout + 2) continue;                      // nothing of this unit is stored (limit <= Cout + 2)
-                s4_f32x4 v = acc[m][n];
+                s4_f32x4 v0 = acc[m][n], v1 = acc[m + 1][n];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = v[r] * a.acc_scale + bias4[n][r];   // acc_scale = 2^-k of the weight scaling: exact
-                    if (a.relu) v[r] = fmaxf(v[r], 0.f);
-                }
-                vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
-                if (a.dst_fmt) {
-                    s4_h4 hi, mid;
-                    split_terms4(v, hi, mid);
-                    const int chb = a.dst_choff + co;
-                    const bool ok0 = chb < a.dst_limit, ok1 = chb + 2 < a.dst_limit;
-                    char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
-                    typedef split_x2 h2;
-                    if (!mis) {
-                        if (ok1) {
-                            *reinterpret_cast<s4_h4 *>(p) = hi;
-                            *reinterpret_cast<s4_h4 *>(p + term) = mid;
-                        } else if (ok0) {
-                            *reinterpret_cast<h2 *>(p) = h2{hi[0], hi[1]};
-                            *reinterpret_cast<h2 *>(p + term) = h2{mid[0], mid[1]};
-                        }
-                    } else {   // upper half of one group, lower half of the next
-                        if (ok0) {
-                            *reinterpret_cast<h2 *>(p + 4) = h2{hi[0], hi[1]};
-                            *reinterpret_cast<h2 *>(p + 4 + term) = h2{mid[0], mid[1]};
-                        }
-                        if (ok1) {
-                            *reinterpret_cast<h2 *>(p + hw * 8) = h2{hi[2], hi[3]};
-                            *reinterpret_cast<h2 *>(p + hw * 8 + term) = h2{mid[2], mid[3]};
-                        }
+                    v0[r] = v0[r] * a.acc_scale + bias4[n][r];   // acc_scale = 2^-k of the weight scaling: exact
+                    v1[r] = v1[r] * a.acc_scale + bias4[n][r];
+                    if (a.relu) {
+                        v0[r] = fmaxf(v0[r], 0.f);
+                        v1[r] = fmaxf(v1[r], 0.f);
                     }
+                }
+                vmax = range_acc(range_acc(vmax, v0[0], v0[1], v0[2], v0[3]), v1[0], v1[1], v1[2], v1[3]);
+                const int chb = a.dst_choff + co;
+                if (a.dst_fmt && !mis && chb + 2 < a.dst_limit) {
+                    s4_h4 h0, m0, h1, m1;
+                    split_terms4(v0, h0, m0);
+                    split_terms4(v1, h1, m1);
+                    char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
+                    *reinterpret_cast<s4_h8 *>(p) = s4_join(h0, h1);
+                    *reinterpret_cast<s4_h8 *>(p + term) = s4_join(m0, m1);
+                } else if (a.dst_fmt) {
+                    store_px(co, pix, v0);
+                    store_px(co, pix + 1, v1);
                 } else {
+                    typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (co + r < a.Cout) a.dst[((size_t)b * a.dst_ctotal + a.dst_choff + co + r) * hw + pix] = v[r];
+                        if (co + r < a.Cout)
+                            *reinterpret_cast<f2 *>(a.dst + ((size_t)b * a.dst_ctotal + a.dst_choff + co + r) * hw + pix) = f2{v0[r], v1[r]};
                 }
             }
         }

@@ -74,20 +74,23 @@ def _record_grad_distances(tag, hip, aten):
         tag, max(hip.values()), sorted(hip.values())[len(hip) // 2], max(aten.values())))
 
 
-def _oracle_grads(sd, inputs, labels):
+def _oracle_grads(sd, inputs, labels, tag):
     """(fp64 gradients, fp32 result, per-key bar).  The gradient of this 70-layer ReLU network is ill-conditioned in fp32:
     forward round-off (1e-7 after the first layer) grows ~1.3x per layer to 3e-5..1e-4 at the output, every pre-activation
     closer to zero than that flips its ReLU mask between two fp32 implementations, and a flipped element changes the
-    gradient by its full value — relative gradient error ~ sqrt(relative forward error).  The reference's own ATen fp32
-    gradients are 5..8 % (rel. L2) away from the float64 gradients in the encoder at this size.  So the bar per tensor
-    is set by what fp32 can deliver here: 4x the distance fp32-ATen <-> float64, floor 3e-2.  Kernel-level parity
-    (1e-4) is test_mini_network_training_step_vs_autograd."""
+    gradient by its full value - relative gradient error ~ sqrt(relative forward error).  The reference's own ATen fp32
+    gradients are 0.7 % (median) .. 1.5-4 % (worst tensor) away from the float64 gradients at these sizes (rel. L2), and so
+    are the HIP path's (profiles/r03_train_grad_dist.json: HIP median 7.5e-3 / max 1.7e-2, ATen 6.9e-3 / 1.5e-2 at
+    128x256).  The bar per tensor is 1.5x the distance HIP <-> float64 MEASURED on MI355X for that tensor
+    (tests/golden/train_grad_bars.json, floor 1e-4 = the kernel-level bar of test_mini_network_training_step_vs_autograd);
+    the measured distances of every run are printed and written to gpurun_out/r03_train_grad_dist.json."""
     r32 = hardnet_ref.bg_train_step({k: v.clone() for k, v in sd.items()}, inputs, labels, clip_grad_norm=None, apply_update=False)
     sd64 = {k: (v.double() if v.dtype == torch.float32 else v.clone()) for k, v in sd.items()}
     in64 = dict(inputs)
     in64['depth'] = inputs['depth'].double()
     r64 = hardnet_ref.bg_train_step(sd64, in64, labels, clip_grad_norm=None, apply_update=False)
-    bars = {k: max(4 * _rel(r32['grads'][k], g), 3e-2) for k, g in r64['grads'].items()}
+    with open(os.path.join(G, 'train_grad_bars.json')) as f:
+        bars = json.load(f)['bars'][tag]
     return r64['grads'], r32, bars, sd64
 
 
@@ -105,7 +108,7 @@ def test_forward_backward_vs_oracle(size):
     tr = BGTrainer(_params())
     tr.load_state_dict(sd)
     out = tr.forward_backward(_cuda(inputs), _cuda(labels))
-    g64, ref, bars, sd64 = _oracle_grads(sd, inputs, labels)
+    g64, ref, bars, sd64 = _oracle_grads(sd, inputs, labels, '%dx%d' % size)
     assert abs(float(out['loss']) - float(ref['loss'])) <= LOSS_REL * abs(float(ref['loss']))
     assert abs(float(out['accuracy']) - float(ref['accuracy'])) <= 2e-4        # an argmax near-tie may flip a pixel
     got = tr.named_grads()
@@ -126,7 +129,8 @@ def test_forward_backward_vs_oracle(size):
         coef = min(1.0, 5.0 / (z['grad_norm'][0] + 1e-6))
         for name in z.files:
             if name.startswith('grad::'):
-                assert _rel(got[name[6:]].cpu() * coef, torch.from_numpy(z[name])) <= 2 * bars[name[6:]], name
+                # the fixture is the reference's own fp32 (ATen) gradient: two fp32 implementations, each within its bar of float64
+                assert _rel(got[name[6:]].cpu() * coef, torch.from_numpy(z[name])) <= bars[name[6:]] + 1.5 * _rel(ref['grads'][name[6:]], g64[name[6:]]), name
 
 
 def test_two_training_steps_vs_reference_fixture():
@@ -224,10 +228,12 @@ def test_bgmodel_training_loss_is_a_drop_in_for_the_reference_loop():
         if s == 0:
             assert abs(float(total) - z['grad_norm'][0]) <= 0.1 * z['grad_norm'][0]      # see _oracle_grads on conditioning
             grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
-            bars = _oracle_grads(sd, inputs, labels)[2]
+            g64, r32, bars, _ = _oracle_grads(sd, inputs, labels, '64x128')
+            coef = min(1.0, 5.0 / (z['grad_norm'][0] + 1e-6))     # the fixture holds the reference's CLIPPED fp32 gradients
             for name in z.files:
                 if name.startswith('grad::'):
-                    assert _rel(grads[name[6:]].cpu(), torch.from_numpy(z[name])) <= 2 * bars[name[6:]], name
+                    k = name[6:]
+                    assert _rel(grads[k].cpu(), torch.from_numpy(z[name])) <= bars[k] + 1.5 * _rel(r32['grads'][k], g64[k]), name
         opt.step()
         opt.zero_grad()
         ref = hardnet_ref.bg_train_step(osd, inputs, labels, momentum_bufs=bufs)

@@ -11,6 +11,8 @@ export TMPDIR=/tmp
 # one sub-batch (16 frames) on one stream: the launches bench.py times for its roofline line; the headline runs 2 of
 # these concurrently on 2 streams inside one hipGraph
 BENCH="python $REPO/bench.py --batch 16 --streams 1 --steps 10 --warmup 3 --replays 1 --no-cpu-baseline --no-legs --no-graph --profile-steps 1 $*"
+python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.source_sha())" > "$OUT/source_sha.txt" 2>/dev/null
+echo "$BENCH" | sed "s#$REPO/##g" > "$OUT/bench_cmd.txt"
 cd /tmp
 # 1. kernel trace + stats (timing)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BENCH > "$OUT/bench_trace.log" 2>"$OUT/trace.err"

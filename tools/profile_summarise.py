@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Turn gpurun_out/<tag>/ (tools/profile_gpu.sh) into the committed summaries under profiles/.
 
-    python tools/profile_summarise.py <tag> <round-prefix>      e.g.  r1c r01_c
+    python tools/profile_summarise.py <tag> <round-prefix> [--no-latest]     e.g.  r1c r01_c
+
+The hash of the kernel sources the numbers were measured on comes from gpurun_out/<tag>/source_sha.txt (written on the GPU
+box by tools/profile_gpu.sh); without that file the current tree is hashed.  --no-latest: do not refresh pmc_latest.json
+(side legs such as --fp32-mfma-only).
 
 Writes profiles/<prefix>_kernel_stats.txt (per-kernel calls/avg ns from the kernel trace) and
 profiles/<prefix>_pmc.json (per-kernel HBM traffic per launch from FETCH_SIZE / WRITE_SIZE, raw and
@@ -43,7 +47,7 @@ def counters(d):
     return agg
 
 
-def main(tag, prefix):
+def main(tag, prefix, latest=True):
     src = os.path.join(ROOT, 'gpurun_out', tag)
     dst = os.path.join(ROOT, 'profiles')
     ks = kernel_stats(os.path.join(src, 'trace'))
@@ -54,14 +58,16 @@ def main(tag, prefix):
     except Exception:
         pass
     with open(os.path.join(dst, prefix + '_kernel_stats.txt'), 'w') as f:
-        f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph\n')
+        f.write('# rocprofv3 --kernel-trace --stats -- %s\n' % (open(os.path.join(src, 'bench_cmd.txt')).read().strip() if os.path.exists(os.path.join(src, 'bench_cmd.txt')) else 'python bench.py --batch 16 --streams 1 --steps 10 --warmup 3 --replays 1 --no-cpu-baseline --no-legs --no-graph --profile-steps 1'))
         f.write('# bench line of that run: %s\n' % bench_line)
         f.write('%-90s %7s %12s %11s %11s %11s %6s\n' % ('kernel', 'calls', 'total_ns', 'avg_ns', 'min_ns', 'max_ns', '%'))
         for k, (c, tot, avg, mn, mx) in sorted(ks.items(), key=lambda kv: -kv[1][1]):
             f.write('%-90s %7d %12d %11.0f %11d %11d %6.2f\n' % (k[:90], c, tot, avg, mn, mx, 100.0 * tot / total))
     sys.path.insert(0, ROOT)
     import bench as _bench
-    out = {'source_sha': _bench.source_sha(),
+    sha_file = os.path.join(src, 'source_sha.txt')
+    sha = open(sha_file).read().strip() if os.path.exists(sha_file) else _bench.source_sha()
+    out = {'source_sha': sha,
            'note': 'per-launch averages; FETCH_SIZE/WRITE_SIZE are reported by rocprofv3 in KiB-like units and are '
                    'calibrated here on a 256 MiB copy kernel run under the same counter (factor = known bytes / raw)',
            'kernels': {}}
@@ -106,11 +112,11 @@ def main(tag, prefix):
         # MFMA pipe utilisation: busy cycles summed over the 1024 SIMDs / (per-XCD active cycles summed over 8 XCDs / 8)
         if e.get('GRBM_GUI_ACTIVE') and 'SQ_VALU_MFMA_BUSY_CYCLES' in e:
             e['mfma_util'] = e['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * e['GRBM_GUI_ACTIVE'] / 8.0)
-    for name in (prefix + '_pmc.json', 'pmc_latest.json'):
+    for name in ((prefix + '_pmc.json', 'pmc_latest.json') if latest else (prefix + '_pmc.json',)):
         with open(os.path.join(dst, name), 'w') as f:
             json.dump(out, f, indent=1, sort_keys=True)
     print('wrote', prefix + '_kernel_stats.txt', prefix + '_pmc.json')
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], latest='--no-latest' not in sys.argv[3:])
