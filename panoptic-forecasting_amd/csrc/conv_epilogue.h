@@ -201,11 +201,12 @@ __device__ __forceinline__ void epi_store(const ConvArgs &a, int b, int co, int 
     }
     float *p = a.dst + ((size_t)b * a.dst_ctotal + a.dst_choff + co) * ((size_t)a.Hout * a.Wout) + (size_t)oy * a.Wout + ox;
     if ((a.Wout & 3) == 0 && ox + 3 < a.Wout) {
+        if (a.accum) v += *reinterpret_cast<const epi_f32x4 *>(p);   // training: the gradient of a tensor collects all its consumers'
         *reinterpret_cast<epi_f32x4 *>(p) = v;
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (ox + r < a.Wout) p[r] = v[r];
+            if (ox + r < a.Wout) p[r] = a.accum ? p[r] + v[r] : v[r];
     }
 }
 

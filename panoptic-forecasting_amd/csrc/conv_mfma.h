@@ -44,7 +44,8 @@ struct ConvArgs {
     long long *probe;        // PF_PROBE builds only: in-kernel timestamps of workgroup 0 / wave 0 (else nullptr)
     unsigned *status;        // range guard of the two-term operand split (below): word 0 of the forward's workspace, or
                              // nullptr (fp32-only plans, training): epilogues OR PF_STATUS_RANGE into it when they store |v| > 65504
-    int accum;               // generic kernel (conv_mfma.hip) only: dst += result (gradient accumulation of the training path)
+    int accum;               // fp32 NCHW stores of conv_mfma.hip and of epi_store (conv_dma / conv_wave): dst += result (gradient
+                             // accumulation of the training path); not combined with rem / pool / S4 destinations
     float acc_scale;         // split kernels (conv_split.hip, conv_s4.hip) only: their weights are packed as fp16 terms of
                              // w * 2^k (k per conv, split_weight_scale()); the raw sums are multiplied by 2^-k (exact)
     // ---- packed-pair ("S4") activation layout, conv_s4.hip: a tensor of C channels is stored as

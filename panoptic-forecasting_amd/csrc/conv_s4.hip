@@ -43,6 +43,9 @@
 #define S4_PROBE(i) do { } while (0)
 #endif
 
+#ifndef S4_PAIRED      // 1: M-tile pairs = even / odd pixels of a 32-pixel segment, 16-B epilogue stores; 0: 16 consecutive pixels, 8-B stores (A/B)
+#define S4_PAIRED 0
+#endif
 #ifndef S4_ISSUE_FIRST
 #define S4_ISSUE_FIRST 1
 #define S4_ISSUE_STEP 2
@@ -103,7 +106,8 @@ struct S4Cfg {
     static constexpr int BPT = COLREG ? 2 : 3;                            // blocks per cout tile in LDS: instr 0, instr 1[, collected tap]
     static constexpr int WBUF = NT * BPT * WBLK;                          // [nt][block][term][lane]
     static constexpr int WPIECES = WBUF / 16, NITW = (WPIECES + 255) / 256;
-    static constexpr size_t LDS_BYTES = 2 * (size_t)ABUF + 2 * (size_t)WBUF;
+    static constexpr size_t STAGES_BYTES = 2 * (size_t)ABUF + 2 * (size_t)WBUF;
+    static constexpr size_t LDS_BYTES = STAGES_BYTES + NT * 16 * sizeof(float);   // + the bias values of the workgroup's couts
 };
 
 // weight blocks in front of round r (2 per round + one collected-tap block per started group of 4 rounds before it)
@@ -165,17 +169,21 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
         // the epilogue instead of two 8-B ones (the epilogue is store-issue-bound: 16 % of a workgroup's life).  Bank-wise
         // the lane stride of 16 B keeps the two lane groups of a ds_read_b64 pass apart exactly as the stride of 8 B did
 #pragma unroll
-        for (int s = 0; s < 2; ++s) aoff[s] = ((wave * 2 + ky[s]) * C::IW + 2 * (lane & 15) + kx[s] + 1) * 8;
-        aoff_col = ((wave * 2 + 2) * C::IW + 2 * (lane & 15) + 2 + 1) * 8;
+        for (int s = 0; s < 2; ++s) aoff[s] = ((wave * 2 + ky[s]) * C::IW + (S4_PAIRED ? 2 : 1) * (lane & 15) + kx[s] + 1) * 8;
+        aoff_col = ((wave * 2 + 2) * C::IW + (S4_PAIRED ? 2 : 1) * (lane & 15) + 2 + 1) * 8;
     }
 
     // operand roles are swapped with respect to conv_split.hip (weights = A, pixels = B): the D fragment of lane (g, i) is
-    // couts 4g .. 4g+3 of pixel i = one 8-B unit of the packed layout per term, no cross-lane traffic in the epilogue
-    s4_f32x4 bias4[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias4[n][r] = epi_bias(a, (tile0 + n) * 16 + g * 4 + r);
+    // couts 4g .. 4g+3 of a pixel = one 8-B unit of the packed layout per term, no cross-lane traffic in the epilogue.
+    // The bias values of the workgroup's couts go to LDS by DMA now (4 B per lane, zero for couts past the layer) and are
+    // read back in the epilogue: kept in registers across the main loop they cost NT * 4 registers (spilled at NT = 2, 3),
+    // and either way the epilogue had to wait for them with vmcnt - which on gfx950 also waits for the epilogue's own stores
+    float *bias_lds = reinterpret_cast<float *>(smem_raw + C::STAGES_BYTES);
+    if (wave == 0 && lane < NT * 16) {
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias, 0, 0x7FFFFFFF, 0x00020000);
+        const int co = tile0 * 16 + lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (s4_lds_ptr_t)bias_lds, 4, co < a.ntiles * 16 ? (unsigned)co * 4u : kS4Oob, 0, 0, 0);
+    }
 
     const int nrounds = a.nchunks;   // 3x3 launches always run the whole K range (the collected tap spans 4 rounds)
     // The DMA instructions of the next stage go out between the matrix groups of the current one (a part = one activation
@@ -239,7 +247,9 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
             h = s4_join(*reinterpret_cast<const s4_h4 *>(p), *reinterpret_cast<const s4_h4 *>(p + C::PLANE));
             md = s4_join(*reinterpret_cast<const s4_h4 *>(p + 2 * C::PLANE), *reinterpret_cast<const s4_h4 *>(p + 3 * C::PLANE));
         };
-        auto mtile_off = [&](int mm) { return ((mm / C::MTR) * C::IW + ((mm % C::MTR) >> 1) * 32 + (mm & 1)) * 8; };
+        auto mtile_off = [&](int mm) {
+            return S4_PAIRED ? ((mm / C::MTR) * C::IW + ((mm % C::MTR) >> 1) * 32 + (mm & 1)) * 8 : ((mm / C::MTR) * C::IW + (mm % C::MTR) * 16) * 8;
+        };
         // the three products of one block of weights with 4 M-tiles; `slot0` numbers the MFMA groups for the DMA parts
         auto mfmas = [&](const s4_h8 (&wh)[NT], const s4_h8 (&wm)[NT], int m0, const s4_h8 (&fh)[4], const s4_h8 (&fm)[4], int slot0, bool dma) {
 #pragma unroll
@@ -323,6 +333,12 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
     // ---- epilogue: bias + ReLU; lane (g, i) holds couts 4g..4g+3 of the pixel pair (2i, 2i+1) of every M-tile pair: one
     //      16-B unit [2 px][4 ch] per term, or fp32 NCHW pairs
     {
+        // Nothing in flight may be left for the compiler's wait-count pass to protect inside the store loop below: the main
+        // loop's waits are inline asm (invisible to the pass), so a register it believes pending - a scratch reload, a value
+        // loaded before the loop - got an s_waitcnt vmcnt(0) in EVERY iteration of that loop, and on gfx950 stores count in
+        // vmcnt: each unit then sat through the store round trips of the unit before it (tools/asm_store_waits.py lists the
+        // kernels that wait for their own stores).  One wait the pass can see, here:
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt / lgkmcnt untouched
         const int g = lane >> 4, px = lane & 15;
         const size_t hw = (size_t)a.Hout * a.Wout;
         const size_t term = (size_t)a.dst_c4 * hw * 8;
@@ -355,6 +371,36 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
                 }
             }
         };
+#if !S4_PAIRED
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m) {
+            const int mt = wave * C::MP + m;
+            const int oy = tileY * C::TH + mt / C::MTR;
+            const int ox = tileX * C::TW + (mt % C::MTR) * 16 + px;
+            if (oy >= a.Hout || ox >= a.Wout) continue;
+            const size_t pix = (size_t)oy * a.Wout + ox;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = (tile0 + n) * 16 + 4 * g;
+                if (co >= a.Cout + 2) continue;
+                s4_f32x4 v = acc[m][n];
+                const s4_f32x4 b4 = *reinterpret_cast<const s4_f32x4 *>(bias_lds + n * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = v[r] * a.acc_scale + b4[r];
+                    if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                }
+                vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
+                if (a.dst_fmt) {
+                    store_px(co, pix, v);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < a.Cout) a.dst[((size_t)b * a.dst_ctotal + a.dst_choff + co + r) * hw + pix] = v[r];
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int m = 0; m < C::MP; m += 2) {
             const int mt = wave * C::MP + m;
@@ -367,10 +413,11 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
                 const int co = (tile0 + n) * 16 + 4 * g;
                 if (co >= a.Cout + 2) continue;                      // nothing of this unit is stored (limit <= Cout + 2)
                 s4_f32x4 v0 = acc[m][n], v1 = acc[m + 1][n];
+                const s4_f32x4 b4 = *reinterpret_cast<const s4_f32x4 *>(bias_lds + n * 16 + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v0[r] = v0[r] * a.acc_scale + bias4[n][r];   // acc_scale = 2^-k of the weight scaling: exact
-                    v1[r] = v1[r] * a.acc_scale + bias4[n][r];
+                    v0[r] = v0[r] * a.acc_scale + b4[r];   // acc_scale = 2^-k of the weight scaling: exact
+                    v1[r] = v1[r] * a.acc_scale + b4[r];
                     if (a.relu) {
                         v0[r] = fmaxf(v0[r], 0.f);
                         v1[r] = fmaxf(v1[r], 0.f);
@@ -397,6 +444,7 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
                 }
             }
         }
+#endif
         range_commit(a.status, vmax);
     }
     S4_PROBE(59);
@@ -439,7 +487,8 @@ template <int NT>
 struct S41Cfg {
     static constexpr int TW = 32, TH = 8, MP = 4;
     static constexpr int WBUF = NT * 2 * 64 * 16;                   // [nt][term][lane][8 fp16]
-    static constexpr int MAIN = 2 * WBUF;
+    static constexpr int BIAS_OFF = 2 * WBUF;                       // the workgroup's bias values (DMA, read in the epilogue)
+    static constexpr int MAIN = 2 * WBUF + 256;
     static constexpr int WPIECES = WBUF / 16, NITW = (WPIECES + 255) / 256;
 };
 
@@ -484,12 +533,15 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
     }
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wpk, 0, 0x7FFFFFFF, 0x00020000);
 
-    // operand roles swapped (weights = A, pixels = B): lane (g, i) ends up with couts 4g..4g+3 of the pixel pair (2i, 2i+1)
-    s4_f32x4 bias4[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias4[n][r] = epi_bias(a, (tile0 + n) * 16 + g * 4 + r);
+    // operand roles swapped (weights = A, pixels = B): lane (g, i) ends up with couts 4g..4g+3 of the pixel pair (2i, 2i+1).
+    // Bias values through LDS (see conv_s4_kernel); zero for the low-resolution half of a commuted upsample (no_bias)
+    float *bias_lds = reinterpret_cast<float *>(smem_raw + C::BIAS_OFF);
+    if (wave == 0 && lane < NT * 16) {
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias, 0, 0x7FFFFFFF, 0x00020000);
+        const int co = tile0 * 16 + lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (s4_lds_ptr_t)bias_lds, 4, (!a.no_bias && co < a.ntiles * 16) ? (unsigned)co * 4u : kS4Oob, 0,
+                                                 0, 0);
+    }
 
     const int cb = a.chunk_begin, nrounds = a.chunk_end - cb;
     // fragments of one round: [row][entry of the pair][term], each 16 B = 2 pixels x 4 channels
@@ -605,6 +657,7 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
         __syncthreads();   // every wave's pieces of the residual window have landed
     }
     {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) the compiler can see: no waits for loads inside the store loop (conv_s4_kernel)
         const lds_float *res_lds = (const lds_float *)(reinterpret_cast<float *>(smem_raw) + (has_res ? a.res_lds_off : 0));
         const int i2 = 2 * (lane & 15);
         const int ox = tileX * C::TW + i2;
@@ -617,9 +670,10 @@ __global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
         // finished values of pixel (rr, q), cout tile n
         auto finish = [&](int rr, int q, int n, const int (&o0)[2], const int (&o1)[2], const float (&lx1)[2], float hy1) {
             s4_f32x4 v = acc[rr * 2 + q][n];
+            const s4_f32x4 b4 = *reinterpret_cast<const s4_f32x4 *>(bias_lds + n * 16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] = v[r] * a.acc_scale + bias4[n][r];   // acc_scale = 2^-k of the weight scaling: exact
+                v[r] = v[r] * a.acc_scale + b4[r];   // acc_scale = 2^-k of the weight scaling: exact
                 if (has_res) {   // same arithmetic as res_apply (conv_epilogue.h)
                     const lds_float *chan = res_lds + (n * 16 + 4 * g + r) * rw.cs;
                     const float lx0 = 1.f - lx1[q], hy0 = 1.f - hy1;

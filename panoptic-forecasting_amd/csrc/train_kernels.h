@@ -10,6 +10,11 @@ int launch_onehot_dense(const void *seg, int seg_i64, const float *depth, const 
 // weights of forward input range [c0, c0 + ch)
 int launch_pack_weights(const float *w, int cin_f, int cout_f, const ConvTiling &t, int transpose_flip, int c0, int ch, float *out,
                         hipStream_t s);
+// ... -> the per-tile order of the LDS-DMA kernels (conv_dma.hip): src_ch[n_src] = the conv's input ranges (forward), or
+// {forward cout} with transpose_flip (backward-data of forward input range [c0, c0 + ch): a ch-output, cout_f-input conv)
+size_t tiled_packed_floats(const int *src_ch, int n_src, int cout, int ks, int stride);
+int launch_pack_weights_tiled(const float *w, int cin_f, int cout_f, int ks, int stride, const int *src_ch, int n_src, int transpose_flip,
+                              int c0, int ch, float *out, hipStream_t s);
 size_t bn_partial_doubles(int C);
 int launch_bn_forward(const float *y, int B, int C, int H, int W, float eps, float momentum, const float *gamma, const float *beta,
                       float *running_mean, float *running_var, float *mean, float *invstd, double *partial, float *dst, int dst_ctotal,
@@ -17,11 +22,16 @@ int launch_bn_forward(const float *y, int B, int C, int H, int W, float eps, flo
 int launch_bn_backward(const float *g, const float *z, int t_ctotal, int choff, const float *y, const float *mean, const float *invstd,
                        const float *gamma, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial, float *sums,
                        float *dy, hipStream_t s);
-int launch_bias_backward(const float *g, int t_ctotal, int choff, int B, int C, int H, int W, float *dbias, float *dy, hipStream_t s);
-int wgrad_slabs(int cout, int cin, int B, int Hout);
-size_t wgrad_partial_floats(int cout, int cin, int ks, int B, int Hout);
+int launch_bias_backward(const float *g, int t_ctotal, int choff, int B, int C, int H, int W, float *dbias, double *partial /* bn_partial_doubles(C) */,
+                         float *dy, hipStream_t s);
+int wgrad_slabs(int cout, int cin, int B, int Hout, int Win, int Wout);
+size_t wgrad_partial_floats(int cout, int cin, int ks, int B, int Hout, int Win, int Wout);
 // a: the forward conv's arguments (sources, Cin/Cout, Hin/Win/Hout/Wout); dw (OIHW) accumulates
 int launch_wgrad(const ConvArgs &a, int ks, int stride, const float *dy, int B, float *partial, float *dw, hipStream_t s);
+// odd-width convs on copies with a row pitch rounded up to 4 (train_kernels.hip): all input ranges of `a` -> [B][Cin][Hin][Wp];
+// [B][C][H][Wp] -> channels [dst_choff, dst_choff + C) of a [B][dst_ctotal][H][W] tensor
+int launch_pad_gather(const ConvArgs &a, int B, int Wp, float *dst, hipStream_t s);
+int launch_unpad_scatter(const float *src, int B, int C, int H, int W, int Wp, float *dst, int dst_ctotal, int dst_choff, int accum, hipStream_t s);
 int launch_zero_stuff(const float *dy, int planes, int Hout, int Wout, int Hin, int Win, float *up, hipStream_t s);
 int launch_avgpool2_bwd(const float *gout, int planes, int Hin, int Win, float *gin, hipStream_t s);
 // gin (+)= bilinear^T(gout) [* scale / *count when count != nullptr]

@@ -89,6 +89,60 @@ int launch_pack_weights(const float *w, int cin_f, int cout_f, const ConvTiling 
     return PF_OK;
 }
 
+// OIHW -> the per-tile order of the LDS-DMA kernels (conv_dma.hip::pack_conv_weights_tiled: [cout tile][chunk][kgroup][tap][64 lanes],
+// K order = the input ranges in order, each padded to whole chunks of kc channels).  Same two modes as above; the
+// backward-data convolution has ONE input range (the forward cout channels of dy).
+struct TiledPackArgs {
+    int cstart[kConvMaxSrc + 1];   // first conv input channel of each range ([n_src] = cin)
+    int chunk0[kConvMaxSrc + 1];   // first chunk of each range ([n_src] = nchunks)
+    int n_src;
+};
+__global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const float *w, int cin_f, int cout_f, int ks2, int kc, TiledPackArgs pa,
+                                                                 long long total, int transpose_flip, int c0, int ch, float *out) {
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int nchunks = pa.chunk0[pa.n_src];
+    long long r = o;
+    const int lane = (int)(r % 64); r /= 64;
+    const int tap = (int)(r % ks2); r /= ks2;
+    const int kg = (int)(r % (kc / 4)); r /= (kc / 4);
+    const int chunk = (int)(r % nchunks); r /= nchunks;
+    const int t = (int)r;
+    int j = 0;
+    while (j + 1 < pa.n_src && chunk >= pa.chunk0[j + 1]) ++j;
+    const int cl = (chunk - pa.chunk0[j]) * kc + kg * 4 + (lane >> 4), nch = pa.cstart[j + 1] - pa.cstart[j];
+    const int co = t * 16 + (lane & 15), ci = pa.cstart[j] + cl;
+    float v = 0.f;
+    if (cl < nch) {
+        if (!transpose_flip) {
+            if (co < cout_f) v = w[((long long)co * cin_f + ci) * ks2 + tap];
+        } else {
+            if (co < ch) v = w[((long long)ci * cin_f + c0 + co) * ks2 + (ks2 - 1 - tap)];   // ci runs over the forward cout
+        }
+    }
+    out[o] = v;
+}
+size_t tiled_packed_floats(const int *src_ch, int n_src, int cout, int ks, int stride) {
+    return (size_t)((cout + 15) / 16) * dma_chunks(src_ch, n_src, ks, stride) * (dma_kc(ks, stride) / 4) * ks * ks * 64;
+}
+int launch_pack_weights_tiled(const float *w, int cin_f, int cout_f, int ks, int stride, const int *src_ch, int n_src, int transpose_flip,
+                              int c0, int ch, float *out, hipStream_t s) {
+    TiledPackArgs pa;
+    const int kc = dma_kc(ks, stride);
+    pa.n_src = n_src;
+    pa.cstart[0] = 0;
+    pa.chunk0[0] = 0;
+    for (int j = 0; j < kConvMaxSrc; ++j) {
+        pa.cstart[j + 1] = pa.cstart[j] + (j < n_src ? src_ch[j] : 0);
+        pa.chunk0[j + 1] = pa.chunk0[j] + (j < n_src ? (src_ch[j] + kc - 1) / kc : 0);
+    }
+    const long long total = (long long)tiled_packed_floats(src_ch, n_src, transpose_flip ? ch : cout_f, ks, stride);
+    hipLaunchKernelGGL(pack_weights_tiled_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, cin_f, cout_f, ks * ks, kc, pa, total,
+                       transpose_flip, c0, ch, out);
+    PF_LAUNCH_CHECK("pack_weights_tiled_kernel");
+    return PF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm (training mode)
 // partial[c][slab][k]: k = 0 sum(y), 1 sum(y^2)  (stats)   or   0 sum(g'), 1 sum(g' * xhat)  (backward)
 constexpr int kBnSlabs = 64;
@@ -152,15 +206,107 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *y, cons
         }
 }
 
+// ---- the same four passes with 16-B accesses and no per-element index division (planes of HW % 4 == 0 elements): a block
+// walks the planes of its channel sample by sample, a thread adds its four values in fp32 and accumulates those in fp64
+__global__ __launch_bounds__(256) void bn_stats_partial4_kernel(const float *y, int B, int C, int HW4, double *partial) {
+    const int c = blockIdx.x, slab = blockIdx.y;
+    __shared__ double sm[2 * 4];
+    double v[2] = {0.0, 0.0};
+    for (int b = 0; b < B; ++b) {
+        const tr_f32x4 *p = reinterpret_cast<const tr_f32x4 *>(y) + ((long long)b * C + c) * HW4;
+        for (int i = slab * 256 + threadIdx.x; i < HW4; i += kBnSlabs * 256) {
+            const tr_f32x4 x = p[i];
+            v[0] += (double)((x[0] + x[1]) + (x[2] + x[3]));
+            v[1] += (double)((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]));
+        }
+    }
+    block_reduce_d<2>(v, sm);
+    if (threadIdx.x == 0) {
+        partial[((long long)c * kBnSlabs + slab) * 2 + 0] = v[0];
+        partial[((long long)c * kBnSlabs + slab) * 2 + 1] = v[1];
+    }
+}
+__global__ __launch_bounds__(256) void bn_apply_relu4_kernel(const float *y, const float *mean, const float *invstd, const float *gamma,
+                                                             const float *beta, int C, int HW4, float *dst, int dst_ctotal, int dst_choff, int relu) {
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW4) return;
+    const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+    tr_f32x4 v = reinterpret_cast<const tr_f32x4 *>(y)[(long long)bc * HW4 + i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = v[k] * sc + sh;
+        if (relu) v[k] = fmaxf(v[k], 0.f);
+    }
+    reinterpret_cast<tr_f32x4 *>(dst)[((long long)b * dst_ctotal + dst_choff + c) * HW4 + i] = v;
+}
+__global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
+                                                              const float *mean, const float *invstd, int B, int C, int HW4, int relu,
+                                                              double *partial) {
+    const int c = blockIdx.x, slab = blockIdx.y;
+    __shared__ double sm[2 * 4];
+    double v[2] = {0.0, 0.0};
+    const float mu = mean[c], is = invstd[c];
+    for (int b = 0; b < B; ++b) {
+        const long long ti = ((long long)b * t_ctotal + choff + c) * HW4, yi = ((long long)b * C + c) * HW4;
+        for (int i = slab * 256 + threadIdx.x; i < HW4; i += kBnSlabs * 256) {
+            const tr_f32x4 g4 = reinterpret_cast<const tr_f32x4 *>(g)[ti + i], y4 = reinterpret_cast<const tr_f32x4 *>(y)[yi + i];
+            tr_f32x4 z4 = tr_f32x4{1.f, 1.f, 1.f, 1.f};
+            if (relu) z4 = reinterpret_cast<const tr_f32x4 *>(z)[ti + i];
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gp = z4[k] > 0.f ? g4[k] : 0.f;
+                s0 += gp;
+                s1 += gp * ((y4[k] - mu) * is);
+            }
+            v[0] += (double)s0;
+            v[1] += (double)s1;
+        }
+    }
+    block_reduce_d<2>(v, sm);
+    if (threadIdx.x == 0) {
+        partial[((long long)c * kBnSlabs + slab) * 2 + 0] = v[0];
+        partial[((long long)c * kBnSlabs + slab) * 2 + 1] = v[1];
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
+                                                            const float *mean, const float *invstd, const float *gamma, const float *sums,
+                                                            int B, int C, int HW4, int relu, float *dy) {
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW4) return;
+    const float n = (float)((double)B * 4.0 * (double)HW4);
+    const long long ti = ((long long)b * t_ctotal + choff + c) * HW4 + i;
+    const tr_f32x4 g4 = reinterpret_cast<const tr_f32x4 *>(g)[ti], y4 = reinterpret_cast<const tr_f32x4 *>(y)[(long long)bc * HW4 + i];
+    tr_f32x4 z4 = tr_f32x4{1.f, 1.f, 1.f, 1.f};
+    if (relu) z4 = reinterpret_cast<const tr_f32x4 *>(z)[ti];
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], s0 = sums[c] / n, s1 = sums[C + c] / n;
+    tr_f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float gp = z4[k] > 0.f ? g4[k] : 0.f;
+        const float xh = (y4[k] - mu) * is;
+        o[k] = ga * is * (gp - s0 - xh * s1);       // the scalar kernel's expression, term for term
+    }
+    reinterpret_cast<tr_f32x4 *>(dy)[(long long)bc * HW4 + i] = o;
+}
+
 int launch_bn_forward(const float *y, int B, int C, int H, int W, float eps, float momentum, const float *gamma, const float *beta,
                       float *running_mean, float *running_var, float *mean, float *invstd, double *partial, float *dst, int dst_ctotal,
                       int dst_choff, int relu, hipStream_t s) {
     const long long HW = (long long)H * W;
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, y, B, C, HW, partial);
+    const bool vec = (HW & 3) == 0 && HW / 4 < (1ll << 31);
+    if (vec) hipLaunchKernelGGL(bn_stats_partial4_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, y, B, C, (int)(HW / 4), partial);
+    else hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, y, B, C, HW, partial);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, C, (double)B * HW, eps, momentum, mean, invstd,
                        running_mean, running_var);
-    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3((unsigned)((HW / 4 + 256) / 256), B * C), dim3(256), 0, s, y, mean, invstd, gamma, beta, C, HW,
-                       dst, dst_ctotal, dst_choff, relu);
+    if (vec)
+        hipLaunchKernelGGL(bn_apply_relu4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), B * C), dim3(256), 0, s, y, mean, invstd, gamma, beta, C,
+                           (int)(HW / 4), dst, dst_ctotal, dst_choff, relu);
+    else
+        hipLaunchKernelGGL(bn_apply_relu_kernel, dim3((unsigned)((HW / 4 + 256) / 256), B * C), dim3(256), 0, s, y, mean, invstd, gamma, beta, C, HW,
+                           dst, dst_ctotal, dst_choff, relu);
     PF_LAUNCH_CHECK("bn_forward");
     return PF_OK;
 }
@@ -220,32 +366,53 @@ int launch_bn_backward(const float *g, const float *z, int t_ctotal, int choff, 
                        const float *gamma, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial, float *sums,
                        float *dy, hipStream_t s) {
     const long long HW = (long long)H * W;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd, B, C, HW, relu, partial);
+    const bool vec = (HW & 3) == 0 && HW / 4 < (1ll << 31);
+    if (vec)
+        hipLaunchKernelGGL(bn_bwd_partial4_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd, B, C, (int)(HW / 4),
+                           relu, partial);
+    else
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd, B, C, HW, relu, partial);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, C, dgamma, dbeta, sums);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((HW + 255) / 256), B * C), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd,
-                       gamma, sums, B, C, HW, relu, dy);
+    if (vec)
+        hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), B * C), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean,
+                           invstd, gamma, sums, B, C, (int)(HW / 4), relu, dy);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((HW + 255) / 256), B * C), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd,
+                           gamma, sums, B, C, HW, relu, dy);
     PF_LAUNCH_CHECK("bn_backward");
     return PF_OK;
 }
 
-// bias gradient of a conv without BN (finalConv): dbias[c] += sum over (b, pixels) of g; also copies g -> dy (contiguous)
-__global__ __launch_bounds__(256) void bias_bwd_kernel(const float *g, int t_ctotal, int choff, int B, int C, long long HW, float *dbias,
+// bias gradient of a conv without BN (finalConv): dbias[c] += sum over (b, pixels) of g; also copies g -> dy (contiguous).
+// Grid (C, kBnSlabs) with fp64 partials reduced in slab order (one block per channel took 0.49 ms for the 11 logit planes)
+__global__ __launch_bounds__(256) void bias_bwd_kernel(const float *g, int t_ctotal, int choff, int B, int C, long long HW, double *partial,
                                                        float *dy) {
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, slab = blockIdx.y;
     __shared__ double sm[4];
     double v[1] = {0.0};
-    const long long per = (long long)B * HW;
-    for (long long i = threadIdx.x; i < per; i += 256) {
-        const long long b = i / HW, p = i - b * HW;
-        const float x = g[((long long)b * t_ctotal + choff + c) * HW + p];
-        dy[((long long)b * C + c) * HW + p] = x;
-        v[0] += (double)x;
+    for (int b = 0; b < B; ++b) {
+        const float *gp = g + ((long long)b * t_ctotal + choff + c) * HW;
+        float *dp = dy + ((long long)b * C + c) * HW;
+        for (long long p = (long long)slab * 256 + threadIdx.x; p < HW; p += (long long)kBnSlabs * 256) {
+            const float x = gp[p];
+            dp[p] = x;
+            v[0] += (double)x;
+        }
     }
     block_reduce_d<1>(v, sm);
-    if (threadIdx.x == 0) dbias[c] += (float)v[0];
+    if (threadIdx.x == 0) partial[(long long)c * kBnSlabs + slab] = v[0];
 }
-int launch_bias_backward(const float *g, int t_ctotal, int choff, int B, int C, int H, int W, float *dbias, float *dy, hipStream_t s) {
-    hipLaunchKernelGGL(bias_bwd_kernel, dim3(C), dim3(256), 0, s, g, t_ctotal, choff, B, C, (long long)H * W, dbias, dy);
+__global__ void bias_bwd_final_kernel(const double *partial, int C, float *dbias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < kBnSlabs; ++k) s += partial[(long long)c * kBnSlabs + k];
+    dbias[c] += (float)s;
+}
+int launch_bias_backward(const float *g, int t_ctotal, int choff, int B, int C, int H, int W, float *dbias, double *partial, float *dy,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(bias_bwd_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, t_ctotal, choff, B, C, (long long)H * W, partial, dy);
+    hipLaunchKernelGGL(bias_bwd_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, C, dbias);
     PF_LAUNCH_CHECK("bias_bwd_kernel");
     return PF_OK;
 }
@@ -323,45 +490,259 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(ConvArgs a, const fl
 #endif
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial, int slabs, int co_pad, int ci_pad, int ks2, int Cout, int Cin,
-                                                           float *dw) {
-    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)Cout * Cin * ks2;
-    if (o >= total) return;
-    const int t = (int)(o % ks2);
-    const int ci = (int)((o / ks2) % Cin), co = (int)(o / ((long long)ks2 * Cin));
-    float s = 0.f;
-    for (int k = 0; k < slabs; ++k) s += partial[(((long long)k * co_pad + co) * ci_pad + ci) * ks2 + t];
-    dw[o] += s;
+// ---- the LDS-tiled form (input and output widths multiples of 4): round 2's kernel above gathered both operands
+// straight from memory, 16 B per lane from 16 different planes per request, and every (cout tile, cin tile) pair
+// re-read its operands: 12.8 TFLOP/s over the 70 layers of a B = 8, 800 x 800 step (tools/bench_train.py).  Here a
+// workgroup owns 32 couts x 16 cins and walks 64-pixel row segments: dy [32][64] and the x rows the taps need
+// [16][KS][64 S + 8] are loaded with coalesced 16-B loads one segment AHEAD (registers), parked in LDS, and the 4 waves
+// multiply 16 pixels each for all k*k taps from there (pitches == 4 mod 32 floats: at most 2-way bank conflicts on
+// the one-float-per-lane fragment reads).  Partial sums per slab as before, same fixed-order reduction.
+template <int KS, int STRIDE>
+struct WgCfg {
+    static constexpr int KS2 = KS * KS, P = KS / 2, TW = 64;
+    static constexpr int XW = TW * STRIDE + 8;                      // staged x columns: [x0 S - 4, x0 S + 64 S + 4)
+    static constexpr int XCP = (KS * XW + 27) / 32 * 32 + 4;        // channel pitch == 4 (mod 32), >= KS * XW
+    static constexpr int DP = TW + 4;                               // dy row pitch: 68 == 4 (mod 32)
+    static constexpr int NDY = 32 * (TW / 4), NX = 16 * KS * (XW / 4);   // float4 loads per segment
+    static constexpr int ITD = NDY / 256, ITX = (NX + 255) / 256;
+    static constexpr int LDS_FLOATS = 32 * DP + 16 * XCP;
+    static_assert(XCP >= KS * XW && XCP % 32 == 4 && NDY % 256 == 0, "wgrad tile geometry");
+};
+
+template <int KS, int STRIDE>
+__global__ __launch_bounds__(256) void wgrad_tiled_kernel(ConvArgs a, const float *dy, int B, int slabs, float *partial) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using C = WgCfg<KS, STRIDE>;
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS > 3 * 4 * 256 ? C::LDS_FLOATS : 3 * 4 * 256];
+    float *dy_s = lds, *x_s = lds + 32 * C::DP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 16, slab = blockIdx.z;
+    const long long in_plane = (long long)a.Hin * a.Win, out_plane = (long long)a.Hout * a.Wout;
+    const int chunks = (a.Wout + C::TW - 1) / C::TW;
+    const long long items = (long long)B * a.Hout * chunks;
+
+    // this thread's x loads: (channel, tap row, 16-B column) of the staged window -> plane base of the channel (batch 0)
+    const float *xplane[C::ITX];
+    int xrow[C::ITX], xcol[C::ITX], xlds[C::ITX];
+    int xbstride[C::ITX];   // channels of the tensor the plane lives in (batch stride in planes)
+#pragma unroll
+    for (int it = 0; it < C::ITX; ++it) {
+        const int idx = it * 256 + tid;
+        const int c = idx / (KS * (C::XW / 4)), r = idx - c * (KS * (C::XW / 4));
+        const int row = r / (C::XW / 4), c4 = r - row * (C::XW / 4);
+        const int ci = ci0 + c;
+        xplane[it] = nullptr;
+        xbstride[it] = 0;
+        if (idx < C::NX && ci < a.Cin) {
+            int sidx = 0;
+            while (sidx + 1 < a.n_src && ci >= a.src_cstart[sidx + 1]) ++sidx;
+            xplane[it] = a.src[sidx] + (long long)(a.src_choff[sidx] + (ci - a.src_cstart[sidx])) * in_plane;
+            xbstride[it] = a.src_ctotal[sidx];
+        }
+        xrow[it] = row;
+        xcol[it] = c4 * 4;
+        xlds[it] = idx < C::NX ? c * C::XCP + row * C::XW + c4 * 4 : -1;
+    }
+    tr_f32x4 rdy[C::ITD], rx[C::ITX];
+    auto fetch = [&](long long item) {
+        const int ch = (int)(item % chunks);
+        const long long row = item / chunks;
+        const int b = (int)(row / a.Hout), oy = (int)(row - (long long)b * a.Hout);
+        const int x0 = ch * C::TW;
+#pragma unroll
+        for (int it = 0; it < C::ITD; ++it) {
+            const int idx = it * 256 + tid, c = idx >> 4, c4 = idx & 15;
+            const int co = co0 + c, ox = x0 + c4 * 4;
+            rdy[it] = tr_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (co < a.Cout && ox < a.Wout)   // Wout % 4 == 0: a 16-B piece is inside the row or outside it
+                rdy[it] = *reinterpret_cast<const tr_f32x4 *>(dy + ((long long)b * a.Cout + co) * out_plane + (long long)oy * a.Wout + ox);
+        }
+#pragma unroll
+        for (int it = 0; it < C::ITX; ++it) {
+            rx[it] = tr_f32x4{0.f, 0.f, 0.f, 0.f};
+            const int iy = oy * STRIDE + xrow[it] - C::P, ix = x0 * STRIDE - 4 + xcol[it];
+            if (xplane[it] && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
+                rx[it] = *reinterpret_cast<const tr_f32x4 *>(xplane[it] + (long long)b * xbstride[it] * in_plane + (long long)iy * a.Win + ix);
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int it = 0; it < C::ITD; ++it) {
+            const int idx = it * 256 + tid;
+            *reinterpret_cast<tr_f32x4 *>(dy_s + (idx >> 4) * C::DP + (idx & 15) * 4) = rdy[it];
+        }
+#pragma unroll
+        for (int it = 0; it < C::ITX; ++it)
+            if (xlds[it] >= 0) *reinterpret_cast<tr_f32x4 *>(x_s + xlds[it]) = rx[it];
+    };
+
+    tr_f32x4 acc[2][C::KS2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int t = 0; t < C::KS2; ++t) acc[n][t] = tr_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int m = lane & 15, kq = lane >> 4;
+    const bool two = co0 + 16 < a.Cout;   // the second cout tile exists (uniform)
+
+    long long item = slab;
+    if (item < items) fetch(item);
+    for (; item < items; item += slabs) {
+        __syncthreads();            // the previous segment has been multiplied
+        park();
+        __syncthreads();
+        if (item + slabs < items) fetch(item + slabs);   // in flight during the MFMAs
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int q = wave * 4 + qq;                 // 4-pixel group of the segment
+            const float a0 = dy_s[m * C::DP + q * 4 + kq];
+            const float a1 = two ? dy_s[(16 + m) * C::DP + q * 4 + kq] : 0.f;
+#pragma unroll
+            for (int t = 0; t < C::KS2; ++t) {
+                const int ky = t / KS, kx = t - ky * KS;
+                const float bv = x_s[m * C::XCP + ky * C::XW + (q * 4 + kq) * STRIDE + kx - C::P + 4];
+                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][t], 0, 0, 0);
+                if (two) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][t], 0, 0, 0);
+            }
+        }
+    }
+    // combine the 4 waves (3 taps per pass through LDS, fixed order) -> partial[slab][co][ci][tap]
+    const int ci_pad = gridDim.y * 16, co_pad = gridDim.x * 32;
+    float *red = lds;   // [3 taps][4 waves][256]
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int t0 = 0; t0 < C::KS2; t0 += 3) {
+            __syncthreads();
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt)
+                if (t0 + tt < C::KS2)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) red[(tt * 4 + wave) * 256 + i * 64 + lane] = acc[n][t0 + tt][i];
+            __syncthreads();
+            for (int e = tid; e < 3 * 256; e += 256) {
+                const int tt = e >> 8, r = e & 255, i = r >> 6, l = r & 63;
+                if (t0 + tt >= C::KS2) continue;
+                const float v = ((red[(tt * 4 + 0) * 256 + r] + red[(tt * 4 + 1) * 256 + r]) + red[(tt * 4 + 2) * 256 + r]) + red[(tt * 4 + 3) * 256 + r];
+                const int mm = co0 + n * 16 + 4 * (l >> 4) + i, nn = ci0 + (l & 15);
+                partial[(((long long)slab * co_pad + mm) * ci_pad + nn) * C::KS2 + t0 + tt] = v;
+            }
+        }
+#endif
 }
 
-int wgrad_slabs(int cout, int cin, int B, int Hout) {
-    const long long tiles = (long long)((cout + 15) / 16) * ((cin + 15) / 16);
-    long long s = 2048 / tiles;
-    s = s < 1 ? 1 : s;
-    const long long rows = (long long)B * Hout;
-    return (int)(s > rows ? rows : s);
+// partial[slab][co_pad][ci_pad][ks2] -> dw[co][ci][tap] += sum over slabs.  A block = 64 consecutive outputs x 4 slab lanes:
+// lane j adds the slabs j, j + 4, ... in order, the four sums are combined in fixed order through LDS (deterministic).  (As
+// one thread per output walking all slabs this kernel was 5.7 ms of a 27 ms step: 90 blocks for a 91 -> 28 layer, each
+// thread 341 dependent, strided loads.)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial, int slabs, int co_pad, int ci_pad, int ks2, int Cout, int Cin,
+                                                           float *dw) {
+    __shared__ float sm[4][64];
+    const int j = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const long long o = (long long)blockIdx.x * 64 + l;
+    const long long total = (long long)Cout * Cin * ks2;
+    float s = 0.f;
+    if (o < total) {
+        const int t = (int)(o % ks2);
+        const int ci = (int)((o / ks2) % Cin), co = (int)(o / ((long long)ks2 * Cin));
+        const long long at = ((long long)co * ci_pad + ci) * ks2 + t, stride = (long long)co_pad * ci_pad * ks2;
+        for (int k = j; k < slabs; k += 4) s += partial[k * stride + at];
+    }
+    sm[j][l] = s;
+    __syncthreads();
+    if (j == 0 && o < total) dw[o] += ((sm[0][l] + sm[1][l]) + sm[2][l]) + sm[3][l];
 }
-size_t wgrad_partial_floats(int cout, int cin, int ks, int B, int Hout) {
-    return (size_t)wgrad_slabs(cout, cin, B, Hout) * ((cout + 15) / 16 * 16) * ((cin + 15) / 16 * 16) * ks * ks;
+
+static bool wgrad_tiled_ok(int Win, int Wout) { return (Win & 3) == 0 && (Wout & 3) == 0; }
+// cout tiles per workgroup: 2 in the tiled form
+int wgrad_slabs(int cout, int cin, int B, int Hout, int Win, int Wout) {
+    const bool tiled = wgrad_tiled_ok(Win, Wout);
+    const long long tiles = (long long)(tiled ? (cout + 31) / 32 : (cout + 15) / 16) * ((cin + 15) / 16);
+    long long s = (tiled ? 1024 : 2048) / tiles;     // tiled: 2 workgroups per CU resident, 2 rounds
+    s = s < 1 ? 1 : s;
+    const long long units = tiled ? (long long)B * Hout * ((Wout + 63) / 64) : (long long)B * Hout;
+    return (int)(s > units ? units : s);
+}
+size_t wgrad_partial_floats(int cout, int cin, int ks, int B, int Hout, int Win, int Wout) {
+    return (size_t)wgrad_slabs(cout, cin, B, Hout, Win, Wout) * ((cout + 31) / 32 * 32) * ((cin + 15) / 16 * 16) * ks * ks;
 }
 
 int launch_wgrad(const ConvArgs &a, int ks, int stride, const float *dy, int B, float *partial, float *dw, hipStream_t s) {
-    const int slabs = wgrad_slabs(a.Cout, a.Cin, B, a.Hout);
-    const dim3 grid((a.Cout + 15) / 16, (a.Cin + 15) / 16, slabs);
+    const int slabs = wgrad_slabs(a.Cout, a.Cin, B, a.Hout, a.Win, a.Wout);
+    const bool tiled = wgrad_tiled_ok(a.Win, a.Wout);
+    const dim3 grid(tiled ? (a.Cout + 31) / 32 : (a.Cout + 15) / 16, (a.Cin + 15) / 16, slabs);
     const double flops = 2.0 * B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks;
     {
-        ProfScope ps(s, "wgrad_partial_kernel", flops, 4.0 * B * ((double)a.Cout * a.Hout * a.Wout + (double)a.Cin * a.Hin * a.Win));
-        if (ks == 3 && stride == 1) hipLaunchKernelGGL((wgrad_partial_kernel<3, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
-        else if (ks == 3 && stride == 2) hipLaunchKernelGGL((wgrad_partial_kernel<3, 2>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
-        else if (ks == 1 && stride == 1) hipLaunchKernelGGL((wgrad_partial_kernel<1, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
-        else return fail(PF_EUNSUPPORTED, "wgrad: k=%d stride=%d", ks, stride);
-        PF_LAUNCH_CHECK("wgrad_partial_kernel");
+        ProfScope ps(s, tiled ? "wgrad_tiled_kernel" : "wgrad_partial_kernel", flops,
+                     4.0 * B * ((double)a.Cout * a.Hout * a.Wout + (double)a.Cin * a.Hin * a.Win));
+        if (tiled) {
+            if (ks == 3 && stride == 1) hipLaunchKernelGGL((wgrad_tiled_kernel<3, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
+            else if (ks == 3 && stride == 2) hipLaunchKernelGGL((wgrad_tiled_kernel<3, 2>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
+            else if (ks == 1 && stride == 1) hipLaunchKernelGGL((wgrad_tiled_kernel<1, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
+            else return fail(PF_EUNSUPPORTED, "wgrad: k=%d stride=%d", ks, stride);
+        } else {
+            if (ks == 3 && stride == 1) hipLaunchKernelGGL((wgrad_partial_kernel<3, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
+            else if (ks == 3 && stride == 2) hipLaunchKernelGGL((wgrad_partial_kernel<3, 2>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
+            else if (ks == 1 && stride == 1) hipLaunchKernelGGL((wgrad_partial_kernel<1, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
+            else return fail(PF_EUNSUPPORTED, "wgrad: k=%d stride=%d", ks, stride);
+        }
+        PF_LAUNCH_CHECK("wgrad kernel");
     }
     const long long total = (long long)a.Cout * a.Cin * ks * ks;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, slabs, (int)grid.x * 16, (int)grid.y * 16,
-                       ks * ks, a.Cout, a.Cin, dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, partial, slabs, (int)grid.x * (tiled ? 32 : 16),
+                       (int)grid.y * 16, ks * ks, a.Cout, a.Cin, dw);
     PF_LAUNCH_CHECK("wgrad_reduce_kernel");
+    return PF_OK;
+}
+
+// ---- widths that are not a multiple of 4 (the 50- and 25-pixel levels of an 800 x 800 crop): the LDS-DMA kernels move
+// 16-B pieces and need 16-B aligned rows.  Such a conv runs on COPIES with the row pitch rounded up to 4: its input ranges
+// gathered into one contiguous tensor [B][Cin][H][Wp] with zero pad columns (= the convolution's own zero padding, so the
+// real columns of the result are unchanged), its result [B][Cout][Hout][Wop] scattered back into the destination slice
+// (accumulating for backward-data).  Two small copy kernels around a fast conv instead of the register-staged generic
+// kernel (1.7-16 TFLOP/s on these levels: 14 ms of a 44 ms step).
+struct PadGatherArgs {
+    const float *src[kConvMaxSrc];
+    int ctotal[kConvMaxSrc], choff[kConvMaxSrc], cstart[kConvMaxSrc + 1], n_src;
+};
+__global__ __launch_bounds__(256) void pad_gather_kernel(PadGatherArgs g, int Cin, int H, int W, int Wp, float *dst) {
+    const int bc = blockIdx.y, b = bc / Cin, c = bc - b * Cin;
+    const int i4 = blockIdx.x * 256 + threadIdx.x;          // 4-column group of the padded plane
+    const int wp4 = Wp / 4;
+    if (i4 >= H * wp4) return;
+    const int y = i4 / wp4, x = (i4 - y * wp4) * 4;
+    int j = 0;
+    while (j + 1 < g.n_src && c >= g.cstart[j + 1]) ++j;
+    const float *sp = g.src[j] + ((long long)b * g.ctotal[j] + g.choff[j] + (c - g.cstart[j])) * H * W + (long long)y * W;
+    tr_f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = x + k < W ? sp[x + k] : 0.f;
+    *reinterpret_cast<tr_f32x4 *>(dst + ((long long)bc * H + y) * Wp + x) = v;
+}
+__global__ __launch_bounds__(256) void unpad_scatter_kernel(const float *src, int C, int H, int W, int Wp, float *dst, int dst_ctotal, int dst_choff,
+                                                            int accum) {
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i - y * W;
+    float *d = dst + ((long long)b * dst_ctotal + dst_choff + c) * H * W + i;
+    const float v = src[((long long)bc * H + y) * Wp + x];
+    *d = accum ? *d + v : v;
+}
+int launch_pad_gather(const ConvArgs &a, int B, int Wp, float *dst, hipStream_t s) {
+    PadGatherArgs g;
+    g.n_src = a.n_src;
+    for (int j = 0; j < kConvMaxSrc; ++j) {
+        g.src[j] = a.src[j]; g.ctotal[j] = a.src_ctotal[j]; g.choff[j] = a.src_choff[j]; g.cstart[j] = a.src_cstart[j];
+    }
+    g.cstart[kConvMaxSrc] = a.src_cstart[kConvMaxSrc];
+    hipLaunchKernelGGL(pad_gather_kernel, dim3((unsigned)((a.Hin * (Wp / 4) + 255) / 256), B * a.Cin), dim3(256), 0, s, g, a.Cin, a.Hin, a.Win, Wp, dst);
+    PF_LAUNCH_CHECK("pad_gather_kernel");
+    return PF_OK;
+}
+int launch_unpad_scatter(const float *src, int B, int C, int H, int W, int Wp, float *dst, int dst_ctotal, int dst_choff, int accum, hipStream_t s) {
+    hipLaunchKernelGGL(unpad_scatter_kernel, dim3((unsigned)((H * W + 255) / 256), B * C), dim3(256), 0, s, src, C, H, W, Wp, dst, dst_ctotal, dst_choff,
+                       accum);
+    PF_LAUNCH_CHECK("unpad_scatter_kernel");
     return PF_OK;
 }
 

@@ -12,9 +12,11 @@
 //     with BatchNorm:  gamma[cout], beta[cout], running_mean[cout], running_var[cout]      (ConvLayer, hardnet.py:16-25)
 //     without       :  bias[cout]                                                          (finalConv, hardnet.py:325-327)
 //
-// Convolutions run on the fp32 matrix cores: forward and backward-data through the generic implicit-GEMM kernel of
-// conv_mfma.hip (weights re-packed on the device every step: forward order, or transposed + flipped per input range;
-// stride-2 backward-data = stride-1 conv over the zero-stuffed gradient), backward-weight through wgrad_partial_kernel.
+// Convolutions run on the fp32 matrix cores: forward and backward-data through the LDS-DMA kernels of the inference path
+// (conv_dma.hip; the generic implicit-GEMM kernel of conv_mfma.hip for widths that are not a multiple of 4) with the
+// weights re-packed on the device every step (forward order, or transposed + flipped per input range; stride-2
+// backward-data = stride-1 conv over the zero-stuffed gradient; a tensor's gradient accumulates over its consumers in
+// the store), backward-weight through the LDS-tiled wgrad kernels of train_kernels.hip.
 #include <cstring>
 #include <vector>
 
@@ -67,6 +69,7 @@ struct TLayout {
     std::vector<size_t> act, grad;     // per tensor (bytes); act[input] = the dense one-hot/depth tensor
     std::vector<size_t> ypre, stat;    // per op: pre-BN conv output, {mean[cout], invstd[cout]}
     size_t dy = 0, wpk = 0, wpart = 0, dfull = 0, cepart = 0, bnpart = 0, sums = 0, out3 = 0, total = 0;
+    size_t pad_in = 0, pad_out = 0;    // odd-width convs: gathered input / result with the row pitch rounded up to 4
     size_t grad_begin = 0, grad_end = 0;
 };
 
@@ -91,7 +94,7 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
     for (size_t t = 0; t < nt; ++t)
         if (d[t].h && t != input) L.grad[t] = take(tbytes(t));
     L.grad_end = cur;
-    size_t max_dy = 0, max_wpk = 0, max_wpart = 0, max_c = 16;
+    size_t max_dy = 0, max_wpk = 0, max_wpart = 0, max_c = 16, max_pin = 256, max_pout = 256;
     for (size_t i = 0; i < p->ops.size(); ++i) {
         const BlobOp &o = p->ops[i];
         if (o.kind != OP_STEM && o.kind != OP_CONV) continue;
@@ -107,17 +110,33 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
         max_dy = need > max_dy ? need : max_dy;
         const ConvTiling tf = choose_tiling((int)o.k, (int)o.stride, (int)o.cin, (int)o.cout, 0);
         max_wpk = tf.packed_floats() > max_wpk ? tf.packed_floats() : max_wpk;
+        int src_ch[kMaxSrc];
+        for (uint32_t j = 0; j < o.n_src; ++j) src_ch[j] = (int)o.src[j].ch;
+        size_t tp = tiled_packed_floats(src_ch, (int)o.n_src, (int)o.cout, (int)o.k, (int)o.stride);
+        max_wpk = tp > max_wpk ? tp : max_wpk;
         for (uint32_t j = 0; j < o.n_src; ++j) {
             const ConvTiling tb = choose_tiling((int)o.k, 1, (int)o.cout, (int)o.src[j].ch, 0);
             max_wpk = tb.packed_floats() > max_wpk ? tb.packed_floats() : max_wpk;
+            const int one = (int)o.cout;
+            tp = tiled_packed_floats(&one, 1, (int)o.src[j].ch, (int)o.k, 1);
+            max_wpk = tp > max_wpk ? tp : max_wpk;
         }
-        const size_t wp = wgrad_partial_floats((int)o.cout, (int)o.cin, (int)o.k, B, out.h);
+        if (in.w & 3) {     // padded copies (forward: cin -> cout at the output size; backward-data: cout -> cin at the input size)
+            const size_t wp_in = (size_t)(in.w + 3) / 4 * 4, cmax = o.cin > o.cout ? o.cin : o.cout;
+            const size_t bytes = (size_t)B * cmax * in.h * wp_in * sizeof(float);
+            max_pin = bytes > max_pin ? bytes : max_pin;
+            max_pout = bytes > max_pout ? bytes : max_pout;
+        }
+        const int wpi = o.stride == 1 ? (in.w + 3) / 4 * 4 : in.w, wpo = o.stride == 1 ? (out.w + 3) / 4 * 4 : out.w;   // (padded copies for odd widths)
+        const size_t wp = wgrad_partial_floats((int)o.cout, (int)o.cin, (int)o.k, B, out.h, wpi, wpo);
         max_wpart = wp > max_wpart ? wp : max_wpart;
         max_c = o.cout > max_c ? o.cout : max_c;
     }
     L.dy = take(max_dy + 256);
     L.wpk = take(max_wpk * sizeof(float));
     L.wpart = take(max_wpart * sizeof(float));
+    L.pad_in = take(max_pin);
+    L.pad_out = take(max_pout);
     L.dfull = take((size_t)B * p->hdr.n_cls * out_h * out_w * sizeof(float));
     L.cepart = take(ce_partial_doubles(B, out_h, out_w) * sizeof(double));
     L.bnpart = take(bn_partial_doubles((int)max_c) * sizeof(double));
@@ -252,6 +271,7 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
     float *dy = reinterpret_cast<float *>(wsb + L.dy);
     float *wpk = reinterpret_cast<float *>(wsb + L.wpk);
     float *wpart = reinterpret_cast<float *>(wsb + L.wpart);
+    float *pad_in = reinterpret_cast<float *>(wsb + L.pad_in), *pad_out = reinterpret_cast<float *>(wsb + L.pad_out);
     float *dfull = reinterpret_cast<float *>(wsb + L.dfull);
     double *cepart = reinterpret_cast<double *>(wsb + L.cepart);
     double *bnpart = reinterpret_cast<double *>(wsb + L.bnpart);
@@ -288,22 +308,65 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
         a.src_end = a.n_src;
     };
 
+    // one convolution: a = sources / destination / shapes filled, weights = OIHW in theta.  fwd: the op's own conv (input
+    // ranges src_ch); else the backward-data conv of forward input range [c0, c0 + ch) (one range: the cout_f channels of dy)
+    auto run_conv = [&](ConvArgs &a, int ks, int stride, const float *w, int cin_f, int cout_f, const int *src_ch, int n_src, int tflip, int c0,
+                        int ch) -> int {
+        int rc2 = PF_EUNSUPPORTED;
+        auto fast = [&](ConvArgs &c, const int *chs, int ns) -> int {
+            int r2 = launch_pack_weights_tiled(w, cin_f, cout_f, ks, stride, chs, ns, tflip, c0, ch, wpk, s);
+            if (r2) return r2;
+            const int kc = dma_kc(ks, stride);
+            c.wpk = wpk;
+            c.src_chunk0[0] = 0;
+            for (int j = 0; j < kConvMaxSrc; ++j) c.src_chunk0[j + 1] = c.src_chunk0[j] + (j < ns ? (chs[j] + kc - 1) / kc : 0);
+            c.nchunks = c.src_chunk0[ns];
+            c.chunk_begin = 0;
+            c.chunk_end = c.nchunks;
+            c.rem = 0;
+            return launch_conv_dma(c, ks, stride, B, s);
+        };
+        if ((a.Win & 3) == 0) {
+            rc2 = fast(a, src_ch, n_src);
+            if (rc2 != PF_EUNSUPPORTED) return rc2;
+        } else {
+            // odd width: the same kernels on copies whose rows are padded to a multiple of 4 (train_kernels.hip)
+            const int Wp = (a.Win + 3) / 4 * 4, pad = ks / 2;
+            const int Wop = (Wp + 2 * pad - ks) / stride + 1;
+            if ((rc2 = launch_pad_gather(a, B, Wp, pad_in, s))) return rc2;
+            ConvArgs c = a;
+            c.n_src = 1;
+            c.src[0] = pad_in; c.src_ctotal[0] = a.Cin; c.src_choff[0] = 0; c.src_cstart[0] = 0;
+            for (int k = 1; k <= kConvMaxSrc; ++k) c.src_cstart[k] = a.Cin;
+            c.src_begin = 0; c.src_end = 1;
+            c.Win = Wp; c.Wout = Wop;
+            c.dst = pad_out; c.dst_ctotal = a.Cout; c.dst_choff = 0; c.accum = 0;
+            const int one = a.Cin;
+            rc2 = fast(c, &one, 1);
+            if (rc2 == PF_OK) return launch_unpad_scatter(pad_out, B, a.Cout, a.Hout, a.Wout, Wop, a.dst, a.dst_ctotal, a.dst_choff, a.accum, s);
+            if (rc2 != PF_EUNSUPPORTED) return rc2;
+        }
+        const ConvTiling t = choose_tiling(ks, stride, tflip ? cout_f : cin_f, tflip ? ch : cout_f, 0);
+        if ((rc2 = launch_pack_weights(w, cin_f, cout_f, t, tflip, c0, ch, wpk, s))) return rc2;
+        a.wpk = wpk;
+        a.nchunks = t.nchunks;
+        return launch_conv(a, t, B, s);
+    };
+
     // ================================================================ forward (training mode)
     for (size_t i = 0; i < p->ops.size(); ++i) {
         const BlobOp &o = p->ops[i];
         const TDims in = d[o.src[0].tensor];
         const TDims out = o.kind == OP_HEAD ? in : d[o.dst];
         if (o.kind == OP_STEM || o.kind == OP_CONV) {
-            const ConvTiling t = choose_tiling((int)o.k, (int)o.stride, (int)o.cin, (int)o.cout, 0);
-            if ((rc = launch_pack_weights(theta + p->w_off[i], (int)o.cin, (int)o.cout, t, 0, 0, 0, wpk, s))) return rc;
+            int src_ch[kMaxSrc];
+            for (uint32_t j = 0; j < o.n_src; ++j) src_ch[j] = (int)o.src[j].ch;
             ConvArgs a;
             conv_args(o, in, out, a);
-            a.wpk = wpk;
-            a.nchunks = t.nchunks;
             if (p->bn[i]) {
                 float *y = reinterpret_cast<float *>(wsb + L.ypre[i]);
                 a.dst = y; a.dst_ctotal = (int)o.cout; a.dst_choff = 0; a.relu = 0;
-                if ((rc = launch_conv(a, t, B, s))) return rc;
+                if ((rc = run_conv(a, (int)o.k, (int)o.stride, theta + p->w_off[i], (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, 0, 0, 0))) return rc;
                 float *aux = theta + p->aux_off[i];
                 float *stat = reinterpret_cast<float *>(wsb + L.stat[i]);
                 if ((rc = launch_bn_forward(y, B, (int)o.cout, out.h, out.w, bn_eps, bn_momentum, aux, aux + o.cout,
@@ -314,7 +377,7 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
             } else {
                 a.bias = theta + p->aux_off[i];
                 a.dst = act(o.dst); a.dst_ctotal = (int)p->tensors[o.dst].channels; a.dst_choff = (int)o.dst_choff; a.relu = (int)o.relu;
-                if ((rc = launch_conv(a, t, B, s))) return rc;
+                if ((rc = run_conv(a, (int)o.k, (int)o.stride, theta + p->w_off[i], (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, 0, 0, 0))) return rc;
             }
         } else if (o.kind == OP_POOL) {
             if ((rc = launch_avgpool2(act(o.src[0].tensor), act(o.dst), B * (int)o.cin, in.h, in.w, s))) return rc;
@@ -351,12 +414,31 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
                     return rc;
             } else {
                 if (o.relu) return fail(PF_EUNSUPPORTED, "training: ReLU without BatchNorm (op %zu)", ii);
-                if ((rc = launch_bias_backward(gradt(o.dst), t_ctotal, (int)o.dst_choff, B, (int)o.cout, out.h, out.w, gaux, dy, s))) return rc;
+                if ((rc = launch_bias_backward(gradt(o.dst), t_ctotal, (int)o.dst_choff, B, (int)o.cout, out.h, out.w, gaux, bnpart, dy, s))) return rc;
             }
             // dW
             ConvArgs a;
             conv_args(o, in, out, a);
-            if ((rc = launch_wgrad(a, (int)o.k, (int)o.stride, dy, B, wpart, grad + p->w_off[ii], s))) return rc;
+            if ((in.w & 3) != 0 && o.stride == 1) {
+                // odd width: the tiled kernel on padded copies of x (all ranges gathered) and dy; zero pad columns add nothing
+                const int Wp = (in.w + 3) / 4 * 4;
+                if ((rc = launch_pad_gather(a, B, Wp, pad_in, s))) return rc;
+                ConvArgs gdy;
+                memset(&gdy, 0, sizeof(gdy));
+                gdy.n_src = 1;
+                gdy.src[0] = dy; gdy.src_ctotal[0] = (int)o.cout; gdy.src_cstart[0] = 0;
+                for (int k = 1; k <= kConvMaxSrc; ++k) gdy.src_cstart[k] = (int)o.cout;
+                gdy.Cin = (int)o.cout; gdy.Hin = out.h; gdy.Win = out.w;
+                if ((rc = launch_pad_gather(gdy, B, Wp, pad_out, s))) return rc;
+                ConvArgs ap = a;
+                ap.n_src = 1;
+                ap.src[0] = pad_in; ap.src_ctotal[0] = (int)o.cin; ap.src_choff[0] = 0; ap.src_cstart[0] = 0;
+                for (int k = 1; k <= kConvMaxSrc; ++k) ap.src_cstart[k] = (int)o.cin;
+                ap.Win = Wp; ap.Wout = Wp;
+                if ((rc = launch_wgrad(ap, (int)o.k, 1, pad_out, B, wpart, grad + p->w_off[ii], s))) return rc;
+            } else if ((rc = launch_wgrad(a, (int)o.k, (int)o.stride, dy, B, wpart, grad + p->w_off[ii], s))) {
+                return rc;
+            }
             // dX per input range (the network input needs none)
             const float *dsrc = dy;
             if (o.stride == 2) {
@@ -370,18 +452,17 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
             for (uint32_t j = 0; j < o.n_src; ++j) {
                 const int ch = (int)o.src[j].ch;
                 if (o.src[j].tensor != input) {
-                    const ConvTiling tb = choose_tiling((int)o.k, 1, (int)o.cout, ch, 0);
-                    if ((rc = launch_pack_weights(theta + p->w_off[ii], (int)o.cin, (int)o.cout, tb, 1, c0, ch, wpk, s))) return rc;
                     ConvArgs b;
                     memset(&b, 0, sizeof(b));
                     b.n_src = 1;
                     b.src[0] = dsrc; b.src_ctotal[0] = (int)o.cout; b.src_choff[0] = 0; b.src_cstart[0] = 0;
                     for (int k = 1; k <= kConvMaxSrc; ++k) b.src_cstart[k] = (int)o.cout;
-                    b.wpk = wpk; b.nchunks = tb.nchunks; b.bias = p->dev_zero; b.zero_page = p->dev_zero;
+                    b.bias = p->dev_zero; b.zero_page = p->dev_zero;
                     b.dst = gradt(o.src[j].tensor); b.dst_ctotal = (int)p->tensors[o.src[j].tensor].channels; b.dst_choff = (int)o.src[j].choff;
                     b.Cin = (int)o.cout; b.Cout = ch; b.Hin = in.h; b.Win = in.w; b.Hout = in.h; b.Wout = in.w;
                     b.ntiles = (ch + 15) / 16; b.src_end = 1; b.accum = 1;
-                    if ((rc = launch_conv(b, tb, B, s))) return rc;
+                    const int dy_ch = (int)o.cout;
+                    if ((rc = run_conv(b, (int)o.k, 1, theta + p->w_off[ii], (int)o.cin, (int)o.cout, &dy_ch, 1, 1, c0, ch))) return rc;
                 }
                 c0 += ch;
             }

@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--size', type=int, default=800)
     ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--out', default='', help='also write the JSON line here')
     a = ap.parse_args()
     params = {'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])]},
               'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True},
@@ -44,10 +45,17 @@ def main():
     torch.cuda.synchronize()
     recs = pflib.profile_results()
     pflib.profile(False)
-    top = sorted(recs, key=lambda r: -r['ms'])[:8]
-    print(json.dumps({'ms_per_step': ms, 'samples_per_s': a.batch / ms * 1e3, 'batch': a.batch, 'size': a.size, 'loss': float(out['loss']),
-                      'workspace_GB': tr._ws.numel() / 1e9,
-                      'profiled_kernels': {r['label'][:60]: round(r['ms'], 2) for r in top}}))
+    top = sorted(recs, key=lambda r: -r['ms'])
+    line = {'ms_per_step': ms, 'samples_per_s': a.batch / ms * 1e3, 'batch': a.batch, 'size': a.size, 'loss': float(out['loss']),
+            'workspace_GB': tr._ws.numel() / 1e9, 'kernel_ms_sum': sum(r['ms'] for r in recs),
+            'profiled_kernels': {r['label'][:70]: {'ms': round(r['ms'], 3), 'launches': r['launches'],
+                                                   'TFLOPs': round(r['flops'] / max(r['ms'], 1e-9) / 1e9, 1),
+                                                   'GBps': round(r['bytes'] / max(r['ms'], 1e-9) / 1e6, 0)} for r in top}}
+    print(json.dumps(line))
+    if a.out:
+        os.makedirs(os.path.dirname(a.out) or '.', exist_ok=True)
+        with open(a.out, 'w') as f:
+            json.dump(line, f, indent=1)
 
 
 if __name__ == '__main__':
