@@ -9,8 +9,11 @@ the PQ accumulators.  Prints ONE JSON line on rank 0.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--replays R] [--no-graph] [--no-cpu-baseline] [--no-legs]
 
-A step visits the rank's resident synthetic batch R times (``--replays``, default 4: 4 x 32 = 128 forecast frames per GPU per
-step), so that the driver's 20 steps time about a second instead of a quarter of one; ``config`` states it.
+A step visits the rank's resident synthetic batch R times (``--replays``, default 2: 2 x 64 = 128 forecast frames per GPU per
+step, one hipGraph), so that the driver's 20 steps time about a second instead of a quarter of one; ``config`` states it.
+The 64 resident frames run as 4 sub-batches of 16 on 4 HIP streams, staggered (``--stagger 1``): the warp/splat of sub-batch
+i + 1 starts when that of sub-batch i is done, so the vector-ALU-bound front of one sub-batch runs beside the memory-bound
+convolutions of another (+3 % over starting them together: profiles/r03_experiments.md).
 
 ``--gpus N`` with N > 1 and no launcher environment (WORLD_SIZE unset) re-executes this file under
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` — one rank per GPU over
@@ -234,8 +237,12 @@ class Workload:
     one captured hipGraph.  The low-resolution layers of one sub-batch (small grids, latency-bound) and its memory-bound
     splat/stem kernels overlap the matrix-bound high-resolution layers of another."""
 
-    def __init__(self, sd, B, S, dev, seed0, term, use_graph=True, stagger=False, free_run_ms=None, **model_kw):
+    def __init__(self, sd, B, S, dev, seed0, term, use_graph=True, stagger=False, free_run_ms=None, passes=1, batch=None, **model_kw):
         self.stagger = stagger
+        # passes: how many times step() visits the resident batch.  With `stagger` they form ONE software pipeline (the
+        # warp/splat of sub-batch i + 1 starts when that of sub-batch i is done, across pass boundaries too), captured
+        # in one hipGraph: the streams join once per step, not once per pass
+        self.passes = max(1, passes)
         # free_run_ms (experiment, --free-run MS): one hipGraph PER sub-batch, each replayed on its own stream with no join
         # between steps; sub-batch i starts i * MS late (a spin kernel inside the timed region), so that the streams run
         # out of phase instead of in lockstep.  K steps still enqueue K forwards of every sub-batch; the clock stops when
@@ -244,7 +251,7 @@ class Workload:
         if B % S:
             raise SystemExit('--batch must be a multiple of --streams')
         self.B, self.S, self.use_graph = B, S, use_graph
-        self.batch = make_batch(B, seed0=seed0, device=dev, term=term)
+        self.batch = batch if batch is not None else make_batch(B, seed0=seed0, device=dev, term=term)
         self.models = []
         for _ in range(S):
             m = build_model(model_params(**model_kw))
@@ -299,31 +306,37 @@ class Workload:
         cur = torch.cuda.current_stream()
         outs = [None] * self.S
         if self.stagger and self.S > 1:
-            # software pipeline inside the step: sub-batch i + 1 starts when the warp/splat of sub-batch i has finished, so
-            # that its vector-ALU-bound warp/splat + stem run beside the matrix-bound convolutions of sub-batch i instead
-            # of beside another warp/splat (two identical chains started together stay in lockstep: tools/graph_timeline.py)
+            # software pipeline: sub-batch i + 1 starts when the warp/splat of sub-batch i has finished, so that its
+            # vector-ALU-bound warp/splat + stem run beside the memory-bound convolutions of sub-batch i instead of beside
+            # another warp/splat (two identical chains started together stay in lockstep: tools/graph_timeline.py).  The
+            # chain continues across the passes of a step: sub-batch 0 of pass p + 1 follows the splat of the last
+            # sub-batch of pass p (and, on its own stream, its own network of pass p)
             streams = [cur] + self.side
+            for st in self.side:
+                st.wait_stream(cur)
             prev = None
-            for i in range(self.S):
-                st = streams[i]
-                if i > 0:
-                    st.wait_event(prev)
-                ev = torch.cuda.Event()
-                self.models[i].after_splat = (lambda e=ev, q=st: e.record(q))
-                with torch.cuda.stream(st):
-                    outs[i] = self.models[i].predict(self.subs[i], None)
-                self.models[i].after_splat = None
-                prev = ev
+            for _ in range(self.passes):
+                for i in range(self.S):
+                    st = streams[i]
+                    if prev is not None:
+                        st.wait_event(prev)
+                    ev = torch.cuda.Event()
+                    self.models[i].after_splat = (lambda e=ev, q=st: e.record(q))
+                    with torch.cuda.stream(st):
+                        outs[i] = self.models[i].predict(self.subs[i], None)
+                    self.models[i].after_splat = None
+                    prev = ev
             for i in range(1, self.S):
                 cur.wait_stream(self.side[i - 1])
             return outs
-        for i in range(1, self.S):
-            self.side[i - 1].wait_stream(cur)
-            with torch.cuda.stream(self.side[i - 1]):
-                outs[i] = self.models[i].predict(self.subs[i], None)
-        outs[0] = self.models[0].predict(self.subs[0], None)
-        for i in range(1, self.S):
-            cur.wait_stream(self.side[i - 1])
+        for _ in range(self.passes):
+            for i in range(1, self.S):
+                self.side[i - 1].wait_stream(cur)
+                with torch.cuda.stream(self.side[i - 1]):
+                    outs[i] = self.models[i].predict(self.subs[i], None)
+            outs[0] = self.models[0].predict(self.subs[0], None)
+            for i in range(1, self.S):
+                cur.wait_stream(self.side[i - 1])
         return outs
 
     def timed_free_run(self, steps, warmup, dev, barrier):
@@ -353,18 +366,18 @@ class Workload:
             torch.distributed.barrier()
         return pfdist.max_over_ranks(time.perf_counter() - t0, dev) if barrier else time.perf_counter() - t0
 
-    def timed(self, steps, warmup, dev, barrier=False, replays=1):
-        """Seconds for `steps` steps (max over ranks when `barrier`), each step = `replays` passes over the resident batch.
-        self.local_s keeps this rank's own time between the two synchronisations."""
+    def timed(self, steps, warmup, dev, barrier=False):
+        """Seconds for `steps` steps (max over ranks when `barrier`), each step = self.passes passes over the resident batch
+        (one graph replay).  self.local_s keeps this rank's own time between the two synchronisations."""
         if self.free_run_ms is not None:
-            return self.timed_free_run(steps * replays, warmup * replays, dev, barrier)
-        for _ in range(warmup * replays):
+            return self.timed_free_run(steps * self.passes, warmup * self.passes, dev, barrier)
+        for _ in range(warmup):
             self.run()
         if barrier and pfdist.is_dist():
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps * replays):
+        for _ in range(steps):
             self.run()
         torch.cuda.synchronize()
         self.local_s = time.perf_counter() - t0
@@ -468,9 +481,10 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='forecast frames per GPU per step (the reference export loop '
-                    'batches 2; throughput saturates around 32-48 frames in flight as two or three concurrent sub-batches of 16)')
-    ap.add_argument('--replays', type=int, default=4, help='passes over the resident batch per step: a step is '
+    ap.add_argument('--batch', type=int, default=64, help='resident forecast frames per GPU, run as --streams concurrent '
+                    'sub-batches (the reference export loop batches 2; throughput saturates at 48-64 frames in flight as three or '
+                    'four staggered sub-batches of 16)')
+    ap.add_argument('--replays', type=int, default=2, help='passes over the resident batch per step (one hipGraph): a step is '
                     '--replays x --batch forecast frames per GPU (20 steps then time about a second)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -481,7 +495,7 @@ def parse_args(argv=None):
                     "(model param split_f16=0): every convolution on v_mfma_f32_16x16x4_f32 / the fp32 VALU")
     ap.add_argument('--streams', type=int, default=0, help='sub-batches run concurrently on this many HIP streams '
                     '(0 = one per 16 frames of the batch)')
-    ap.add_argument('--stagger', type=int, default=0, help='1: sub-batch i + 1 of a step starts when the warp/splat of '
+    ap.add_argument('--stagger', type=int, default=1, help='1: sub-batch i + 1 of a step starts when the warp/splat of '
                     'sub-batch i is done (software pipeline inside the step) instead of all sub-batches starting together')
     ap.add_argument('--free-run', type=float, default=None, metavar='MS', help='experiment: one hipGraph per sub-batch on its '
                     'own stream, no join between steps, sub-batch i starts i * MS late (streams out of phase)')
@@ -549,10 +563,10 @@ def main():
     S = max(1, min(args.streams, B)) if args.streams > 0 else max(1, B // SUB_BATCH)
     use_graph = not args.no_graph
     head_kw = {'split_f16': 0} if args.fp32_mfma_only else {}
-    wl = Workload(sd, B, S, dev, seed0=rank * B, term=args.term, use_graph=use_graph, stagger=bool(args.stagger),
-                  free_run_ms=args.free_run, **head_kw)
     R = max(1, args.replays)
-    elapsed = wl.timed(args.steps, args.warmup, dev, barrier=True, replays=R)
+    wl = Workload(sd, B, S, dev, seed0=rank * B, term=args.term, use_graph=use_graph, stagger=bool(args.stagger),
+                  free_run_ms=args.free_run, passes=R, **head_kw)
+    elapsed = wl.timed(args.steps, args.warmup, dev, barrier=True)
     frames = world * B * R * args.steps
     value = frames / elapsed
     overflow = wl.range_overflow()
@@ -612,6 +626,7 @@ def main():
         parity = parity_of(sub0, head_kw)
 
     if single and not args.no_legs:
+        shared_batch = wl.batch          # the fp32-only leg runs the same resident frames (no second synthetic generation)
         del wl
         torch.cuda.empty_cache()
         # SURVEY.md 8d Config 2: B in {1, 2, 4} frames per step on ONE stream (B=1 is the latency configuration)
@@ -627,8 +642,9 @@ def main():
             torch.cuda.empty_cache()
         if not args.fp32_mfma_only:
             # fp32-instruction configuration: no two-term fp16 operands anywhere (fp32 MFMA / fp32 VALU only)
-            leg = Workload(sd, B, S, dev, seed0=0, term=args.term, use_graph=use_graph, split_f16=0)
-            dt = leg.timed(args.steps, args.warmup, dev, replays=R)
+            leg = Workload(sd, B, S, dev, seed0=0, term=args.term, use_graph=use_graph, stagger=bool(args.stagger), passes=R,
+                           batch=shared_batch, split_f16=0)
+            dt = leg.timed(args.steps, args.warmup, dev)
             fp32_only = {'value': B * R * args.steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / args.steps,
                          'frames_per_gpu_per_step': B * R, 'streams': S, 'dtype': 'f32'}
             recs = profile_records(lambda: leg.models[0].predict(leg.subs[0], None), args.profile_steps)
@@ -658,7 +674,7 @@ def main():
                                         'configs[2]: bg mid-term forecast, 3 frames in, dt=9, predicted-odometry ego chain') +
                                        ', 1024x2048, random-init calibrated weights; step = 3 warp/splats + HarDNet + upsample/argmax',
                            'frames_per_gpu_per_step': B * R, 'resident_frames_per_gpu': B, 'passes_per_step': R, 'streams': S, 'launch': ('hipGraph per sub-batch on free-running streams, offset %g ms' % args.free_run) if (args.free_run is not None and use_graph and S > 1)
-                           else ('hipGraph replay' if use_graph else 'eager'),
+                           else (('hipGraph replay' if use_graph else 'eager') + (', sub-batches staggered (software pipeline across the passes of a step)' if (args.stagger and S > 1) else '')),
                            'sharding': 'batch over %d rank(s), no data-path collective' % world,
                            'world': joined, 'device': torch.cuda.get_device_name(local),
                            'backend': 'nccl (RCCL)' if pfdist.is_dist() else 'single process'},

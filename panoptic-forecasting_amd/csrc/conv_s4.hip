@@ -451,24 +451,26 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
 #endif
 }
 
+int g_s4_lds_pad = 0;   // experiment (pf_set_option "s4_lds_pad"): extra LDS bytes per 3x3 workgroup = fewer resident workgroups per CU
+
 template <int NT, int TW_>
 static int launch_s4_cfg(const ConvArgs &a0, int B, hipStream_t s) {
     using C = S4Cfg<NT, TW_>;
     ConvArgs a = a0;
     a.tilesX = (a.Wout + C::TW - 1) / C::TW;
     a.tilesY = (a.Hout + C::TH - 1) / C::TH;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_set = -1;
+    if (attr_set != g_s4_lds_pad) {
         PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s4_kernel<NT, TW_>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES + g_s4_lds_pad));
+        attr_set = g_s4_lds_pad;
     }
     char label[96];
     snprintf(label, sizeof(label), "void pf::conv_s4_kernel<%d, %d>(pf::ConvArgs)", NT, TW_);
     const double px = (double)B * a.Hout * a.Wout;
     ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * 9,
                  4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * 9));
-    hipLaunchKernelGGL((conv_s4_kernel<NT, TW_>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(256), C::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_s4_kernel<NT, TW_>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(256), C::LDS_BYTES + g_s4_lds_pad, s, a);
     PF_LAUNCH_CHECK("conv_s4_kernel");
     return PF_OK;
 }
@@ -496,7 +498,7 @@ typedef unsigned s4_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned s4_u32x2 __attribute__((ext_vector_type(2)));
 
 template <int NT, int EPI>
-__global__ __launch_bounds__(256) void conv_s4_1x1_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, NT <= 2 ? 4 : (NT == 3 ? 3 : 2)) void conv_s4_1x1_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = S41Cfg<NT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

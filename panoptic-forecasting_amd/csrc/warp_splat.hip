@@ -13,7 +13,8 @@
 //                  -ffp-contract=off; every product/sum rounded separately, IEEE divides) — four pixels per lane in
 //                  lockstep on the packed fp32 pipe with exact shortcuts for affine cameras (project4_fast), the full (project4_full)
 //                  scalar chain otherwise — stored as 8 B per point {bits(z), packed bins}; block max(z) partial; the
-//                  bounding box of the destination bins its points reach (valid or not); optional result2d.  The tile then
+//                  bounding box of the destination bins its VALID points reach; a byte mark per bin reached by an
+//                  INVALID point (plain stores of the constant 1 - no atomics needed); optional result2d.  The tile then
 //                  appends its id to the list of every destination tile its box touches (one global atomicAdd per pair).
 //   raster_kernel  one workgroup (512 threads = two groups of 256, each taking its own source tiles) per 32x128 DESTINATION
 //                  tile: reads its list (kFlight source tiles' 32-B-per-lane records in flight per group at a time; a list that overflowed kListCap falls back to testing every box of the frame), and
@@ -26,11 +27,9 @@
 //
 // Packed key (valid points have z > 0, so raw fp32 bits are monotone as unsigned):
 //     [ bits(z) : 32 | e : 32 ],  e = r*P + t*N + n  (corner replica r, P = T*N)   — pc_transform_model.py:112
-// Invalid points all carry the same depth (max+1, :105) and a zeroed payload (:133), so which of them wins a bin is
-// unobservable: they go through the same z-buffer with ONE constant key above every valid key and below "empty"
-// (kInvalidKey) and reproduce the reference output exactly (seg 0, depth max+1) wherever no valid point lands; untouched bins
-// give seg 0, depth -1 (:136-138).  (Rounds 1-2 kept a byte plane "an invalid point landed here" beside the z-buffer: a
-// memset, 4 scattered byte stores per invalid point and a plane read per pixel - 4.4 of the 32 B/point the pair moved.)
+// Invalid points all carry the same depth (max+1, :105) and a zeroed payload (:133), so which of them wins a
+// bin is unobservable: a per-bin "touched by an invalid point" byte reproduces the reference output exactly
+// (seg 0, depth max+1) wherever no valid point lands; untouched bins give seg 0, depth -1 (:136-138).
 #include "pf_common.h"
 #include "pf_prof.h"
 #include <cstdlib>
@@ -48,7 +47,6 @@ namespace pf {
 long long *probe_buffer();
 
 constexpr unsigned long long kEmpty = ~0ull;
-constexpr unsigned kInvalidHi = 0xFFFFFFFEu;   // high word of the key of every invalid point: above any fp32 z > 0, below kEmpty
 constexpr int kThreads = 256;
 // raster workgroup shape (A/B builds: -DPF_RASTER_THREADS=256 -DPF_RASTER_FLIGHT=8 -DPF_RASTER_MINWAVES=1 is the round-2 start).
 // The kernel waits on dependent memory round trips (list -> records -> LDS -> gather -> store) at a workgroup count per CU
@@ -81,9 +79,10 @@ struct SplatArgs {
     const uint8_t *mask;
     const uint8_t *seg;
     const float *Kinv, *E, *Tt, *Einv, *K;
-    int4 *bbox;           // [B][T][src tiles]  (x0min, y0min, x1max, y1max) of the points' bins
+    int4 *bbox;           // [B][T][src tiles]  (x0min, y0min, x1max, y1max) of valid points' bins
     unsigned *zmax_part;  // [G][kZSlots]       order-preserving u32 of max(z) per z-buffer group (atomicMax, zeroed per call)
-    uint2 *proj;          // [B][T][N]          {bits(z), x0 | y0<<13 | (x1!=x0)<<26 | (y1!=y0)<<27 | valid<<28 | 1<<29}
+    uint8_t *inv_mark;    // [B*G][N]           1 where an invalid point lands
+    uint2 *proj;          // [B][T][N]          {bits(z), x0 | y0<<13 | (x1!=x0)<<26 | (y1!=y0)<<27 | valid<<28}
     unsigned *count;      // [B][G][dst tiles]  fill of the destination tile's list (zeroed per call; > kListCap = overflowed)
     unsigned *lists;      // [B][G][dst tiles][kListCap]  source tiles whose valid points can reach the destination tile
     uint8_t *out_seg;
@@ -346,6 +345,7 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
                   pT = (GlobalF)a.Tt + ((long long)b * a.T_total + t) * 16;
     const bool affine = camera_affine(pKinv, pE, pT, pEinv, pK);
     const int g = a.per_frame ? tl : 0, G = a.per_frame ? a.T : 1;
+    uint8_t *mark = a.inv_mark + ((long long)b * G + g) * N;
     long long *r2d = a.out_r2d ? a.out_r2d + ((long long)b * a.T + tl) * N * 2 : nullptr;
     const float Wf = (float)a.W, Hf = (float)a.H;
 
@@ -367,17 +367,26 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
             zmax = fmaxf(zmax, p.z);   // :105 max runs over valid and invalid points alike
             pk[2 * k] = __float_as_uint(p.z);
             pk[2 * k + 1] = (unsigned)p.x0 | ((unsigned)p.y0 << 13) | ((unsigned)(p.x1 != p.x0) << 26) |
-                            ((unsigned)(p.y1 != p.y0) << 27) | ((unsigned)p.valid << 28) | (1u << 29);   // bit 29: a record
+                            ((unsigned)(p.y1 != p.y0) << 27) | ((unsigned)p.valid << 28);
             if ((a.W & 3) != 0) pj[k] = make_uint2(pk[2 * k], pk[2 * k + 1]);
             if (r2d) {
                 const long long n = (long long)y * a.W + x + k;
                 r2d[n * 2] = p.x0;      // :147 floor/floor corner after the clamp
                 r2d[n * 2 + 1] = p.y0;
             }
-            // every point is rasterised, valid or not (an invalid one with the constant key kInvalidHi): the box covers all.
-            // Bins are clamped to the image, so even a non-finite projection (bin 0) only stretches this tile's box
-            bx0 = min(bx0, p.x0); by0 = min(by0, p.y0);
-            bx1 = max(bx1, p.x1); by1 = max(by1, p.y1);
+            if (p.valid) {
+                bx0 = min(bx0, p.x0); by0 = min(by0, p.y0);
+                bx1 = max(bx1, p.x1); by1 = max(by1, p.y1);
+            } else {
+                // every invalid point carries depth max+1 and payload 0: marking its bins is enough (32-bit offsets from
+                // the uniform base: N < 2^30 is checked at launch)
+                const unsigned o00 = (unsigned)p.y0 * (unsigned)a.W + (unsigned)p.x0, dxo = (unsigned)(p.x1 - p.x0);
+                const unsigned o10 = (unsigned)p.y1 * (unsigned)a.W + (unsigned)p.x0;
+                mark[o00] = 1;
+                mark[o10] = 1;
+                mark[o00 + dxo] = 1;
+                mark[o10 + dxo] = 1;
+            }
         }
         if ((a.W & 3) == 0) {   // the raster pass re-reads these instead of re-projecting (coalesced 32 B per thread)
             reinterpret_cast<uint4 *>(pj)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
@@ -494,8 +503,7 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned f = pk[2 * k + 1];
-            if (!((f >> 29) & 1u)) continue;   // no record (lanes past the image, list padding)
-            const bool val = ((f >> 28) & 1u) != 0u;
+            if (!((f >> 28) & 1u)) continue;   // invalid points were handled by the byte marks
             const unsigned rx0 = (f & 8191u) - (unsigned)dx0, ry0 = ((f >> 13) & 8191u) - (unsigned)dy0;
             const unsigned fx = (f >> 26) & 1u, fy = (f >> 27) & 1u;
             const unsigned rx1 = rx0 + fx, ry1 = ry0 + fy;
@@ -503,9 +511,8 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
             // on the bin of a lower replica of the same point can never win the tie-break: skip it.
             const bool in_x0 = rx0 < (unsigned)kDstTW, in_x1 = rx1 < (unsigned)kDstTW && fx != 0u;
             const bool in_y0 = ry0 < (unsigned)kDstTH, in_y1 = ry1 < (unsigned)kDstTH && fy != 0u;
-            // an invalid point: one constant key for all its replicas (every invalid point carries depth max + 1 and payload 0)
-            const unsigned e0 = val ? e_first + (unsigned)k : 0u;
-            const unsigned long long khi = (unsigned long long)(val ? pk[2 * k] : kInvalidHi) << 32;
+            const unsigned e0 = e_first + (unsigned)k;
+            const unsigned long long khi = (unsigned long long)pk[2 * k] << 32;
             if (in_x0 && in_y0) atomicMin(&zb[ry0 * kDstTW + rx0], khi | e0);
             if (in_x0 && in_y1) atomicMin(&zb[ry1 * kDstTW + rx0], khi | (e0 + Pu1));
             if (in_x1 && in_y0) atomicMin(&zb[ry0 * kDstTW + rx1], khi | (e0 + 2u * Pu1));
@@ -605,6 +612,7 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
 
     // ---- resolve this tile's pixels (:120-139): 4 consecutive pixels per lane, all loads issued before any is used
     const float sentinel = sentinel_s;
+    const uint8_t *mark = a.inv_mark + ((long long)b * G + g) * N;
     const long long out_base = ((long long)b * G + g) * N;
     const long long seg_base = ((long long)b * a.T_total + a.t_first + (a.per_frame ? g : 0)) * N;
     const int C = a.C;
@@ -621,24 +629,31 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
         const unsigned n0 = (unsigned)y * (unsigned)a.W + (unsigned)x;
         unsigned zbits[4], src[4];
         bool empty[4];
-        uint8_t sg[4];
+        uint8_t mk[4], sg[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned long long key = zb[i4 * 4 + k];
             zbits[k] = (unsigned)(key >> 32);
-            empty[k] = zbits[k] >= kInvalidHi;           // kEmpty or won by an invalid point; a valid z > 0 is below both patterns
+            empty[k] = zbits[k] == 0xFFFFFFFFu;          // kEmpty; a valid point's z > 0 is never the all-ones pattern
             unsigned e = (unsigned)key;                  // e = r*P + t*N + n with r < 4: strip the corner replica
             e -= e >= 2u * Pu ? 2u * Pu : 0u;
             e -= e >= Pu ? Pu : 0u;
             src[k] = empty[k] ? 0u : e;                  // always a readable address
+        }
+        if ((a.W & 3) == 0) {
+            const uchar4 mv = *reinterpret_cast<const uchar4 *>(mark + n0);
+            mk[0] = mv.x; mk[1] = mv.y; mk[2] = mv.z; mk[3] = mv.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mk[k] = x + k < a.W ? mark[n0 + k] : (uint8_t)0;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) sg[k] = C == 1 ? segp[src[k]] : (uint8_t)0;
         float dep[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            // no valid point: won by an invalid one (:105,:133) -> max+1, or never touched (:136-138) -> -1
-            dep[k] = !empty[k] ? __uint_as_float(zbits[k]) : (zbits[k] == kInvalidHi ? sentinel : -1.0f);
+            // empty bin: won by an invalid point (:105,:133) -> max+1, or never touched (:136-138) -> -1
+            dep[k] = !empty[k] ? __uint_as_float(zbits[k]) : (mk[k] ? sentinel : -1.0f);
             if (empty[k]) sg[k] = 0;
         }
         if ((a.W & 3) == 0) {
@@ -664,7 +679,7 @@ __global__ __launch_bounds__(kRThreads, PF_RASTER_MINWAVES) void raster_kernel(S
 }
 
 struct SplatLayout {
-    size_t bbox_off, zmax_off, count_off, clear_end, proj_off, lists_off, total;
+    size_t bbox_off, zmax_off, count_off, mark_off, mark_bytes, proj_off, lists_off, total;
     int stx, sty, dtx, dty;
 };
 
@@ -675,11 +690,12 @@ static SplatLayout splat_layout(int B, int T, int H, int W, int per_frame) {
     const size_t ntile = (size_t)L.stx * L.sty, N = (size_t)H * W;
     L.bbox_off = 0;
     L.zmax_off = align_up(L.bbox_off + (size_t)B * T * ntile * sizeof(int4), 256);
-    // zmax slots and list counters are contiguous: one small memset per call
+    // zmax slots, list counters and marks are contiguous: one memset per call
     const size_t ndst = (size_t)L.dtx * L.dty, G = per_frame ? T : 1;
     L.count_off = align_up(L.zmax_off + (size_t)B * T * kZSlots * sizeof(unsigned), 256);
-    L.clear_end = align_up(L.count_off + B * G * ndst * sizeof(unsigned), 256);
-    L.proj_off = L.clear_end;
+    L.mark_off = align_up(L.count_off + B * G * ndst * sizeof(unsigned), 256);
+    L.mark_bytes = (size_t)B * G * N;
+    L.proj_off = align_up(L.mark_off + L.mark_bytes, 256);
     L.lists_off = align_up(L.proj_off + (size_t)B * T * N * sizeof(uint2), 256);
     L.total = align_up(L.lists_off + B * G * ndst * kListCap * sizeof(unsigned), 256);
     return L;
@@ -722,6 +738,7 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     a.Kinv = Kinv; a.E = E; a.Tt = T_tgt; a.Einv = Einv; a.K = K;
     a.bbox = (int4 *)((char *)ws + L.bbox_off);
     a.zmax_part = (unsigned *)((char *)ws + L.zmax_off);
+    a.inv_mark = (uint8_t *)ws + L.mark_off;
     a.proj = (uint2 *)((char *)ws + L.proj_off);
     a.count = (unsigned *)((char *)ws + L.count_off);
     a.lists = (unsigned *)((char *)ws + L.lists_off);
@@ -740,8 +757,11 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
 
     // algorithmic bytes: source side depth 4 + mask 1 B/px; destination side seg 1 in, seg 1 + depth 4 out
     const double src_px = (double)B * T * H * W, dst_px = (double)B * G * H * W;
-    // zmax slots (ordered-u32 encoding: 0 is below every float) + list counters: a few KB
-    PF_HIP_CHECK(hipMemsetAsync(a.zmax_part, 0, L.clear_end - L.zmax_off, s));
+    {
+        pf::ProfScope ps(s, "inv_mark_memset", 0, (double)L.mark_bytes);
+        // zmax slots (ordered-u32 encoding: 0 is below every float) + invalid-point marks, contiguous
+        PF_HIP_CHECK(hipMemsetAsync(a.zmax_part, 0, (L.mark_off - L.zmax_off) + L.mark_bytes, s));
+    }
     {
         pf::ProfScope ps(s, "pf::bin_kernel(pf::SplatArgs)", 0, src_px * (5.0 + (out_result2d ? 16.0 : 0.0)));
         hipLaunchKernelGGL(pf::bin_kernel, dim3(L.stx * L.sty, T, B), dim3(pf::kThreads), 0, s, a);
