@@ -1,0 +1,311 @@
+// The 512x1024 front end in one pass: base.1 (3x3, stride 1) and base.2 (3x3, stride 2) of FC-HarDNet (hardnet.py:274-283)
+// as ONE kernel - the tensor between them (24 channels at half resolution: 100 MB per 1024x2048 frame, written and read back,
+// 39 % of the bytes the three front-end kernels moved) never leaves LDS.
+//
+// Round 2 ran stem -> conv_split<2, 64> (438 us per 16 frames, 3.1 TB/s of algorithmic bytes: bound by the fabric) ->
+// conv_dma stride 2 (332 us, fp32 MFMA): 1.09 ms of a 7.2 ms step.  Here the stem writes the packed-pair layout of
+// conv_mfma.h (two fp16 terms per value, [B][2][C/4][H][W][4]) and a workgroup of 5 waves produces a 2 x 32-pixel tile of
+// the stride-2 conv's output:
+//   1. the 7 x 68-pixel window of the stem output it needs arrives by LDS-DMA (8 planes = 2 terms x 4 channel groups; out-of-
+//      image pieces land as zeros = the first conv's padding);
+//   2. wave r computes row r of the 5 x 65 intermediate region (5 M-tiles of 16 pixels x 2 cout tiles) with the dense-tap
+//      scheme of conv_s4.hip (two full matrix instructions per 8 channels + the collected ninth tap), weights straight from
+//      L2 into registers one block ahead (no LDS space);
+//   3. bias, ReLU, zero outside the image (the second conv's padding), split into the two fp16 terms, and into LDS - odd and
+//      even columns in separate planes, so that a lane's stride-2 pixel (2 ox + kx) is a stride-1 slot for the second conv;
+//   4. waves 0..3 compute one 16-pixel M-tile x 2 cout tiles of the stride-2 conv from those planes;
+//   5. bias, ReLU, range guard, packed-pair (or fp32 NCHW) store.
+// The intermediate region is recomputed at tile borders (5 rows for 4, 65 columns for 64: 1.27x the first conv's flops).
+// Arithmetic per layer is that of conv_s4.hip: three fp16 products per fp32 multiply, fp32 accumulation, round-to-nearest
+// split (operand bound 2^-23), weights pre-scaled by a power of two.
+#include "conv_epilogue.h"
+#include "pf_prof.h"
+
+namespace pf {
+
+typedef float fr_f32x4 __attribute__((ext_vector_type(4)));
+typedef split_x8 fr_h8;
+typedef split_x4 fr_h4;
+typedef __attribute__((address_space(3))) void *fr_lds_ptr_t;
+[[maybe_unused]] constexpr unsigned kFrOob = 0x80000000u;
+
+struct FrontCfg {
+    static constexpr int TH2 = 2, TW2 = 32;            // output tile of the stride-2 conv
+    static constexpr int YR = 2 * TH2 + 1;             // rows of the intermediate region (5)
+    static constexpr int YC = 2 * TW2 + 1;             // ... and columns (65)
+    static constexpr int MT1 = (YC + 15) / 16;         // M-tiles per intermediate row (5; the last holds one column)
+    static constexpr int XR = YR + 2, XC = YC + 3;     // stem window: 7 rows x 68 pixels (starts at an even column)
+    static constexpr int XPIECES = XR * (XC / 2);      // 16-B pieces (2 pixels x 4 channels of one term) per plane
+    static constexpr int XPLANE = XPIECES * 16;        // bytes
+    static constexpr int C0G = 4, C1G = 6;             // channel groups of the stem output (16) and of the intermediate (24)
+    static constexpr int XBYTES = 2 * C0G * XPLANE;    // [term][group] planes
+    static constexpr int YS = 34;                      // slots per parity row (33 used by the odd-column plane)
+    static constexpr int YPLANE = YR * YS * 8;         // bytes per (term, group, parity) plane
+    static constexpr int YBYTES = 2 * C1G * 2 * YPLANE;
+    static constexpr int BIAS_OFF = XBYTES + YBYTES;   // 2 x 32 floats
+    static constexpr int LDS_BYTES = BIAS_OFF + 256;
+    static constexpr int NTHR = 64 * YR;               // one wave per intermediate row
+    static constexpr int NDMA = (2 * C0G * XPIECES + NTHR - 1) / NTHR;
+};
+
+__device__ __forceinline__ fr_h8 fr_join(fr_h4 lo, fr_h4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+// one block of packed weights for both cout tiles: [tile][block][term][lane][8 fp16], straight from L2
+struct FrW {
+    fr_h8 h[2], m[2];
+};
+__device__ __forceinline__ FrW fr_load_w(const void *w, int nblocks, int blk, int lane) {
+    FrW r;
+    const char *p = reinterpret_cast<const char *>(w) + ((size_t)blk * 2 * 64 + lane) * 16;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        r.h[n] = *reinterpret_cast<const fr_h8 *>(p + (size_t)n * nblocks * 2 * 64 * 16);
+        r.m[n] = *reinterpret_cast<const fr_h8 *>(p + (size_t)n * nblocks * 2 * 64 * 16 + 64 * 16);
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(FrontCfg::NTHR, 3) void conv_front_kernel(FrontArgs a) {   // 2 workgroups of 5 waves per CU: up to 3 waves on a SIMD
+#if defined(__HIP_DEVICE_COMPILE__)
+    using C = FrontCfg;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *xs = smem, *ys = smem + C::XBYTES;
+    float *bias_lds = reinterpret_cast<float *>(smem + C::BIAS_OFF);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_lin, dummy;
+    xcd_tile_order(a.tilesX * a.tilesY, tile_lin, dummy);
+    const int tileY = tile_lin / a.tilesX, tileX = tile_lin - tileY * a.tilesX, b = blockIdx.z;
+    const int oy0 = tileY * C::TH2, ox0 = tileX * C::TW2;
+    const int yr0 = 2 * oy0 - 1, yc0 = 2 * ox0 - 1;      // intermediate region origin (stride-1 coordinates)
+    const int xr0 = yr0 - 1, xc0 = yc0 - 1;              // stem window origin; xc0 = 2 ox0 - 2 is even
+
+    // ---- 1. stem window -> LDS (one DMA burst; everything the first conv reads), bias values of both convs
+    {
+        const size_t plane_bytes = (size_t)a.H1 * a.W1 * 8;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(reinterpret_cast<const char *>(a.x) + (size_t)b * 2 * C::C0G * plane_bytes), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < C::NDMA; ++it) {
+            const int p = it * C::NTHR + tid;
+            const int pl = p / C::XPIECES, q = p - pl * C::XPIECES;
+            const int row = q / (C::XC / 2), cp = q - row * (C::XC / 2);
+            const int gy = xr0 + row, gx = xc0 + 2 * cp;
+            const bool ok = p < 2 * C::C0G * C::XPIECES && gy >= 0 && gy < a.H1 && gx >= 0 && gx < a.W1;
+            const unsigned off = ok ? (unsigned)(pl * plane_bytes) + (unsigned)(gy * a.W1 + gx) * 8u : kFrOob;
+            if (p < 2 * C::C0G * C::XPIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (fr_lds_ptr_t)(xs + (it * C::NTHR + wave * 64) * 16), 16, off, 0, 0, 0);
+        }
+        if (wave == 0) {
+            const __amdgpu_buffer_rsrc_t b1 = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias1, 0, 0x7FFFFFFF, 0x00020000);
+            const __amdgpu_buffer_rsrc_t b2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias2, 0, 0x7FFFFFFF, 0x00020000);
+            if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(b1, (fr_lds_ptr_t)bias_lds, 4, (unsigned)lane * 4u, 0, 0, 0);
+            if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(b2, (fr_lds_ptr_t)(bias_lds + 32), 4, (unsigned)lane * 4u, 0, 0, 0);
+        }
+    }
+    const int g = lane >> 4, li = lane & 15;
+    // tap of lane group g in the two full instructions / the collected tap (conv_s4.hip): (ky, kx)
+    const int ky0 = g >> 1, kx0 = g & 1, ky1 = g < 2 ? 2 : g - 2, kx1 = g < 2 ? g : 2;
+    const fr_h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- 2. first conv: wave r = row r of the intermediate region, 5 M-tiles x 2 cout tiles
+    constexpr int NB1 = 5;     // s4_blocks_total(2 rounds)
+    fr_f32x4 acc[C::MT1][2];
+#pragma unroll
+    for (int m = 0; m < C::MT1; ++m) acc[m][0] = acc[m][1] = fr_f32x4{0.f, 0.f, 0.f, 0.f};
+    FrW wcur = fr_load_w(a.w1, NB1, 0, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window (and the first weight block) have landed
+    __syncthreads();
+    {
+        const int r = wave;
+        fr_h8 col_h[C::MT1], col_m[C::MT1];
+#pragma unroll
+        for (int m = 0; m < C::MT1; ++m) col_h[m] = col_m[m] = zero8;
+        auto xfrag = [&](int rd, int ky, int kx, int m, fr_h8 &h, fr_h8 &md) {
+            // entries 2 rd, 2 rd + 1 of term 0 / 1: plane (term * 4 + entry)
+            const unsigned char *p = xs + ((r + ky) * C::XC + 16 * m + li + kx) * 8 + (2 * rd) * C::XPLANE;
+            h = fr_join(*reinterpret_cast<const fr_h4 *>(p), *reinterpret_cast<const fr_h4 *>(p + C::XPLANE));
+            md = fr_join(*reinterpret_cast<const fr_h4 *>(p + C::C0G * C::XPLANE), *reinterpret_cast<const fr_h4 *>(p + (C::C0G + 1) * C::XPLANE));
+        };
+        auto mfma3 = [&](const FrW &w, int m, const fr_h8 &fh, const fr_h8 &fm) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                acc[m][n] = PF_MFMA_SPLIT(w.h[n], fm, acc[m][n]);
+                acc[m][n] = PF_MFMA_SPLIT(w.m[n], fh, acc[m][n]);
+                acc[m][n] = PF_MFMA_SPLIT(w.h[n], fh, acc[m][n]);
+            }
+        };
+        int blk = 0;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const FrW wnext = fr_load_w(a.w1, NB1, blk + 1, lane);   // (the block after the last full one is the collected block)
+                const int ky = s == 0 ? ky0 : ky1, kx = s == 0 ? kx0 : kx1;
+#pragma unroll
+                for (int m = 0; m < C::MT1; ++m) {
+                    fr_h8 fh, fm;
+                    xfrag(rd, ky, kx, m, fh, fm);
+                    mfma3(wcur, m, fh, fm);
+                }
+                wcur = wnext;
+                ++blk;
+            }
+            if (g == rd) {   // the ninth tap of this round's entries: K-slice rd of the collected instruction
+#pragma unroll
+                for (int m = 0; m < C::MT1; ++m) xfrag(rd, 2, 2, m, col_h[m], col_m[m]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < C::MT1; ++m) mfma3(wcur, m, col_h[m], col_m[m]);
+
+        // ---- 3. bias, ReLU, zero outside the image, split, -> LDS (odd / even columns in separate planes)
+        const int gy = yr0 + r;
+        const bool row_in = gy >= 0 && gy < a.H1;
+#pragma unroll
+        for (int m = 0; m < C::MT1; ++m) {
+            const int j = 16 * m + li;                   // local column of this lane's pixel
+            if (j >= C::YC) continue;
+            const int gx = yc0 + j;
+            const bool in = row_in && gx >= 0 && gx < a.W1;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int gi = n * 4 + g;                // channel group of the intermediate tensor
+                if (gi >= C::C1G) continue;
+                const fr_f32x4 b4 = *reinterpret_cast<const fr_f32x4 *>(bias_lds + n * 16 + 4 * g);
+                fr_f32x4 v = acc[m][n];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = v[q] * a.scale1 + b4[q];
+                    if (a.relu1) v[q] = fmaxf(v[q], 0.f);
+                    v[q] = in ? v[q] : 0.f;              // the second conv's zero padding
+                }
+                range_commit(a.status, range_acc(0.f, v[0], v[1], v[2], v[3]));   // (rare path: never taken in range)
+                fr_h4 hi, mid;
+                split_terms4(v, hi, mid);
+                unsigned char *p = ys + (size_t)(gi * 2 + (j & 1)) * C::YPLANE + (r * C::YS + (j >> 1)) * 8;
+                *reinterpret_cast<fr_h4 *>(p) = hi;
+                *reinterpret_cast<fr_h4 *>(p + C::C1G * 2 * C::YPLANE) = mid;
+            }
+        }
+    }
+    constexpr int NB2 = 7;     // s4_blocks_total(3 rounds)
+    FrW w2 = fr_load_w(a.w2, NB2, 0, lane);
+    __syncthreads();
+
+    // ---- 4. second conv (stride 2): waves 0..3 = (output row, 16-pixel half), both cout tiles
+    if (wave < 4) {
+        const int ry = wave >> 1, hx = wave & 1;
+        fr_f32x4 acc2[2] = {fr_f32x4{0.f, 0.f, 0.f, 0.f}, fr_f32x4{0.f, 0.f, 0.f, 0.f}};
+        // local column 2 (16 hx + i) + kx: kx = 0, 2 -> the j-even plane (slots i, i + 1), kx = 1 -> the j-odd plane (slot i)
+        auto yfrag = [&](int rd, int ky, int kx, fr_h8 &h, fr_h8 &md) {
+            const int par = kx & 1, slot = 16 * hx + li + (kx >> 1);
+            const unsigned char *p = ys + (size_t)((2 * rd) * 2 + par) * C::YPLANE + ((2 * ry + ky) * C::YS + slot) * 8;
+            h = fr_join(*reinterpret_cast<const fr_h4 *>(p), *reinterpret_cast<const fr_h4 *>(p + 2 * C::YPLANE));
+            md = fr_join(*reinterpret_cast<const fr_h4 *>(p + C::C1G * 2 * C::YPLANE),
+                         *reinterpret_cast<const fr_h4 *>(p + (C::C1G * 2 + 2) * C::YPLANE));
+        };
+        auto mfma3 = [&](const FrW &w, const fr_h8 &fh, const fr_h8 &fm) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                acc2[n] = PF_MFMA_SPLIT(w.h[n], fm, acc2[n]);
+                acc2[n] = PF_MFMA_SPLIT(w.m[n], fh, acc2[n]);
+                acc2[n] = PF_MFMA_SPLIT(w.h[n], fh, acc2[n]);
+            }
+        };
+        fr_h8 col_h = zero8, col_m = zero8;
+        int blk = 0;
+#pragma unroll
+        for (int rd = 0; rd < 3; ++rd) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const FrW wnext = fr_load_w(a.w2, NB2, blk + 1, lane);
+                fr_h8 fh, fm;
+                yfrag(rd, s == 0 ? ky0 : ky1, s == 0 ? kx0 : kx1, fh, fm);
+                mfma3(w2, fh, fm);
+                w2 = wnext;
+                ++blk;
+            }
+            if (g == rd) yfrag(rd, 2, 2, col_h, col_m);
+        }
+        mfma3(w2, col_h, col_m);
+
+        // ---- 5. bias, ReLU, range guard, store: lane (g, i) = couts 4g..4g+3 of output pixel (oy0 + ry, ox0 + 16 hx + i)
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) the compiler can see: nothing left to protect inside the stores (conv_s4.hip)
+        const int oy = oy0 + ry, ox = ox0 + 16 * hx + li;
+        if (oy < a.H2 && ox < a.W2) {
+            const size_t hw = (size_t)a.H2 * a.W2, pix = (size_t)oy * a.W2 + ox;
+            const size_t term = (size_t)a.dst_c4 * hw * 8;
+            const bool mis = (a.dst_choff & 2) != 0;
+            float vmax = 0.f;
+            typedef split_x2 h2;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int co = n * 16 + 4 * g;
+                if (co >= a.C2 + 2) continue;
+                const fr_f32x4 b4 = *reinterpret_cast<const fr_f32x4 *>(bias_lds + 32 + n * 16 + 4 * g);
+                fr_f32x4 v = acc2[n];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = v[q] * a.scale2 + b4[q];
+                    if (a.relu2) v[q] = fmaxf(v[q], 0.f);
+                }
+                vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
+                if (a.dst_fmt) {
+                    fr_h4 hi, mid;
+                    split_terms4(v, hi, mid);
+                    const int chb = a.dst_choff + co;
+                    const bool ok0 = chb < a.dst_limit, ok1 = chb + 2 < a.dst_limit;
+                    char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
+                    if (!mis) {
+                        if (ok1) {
+                            *reinterpret_cast<fr_h4 *>(p) = hi;
+                            *reinterpret_cast<fr_h4 *>(p + term) = mid;
+                        } else if (ok0) {
+                            *reinterpret_cast<h2 *>(p) = h2{hi[0], hi[1]};
+                            *reinterpret_cast<h2 *>(p + term) = h2{mid[0], mid[1]};
+                        }
+                    } else {
+                        if (ok0) {
+                            *reinterpret_cast<h2 *>(p + 4) = h2{hi[0], hi[1]};
+                            *reinterpret_cast<h2 *>(p + 4 + term) = h2{mid[0], mid[1]};
+                        }
+                        if (ok1) {
+                            *reinterpret_cast<h2 *>(p + hw * 8) = h2{hi[2], hi[3]};
+                            *reinterpret_cast<h2 *>(p + hw * 8 + term) = h2{mid[2], mid[3]};
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (co + q < a.C2) a.dst[((size_t)b * a.dst_ctotal + a.dst_choff + co + q) * hw + pix] = v[q];
+                }
+            }
+            range_commit(a.status, vmax);
+        }
+    }
+#endif
+}
+
+// shapes this kernel is built for: 16 -> C1 <= 24 -> C2 <= 32 channels, 3x3 stride 1 then 3x3 stride 2, even width
+bool conv_front_supports(int c0, int c1, int c2, int h1, int w1) { return c0 == 16 && c1 == 24 && c2 <= 32 && c2 > 16 && (w1 & 3) == 0 && h1 >= 2; }
+
+int launch_conv_front(const FrontArgs &a0, int B, hipStream_t s) {
+    using C = FrontCfg;
+    FrontArgs a = a0;
+    a.tilesX = (a.W2 + C::TW2 - 1) / C::TW2;
+    a.tilesY = (a.H2 + C::TH2 - 1) / C::TH2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    const double px1 = (double)B * a.H1 * a.W1, px2 = (double)B * a.H2 * a.W2;
+    ProfScope ps(s, "pf::conv_front_kernel(pf::FrontArgs)", 2.0 * 9 * (px1 * 16 * a.C1 + px2 * a.C1 * a.C2),
+                 4.0 * (px1 * 16 + px2 * a.C2 + 9.0 * (16 * a.C1 + a.C1 * a.C2)));
+    hipLaunchKernelGGL(conv_front_kernel, dim3(a.tilesX * a.tilesY, 1, B), dim3(C::NTHR), C::LDS_BYTES, s, a);
+    PF_LAUNCH_CHECK("conv_front_kernel");
+    return PF_OK;
+}
+
+}  // namespace pf

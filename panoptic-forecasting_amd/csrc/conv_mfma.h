@@ -234,6 +234,23 @@ int launch_s4_pack(const float *src, void *dst, int B, int C, int H, int W, unsi
 int launch_range_check(const float *x, size_t n, unsigned *status, hipStream_t stream);
 int launch_s4_unpack(const void *src, float *dst, int B, int C, int H, int W, hipStream_t stream);
 
+// Fused front end (conv_front.hip): 3x3 stride-1 conv (16 -> 24 channels) + 3x3 stride-2 conv (24 -> <= 32) in one kernel; the
+// input is the stem output in the packed-pair layout, the tensor between the two convs stays in LDS
+struct FrontArgs {
+    const void *x;          // stem output, packed pairs [B][2][4][H1][W1][4] fp16
+    const void *w1, *w2;    // pack_conv_weights_s4() of the two convs (already scaled by 2^k)
+    const float *bias1, *bias2;   // zero padded to 32
+    float scale1, scale2;   // 2^-k
+    float *dst;             // [B][dst_ctotal][H2][W2] fp32 or packed pairs
+    int dst_fmt, dst_c4, dst_ctotal, dst_choff, dst_limit;
+    int H1, W1, H2, W2, C1, C2, relu1, relu2;
+    int tilesX, tilesY;
+    unsigned *status;
+};
+
+bool conv_front_supports(int c0, int c1, int c2, int h1, int w1);
+int launch_conv_front(const FrontArgs &a, int B, hipStream_t s);
+
 // Kernel/shape choice for one stride-1 conv (conv_select.cpp): kind 1 = conv_dma (p0 = WM, p1 = NT),
 // kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK), kind 3 = conv_valu (p0 = rows per wave),
 // kind 4 = conv_split (p0 = NT, p1 = 1: 8x64-pixel tiles), kind 5 = conv_s4 (same parameters; S4 sources).

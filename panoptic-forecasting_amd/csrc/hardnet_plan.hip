@@ -37,6 +37,8 @@ struct ConvPlan {
     size_t s4_off = 0;    // conv_s4.hip packing (stride-1 3x3 and 1x1), else 0
     int s4_rounds = 0;
     bool has_s4 = false, s4_pad = false;   // s4_pad: ranges padded to whole rounds (the conv may run one range at a time)
+    size_t front_off = 0; // conv_s4-style packing of a 3x3 STRIDE-2 conv with one input range (second conv of conv_front.hip), else 0
+    bool has_front = false;
     float split_acc_scale = 1.0f;          // 2^-k: the split / S4 packings hold fp16 terms of w * 2^k (conv_mfma.h)
 };
 
@@ -53,6 +55,7 @@ struct pf_plan {
     // (pf_set_option) when the plan is created and read only by forwards of this plan
     int opt_fuse_pool = 1, opt_fuse_upsample = 1, opt_valu_rem = 1, opt_split = 1, opt_use_tuned = 1;
     int opt_table_batch = 0;   // > 0: per-layer kernel choice as if the batch were this (batch-invariant numerics)
+    int opt_fuse_front = 0;    // stem -> conv_front.hip (3x3 s1 + 3x3 s2 in one kernel, the tensor between them never stored)
     int opt_range_guard = 1;   // kernels raise PF_STATUS_RANGE in the workspace's status word when they store |v| > 65504 while
                                // two-term fp16 operands are in use (conv_mfma.h); 0 = no checks (the clamp-free fp32 path needs none)
     int opt_packed_acts = 1;   // tensors whose producers and consumers all support it live in the S4 layout (conv_s4.hip)
@@ -62,7 +65,7 @@ struct pf_plan {
 
 namespace pf {
 int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_split = 1, g_opt_packed_acts = 1, g_opt_tag_ops = 0;
-int g_opt_range_guard = 1;
+int g_opt_range_guard = 1, g_opt_fuse_front = 0;   // fuse_front: built and bit-checked, measured slower than the three kernels (profiles/r03_experiments.md)
 extern int g_opt_use_tuned;
 extern int g_s4_lds_pad;
 }
@@ -76,6 +79,7 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "split_f16") || !strcmp(name, "split_bf16")) g_opt_split = value;   // (round-1 name kept)
     else if (!strcmp(name, "packed_acts")) g_opt_packed_acts = value;
     else if (!strcmp(name, "range_guard")) g_opt_range_guard = value;
+    else if (!strcmp(name, "fuse_front")) g_opt_fuse_front = value;
     else if (!strcmp(name, "profile_tag_ops")) g_opt_tag_ops = value;
     else if (!strcmp(name, "s4_lds_pad")) g_s4_lds_pad = value < 0 ? 0 : value;   // experiment: profiles/r03_experiments.md
     else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);
@@ -91,6 +95,7 @@ extern "C" int pf_hardnet_plan_set_option(pf_plan *p, const char *name, int valu
     else if (!strcmp(name, "split_f16") || !strcmp(name, "split_bf16")) p->opt_split = value;
     else if (!strcmp(name, "packed_acts")) p->opt_packed_acts = value;
     else if (!strcmp(name, "range_guard")) p->opt_range_guard = value;
+    else if (!strcmp(name, "fuse_front")) p->opt_fuse_front = value;
     else if (!strcmp(name, "table_batch")) p->opt_table_batch = value < 0 ? 0 : value;
     else return fail(PF_EINVAL, "pf_hardnet_plan_set_option: unknown option '%s'", name);
     return PF_OK;
@@ -409,6 +414,83 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             for (uint32_t j = 0; j < op.n_src; ++j) cand[op.src[j].tensor] = 0;
             cand[op.dst] = 0;
         };
+        // stem -> [3x3 s1 16 -> 24] -> [3x3 s2 24 -> <= 32] with single readers: the two convs run as conv_front.hip on the
+        // packed-pair stem output; the tensor between them is never stored
+        bool front = false;
+        if (o.kind == OP_STEM && stem && s4_allowed && p->opt_fuse_front && i + 2 < p->ops.size()) {
+            const BlobOp &n1 = p->ops[i + 1], &n2 = p->ops[i + 2];
+            StemArgs probe = *stem;
+            probe.wdep = p->dev_weights + p->conv[i].dep_off;
+            probe.woh = p->conv[i].has_oh ? p->dev_weights + p->conv[i].oh_off : nullptr;
+            probe.Hout = out.h; probe.Wout = out.w;
+            front = n1.kind == OP_CONV && n1.k == 3 && n1.stride == 1 && n1.n_src == 1 && n1.src[0].tensor == o.dst && n1.src[0].choff == 0 &&
+                    n1.src[0].ch == p->tensors[o.dst].channels && n1.dst_choff == 0 && n1.cout == p->tensors[n1.dst].channels &&
+                    p->readers[o.dst] == 1 && p->readers[n1.dst] == 1 && n1.relu && p->conv[i + 1].has_s4 && p->conv[i + 1].s4_rounds == 2 &&
+                    n2.kind == OP_CONV && n2.k == 3 && n2.stride == 2 && n2.n_src == 1 && n2.src[0].tensor == n1.dst && n2.src[0].choff == 0 &&
+                    n2.src[0].ch == n1.cout && p->conv[i + 2].has_front && (n2.dst_choff & 1) == 0 &&
+                    conv_front_supports((int)o.cout, (int)n1.cout, (int)n2.cout, out.h, out.w) && stem_writes_s4(probe) && g_conv_force.kind == 0;
+        }
+        if (front) {
+            const BlobOp &n1 = p->ops[i + 1], &n2 = p->ops[i + 2];
+            const Dims o2 = d[n2.dst];
+            if (dry) {
+                cand[o.dst] = 0; cand[n1.dst] = 0;   // (not subject to the format decision: the stem output is packed, the middle tensor never exists)
+                ConvRec r;
+                memset(&r, 0, sizeof(r));
+                r.dst_t = n2.dst;
+                r.sb = r.se = 0;
+                r.can_read = false; r.can_write = true; r.can_write_s4 = true;
+                std::vector<uint8_t> &wr = written[n2.dst];
+                const int lo = (int)n2.dst_choff, hi = lo + (int)n2.cout;
+                if ((lo & 3) == 2 && !wr[lo - 2]) cand[n2.dst] = 0;
+                r.dst_limit = ((hi & 3) != 0 && !wr[hi]) ? (hi + 3) / 4 * 4 : hi;
+                for (int c = lo; c < hi; ++c) wr[c] = 1;
+                recs.push_back(r);
+                i += 2;
+                continue;
+            }
+            const ConvRec &rec = recs[rec_i++];
+            StemArgs a = *stem;
+            a.w = p->dev_weights + p->conv[i].raw_off;
+            a.wdep = p->dev_weights + p->conv[i].dep_off;
+            a.woh = p->conv[i].has_oh ? p->dev_weights + p->conv[i].oh_off : nullptr;
+            a.bias = p->dev_weights + p->conv[i].bias_off;
+            a.status = status;
+            a.lut = p->dev_lut;
+            a.dst = tptr(o.dst);
+            a.dst_fmt = 1;
+            a.Hout = out.h; a.Wout = out.w;
+            if ((rc = launch_stem(a, s))) return rc;
+            FrontArgs f;
+            memset(&f, 0, sizeof(f));
+            f.x = tptr(o.dst);
+            f.w1 = p->dev_weights + p->conv[i + 1].s4_off;
+            f.w2 = p->dev_weights + p->conv[i + 2].front_off;
+            f.bias1 = p->dev_weights + p->conv[i + 1].bias_off;
+            f.bias2 = p->dev_weights + p->conv[i + 2].bias_off;
+            f.scale1 = p->conv[i + 1].split_acc_scale;
+            f.scale2 = p->conv[i + 2].split_acc_scale;
+            f.dst = tptr(n2.dst);
+            f.dst_fmt = fmt[n2.dst];
+            f.dst_ctotal = (int)p->tensors[n2.dst].channels;
+            f.dst_c4 = (f.dst_ctotal + 3) / 4;
+            f.dst_choff = (int)n2.dst_choff;
+            f.dst_limit = rec.dst_limit;
+            f.H1 = out.h; f.W1 = out.w; f.H2 = o2.h; f.W2 = o2.w;
+            f.C1 = (int)n1.cout; f.C2 = (int)n2.cout; f.relu1 = (int)n1.relu; f.relu2 = (int)n2.relu;
+            f.status = status;
+            if (tag_ops && prof_enabled()) {
+                char tag[96];
+                snprintf(tag, sizeof(tag), "%02zu+%02zu %s+%s %u->%u->%u %dx%d", i + 1, i + 2, p->tensors[n1.dst].name, p->tensors[n2.dst].name, o.cout,
+                         n1.cout, n2.cout, o2.h, o2.w);
+                prof_set_tag(tag);
+            }
+            if ((rc = launch_conv_front(f, B, s))) return rc;
+            fmt[o.dst] = 1;            // pf_hardnet_tensor_read unpacks the stem output
+            p->last_fmt = fmt;
+            i += 2;
+            continue;
+        }
         if (o.kind == OP_STEM && stem) {
             if (dry) { pin_fp32(o); continue; }
             StemArgs a = *stem;
@@ -566,6 +648,7 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
     p->opt_fuse_pool = g_opt_fuse_pool; p->opt_fuse_upsample = g_opt_fuse_upsample; p->opt_valu_rem = g_opt_valu_rem;
     p->opt_split = g_opt_split; p->opt_use_tuned = g_opt_use_tuned; p->opt_packed_acts = g_opt_packed_acts;
     p->opt_range_guard = g_opt_range_guard;
+    p->opt_fuse_front = g_opt_fuse_front;
     p->hdr = h;
     p->tensors.resize(h.n_tensors);
     p->ops.resize(h.n_ops);
@@ -634,7 +717,7 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
         // the split packings hold fp16 terms of w * 2^k (exact scaling, k per conv: conv_mfma.h)
         std::vector<float> wsc;
         const float *wsplit = wts + o.w_off;
-        if (o.stride == 1 && (o.k == 3 || o.k == 1)) {
+        if ((o.stride == 1 && (o.k == 3 || o.k == 1)) || (o.stride == 2 && o.k == 3 && o.n_src == 1)) {
             const size_t nw = (size_t)o.cout * o.cin * o.k * o.k;
             const float sc = split_weight_scale(wts + o.w_off, nw);
             wsc.resize(nw);
@@ -674,6 +757,14 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
                 host.resize(host.size() + s4_packed_floats(rg, (int)o.n_src, (int)o.cout, (int)o.k, c.s4_pad));
                 pack_conv_weights_s4(wsplit, (int)o.cin, (int)o.cout, (int)o.k, rg, (int)o.n_src, c.s4_pad, host.data() + c.s4_off);
             }
+        }
+        if (o.k == 3 && o.stride == 2 && o.kind == OP_CONV && o.n_src == 1 && (o.src[0].choff & 3) == 0 && o.cout <= 32) {
+            const S4Range rg{(int)o.src[0].choff, (int)o.src[0].ch};
+            host.resize(align_up(host.size(), 16), 0.f);
+            c.front_off = host.size();
+            c.has_front = true;
+            host.resize(host.size() + s4_packed_floats(&rg, 1, (int)o.cout, 3, 0));
+            pack_conv_weights_s4(wsplit, (int)o.cin, (int)o.cout, 3, &rg, 1, 0, host.data() + c.front_off);
         }
         if (o.k == 3 && o.stride == 1 && conv_valu_supports((int)o.cout)) {
             host.resize(align_up(host.size(), 16), 0.f);

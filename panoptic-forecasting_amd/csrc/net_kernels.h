@@ -15,7 +15,8 @@ struct StemArgs {
     const float *woh;      // one-hot rows re-packed [tap][t][n_cls + 1][16], last row of each group zero (nullable)
     const float *bias;     // [16]
     const uint8_t *lut;    // [256] id -> trainId (device)
-    float *dst;            // [B,16,Hout,Wout]
+    float *dst;            // [B,16,Hout,Wout] fp32, or (dst_fmt = 1) the packed-pair layout [B][2][4][Hout][Wout][4] fp16 of conv_mfma.h
+    int dst_fmt;           // 1: only the 2x2-outputs-per-lane kernel writes it (stem_writes_s4() tells whether a launch will use that one)
     float depth_mean, depth_std, min_depth, max_depth;
     int seg_is_i64, hop, B, T, n_cls, H, W, Hout, Wout;
     unsigned *status;      // range guard of the operand split (conv_mfma.h): |output| > 65504 raises PF_STATUS_RANGE; nullable
@@ -31,6 +32,7 @@ struct HeadArgs {
 };
 
 int launch_stem(const StemArgs &a, hipStream_t s);
+bool stem_writes_s4(const StemArgs &a);   // the kernel launch_stem() picks for these arguments can write dst_fmt = 1
 int launch_avgpool2(const float *src, float *dst, int planes, int Hin, int Win, hipStream_t s);
 int launch_upsample(const float *src, float *dst, int planes, int Hin, int Win, int Hout, int Wout, hipStream_t s);
 int launch_head(const HeadArgs &a, hipStream_t s);

@@ -432,6 +432,32 @@ __global__ __launch_bounds__(256) void stem_onehot_v4_kernel(StemArgs a, float i
     }
     const size_t op = (size_t)a.Hout * a.Wout;
     float vmax = 0.f;   // range guard of the operand split (conv_mfma.h): base.1 reads this tensor through conv_split
+    if (a.dst_fmt) {
+        // packed pairs for the fused front kernel (conv_front.hip): per term and channel group one 16-B unit [2 px][4 ch]
+        char *base = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * 4 * op * 8;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const size_t pix = (size_t)(oy0 + dy) * a.Wout + ox0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4v v0, v1;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    v0[2 * h] = fmaxf(acc[dy][0][2 * g + h].x, 0.f); v0[2 * h + 1] = fmaxf(acc[dy][0][2 * g + h].y, 0.f);
+                    v1[2 * h] = fmaxf(acc[dy][1][2 * g + h].x, 0.f); v1[2 * h + 1] = fmaxf(acc[dy][1][2 * g + h].y, 0.f);
+                }
+                vmax = range_acc(range_acc(vmax, v0[0], v0[1], v0[2], v0[3]), v1[0], v1[1], v1[2], v1[3]);
+                split_x4 h0, m0, h1, m1;
+                split_terms4(v0, h0, m0);
+                split_terms4(v1, h1, m1);
+                char *p = base + ((size_t)g * op + pix) * 8;
+                *reinterpret_cast<split_x8 *>(p) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                *reinterpret_cast<split_x8 *>(p + (size_t)4 * op * 8) = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+        range_commit(a.status, vmax);
+        return;
+    }
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
         float *o = a.dst + (size_t)b * 16 * op + (size_t)(oy0 + dy) * a.Wout + ox0;
@@ -801,9 +827,16 @@ static bool stem_fast_div_exact(float mean, float stdv, float dmin, float dmax) 
     return ok;
 }
 
+// the conditions of the 2 x 2-outputs-per-lane kernel (the only one that writes the packed-pair layout)
+bool stem_writes_s4(const StemArgs &a) {
+    return a.T == 3 && a.wdep && a.woh && !a.seg_is_i64 && (a.W & 3) == 0 && (a.H & 3) == 0 && a.Wout * 2 == a.W && a.Hout * 2 == a.H &&
+           (unsigned long long)a.T * a.H * a.W < (1ull << 32) && !ab_env("PF_STEM_GENERIC") && !ab_env("PF_STEM_BATCHED") && !ab_env("PF_STEM_V3");
+}
+
 int launch_stem(const StemArgs &a, hipStream_t s) {
     if (a.T * (a.n_cls + 1) * 9 * 16 * sizeof(float) > 60000)
         return fail(PF_EUNSUPPORTED, "stem: T=%d n_cls=%d weights exceed LDS budget", a.T, a.n_cls);
+    if (a.dst_fmt && !stem_writes_s4(a)) return fail(PF_EUNSUPPORTED, "stem: these arguments select a kernel that writes fp32 only");
     const size_t lds = (size_t)a.T * (a.n_cls + 1) * 9 * 16 * sizeof(float);
     const double ipx = (double)a.B * a.T * a.H * a.W, opx = (double)a.B * a.Hout * a.Wout;
     static const bool generic = ab_env("PF_STEM_GENERIC") != nullptr;   // A/B switch for profiling

@@ -76,6 +76,38 @@ def test_stage_by_stage_vs_oracle():
     assert (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max() <= LOGIT_TOL
 
 
+@pytest.mark.parametrize('h,w,b', [(128, 192, 1), (96, 160, 2), (256, 512, 1), (72, 264, 1)])
+def test_fused_front_end_vs_oracle(h, w, b):
+    """conv_front.hip: base.1 + base.2 as one kernel on the packed-pair stem output (u8 labels select the stem variant that
+    writes it).  The stem output and base.2 against the oracle's taps, the logits against the oracle, and against the same
+    network with the fusion switched off (three separate kernels): the fused path must actually have run."""
+    from helpers import view_tensor
+    from oracle import hardnet_ref
+    from panoptic_forecasting_amd import lib as pflib
+    from panoptic_forecasting_amd import synth
+    inp = synth.make_bg_inputs(b=b, h=h, w=w, seed=h + w)
+    taps = {}
+    ref = hardnet_ref.bg_predict(_sd(), inp, final_size=(h, w), taps=taps)
+    cu = {k: v.cuda() for k, v in inp.items()}
+    cu['seg'] = cu['seg'].to(torch.uint8)                 # 255 = void stays 255
+    outs = {}
+    for fuse in (1, 0):
+        m = _model(h, w, fuse_front=fuse)
+        pflib.profile(True)
+        outs[fuse] = m.predict(cu, None)
+        labels = [r['label'] for r in pflib.profile_results()]
+        pflib.profile(False)
+        assert any('conv_front_kernel' in l for l in labels) == bool(fuse), labels
+        for tap in ('base.0', 'base.2'):
+            got = view_tensor(m._get_plan(), m._ws, tap, b, h, w).cpu()
+            err = (got - taps[tap]).abs().max().item()
+            assert err <= 1e-4 * (1 + taps[tap].abs().max().item()), (fuse, tap, err)
+        assert m.range_status() == 0
+        assert (outs[fuse]['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max() <= LOGIT_TOL
+        assert (outs[fuse]['seg'].cpu() == ref['seg']).float().mean().item() >= AGREE
+    assert (outs[1]['orig_size_logits'] - outs[0]['orig_size_logits']).abs().max().item() <= 1e-4
+
+
 @pytest.mark.parametrize('h,w,b', [(256, 512, 1), (160, 224, 2)])
 def test_matches_oracle(h, w, b):
     from oracle import hardnet_ref
