@@ -269,9 +269,11 @@ class BGModel(BaseModel):
         batch-statistics BatchNorm, cross entropy and the whole backward pass run as ONE device call
         (``pf_train_forward_backward``); the returned loss carries an autograd node that delivers the parameter
         gradients on ``backward()`` (``bg_train.TrainStepFunction``), so ``clip_grad_norm_`` / ``opt.step()`` / DDP work
-        unchanged.  Otherwise the validation form: eval-mode network (folded BN) + ``pf_seg_loss`` (upsample + cross
-        entropy + accuracy fused; the full-resolution logits are never written)."""
-        if self.training and torch.is_grad_enabled():
+        unchanged.  Under ``torch.no_grad()`` a model in training mode still runs that call (batch statistics, running-stat
+        update - what ``nn.BatchNorm2d`` does in the reference) and returns the loss without an autograd node.  In ``eval()``
+        mode the validation form: eval-mode network (folded BN) + ``pf_seg_loss`` (upsample + cross entropy + accuracy fused;
+        the full-resolution logits are never written)."""
+        if self.training:
             return self._train_loss(inputs, labels)
         with torch.no_grad():
             return self._eval_loss(inputs, labels)

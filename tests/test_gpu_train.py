@@ -461,3 +461,27 @@ def test_two_rank_train_driver_equals_one_rank_with_accumulation(tmp_path):
     # ... and into the reference's optimizer class unchanged
     dummy = [torch.nn.Parameter(torch.zeros(shape)) for _, _, shape, _ in tr.trainable_layout()]
     torch.optim.SGD(dummy, lr=2e-3, momentum=0.9).load_state_dict(st['optimizer'])
+
+
+def test_training_mode_loss_under_no_grad_uses_batch_statistics():
+    """model.train() + torch.no_grad(): the reference's BatchNorm still normalises with batch statistics (and updates its running
+    statistics); so does BGModel.loss - same value as the grad-enabled call on the same parameters, no autograd node, and not the
+    folded running-statistics value of eval()."""
+    from panoptic_forecasting_amd.registry import build_model
+    z, batches = _fixture()
+    inputs, labels = batches[0]
+    m = build_model(_params())
+    m.load_state_dict(_sd())
+    m.cuda()
+    m.train()
+    with torch.no_grad():
+        a = m.loss(_cuda(inputs), _cuda(labels))
+    assert a['loss'].grad_fn is None
+    assert abs(float(a['loss']) - z['loss'][0]) <= LOSS_REL * z['loss'][0]        # the reference's train-mode loss of this batch
+    m2 = build_model(_params())
+    m2.load_state_dict(_sd())
+    m2.cuda()
+    m2.eval()
+    e = m2.loss(_cuda(inputs), _cuda(labels))
+    assert abs(float(e['loss']) - float(a['loss'])) > 10 * LOSS_REL * float(a['loss'])
+    assert int(m.state_dict()['model.base.0.norm.num_batches_tracked']) == 1
