@@ -195,15 +195,6 @@ void pack_conv_weights_wave(const float *w_oihw, int cin, int cout, int ks, cons
 size_t wave_packed_floats(const int *src_ch, int n_src, int cout, int ks);
 int launch_conv_wave(const ConvArgs &a, int ks, int mh, int nt, int wk, int B, hipStream_t stream);
 
-// Vector-ALU path (conv_valu.hip; 3x3/s1, Win % 4 == 0, no fused epilogue): a.wpk must point at
-// pack_conv_weights_valu() output, chunks of kValuKc channels.  rows = output rows per wave (1 or 2).
-constexpr int kValuKc = 4;
-bool conv_valu_supports(int cout);
-int valu_chunks(const int *src_ch, int n_src);
-size_t valu_packed_floats(const int *src_ch, int n_src, int cout);
-void pack_conv_weights_valu(const float *w_oihw, int cin, int cout, const int *src_ch, int n_src, float *out);
-int launch_conv_valu(const ConvArgs &a, int rows, int B, hipStream_t stream);
-
 // split path (conv_split.hip; 3x3/s1, Wout % 4 == 0, no fused epilogue; two fp16 terms per operand, see split_terms2
 // above): a.wpk must point at pack_conv_weights_split() output, chunks of 8 channels; the packers take the weights
 // ALREADY multiplied by split_weight_scale() and a.acc_scale = 1 / that scale.
@@ -252,7 +243,7 @@ bool conv_front_supports(int c0, int c1, int c2, int h1, int w1);
 int launch_conv_front(const FrontArgs &a, int B, hipStream_t s);
 
 // Kernel/shape choice for one stride-1 conv (conv_select.cpp): kind 1 = conv_dma (p0 = WM, p1 = NT),
-// kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK), kind 3 = conv_valu (p0 = rows per wave),
+// kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK), (kind 3 was conv_valu: the whole 3x3 conv on v_pk_fma_f32, measured and removed - DESIGN.md 3.2),
 // kind 4 = conv_split (p0 = NT, p1 = 1: 8x64-pixel tiles), kind 5 = conv_s4 (same parameters; S4 sources).
 struct ConvChoice {
     int kind, p0, p1, p2;

@@ -29,8 +29,6 @@ struct ConvPlan {
     int rem_count = 0;
     size_t wave_off = 0;  // fragment-order packing for the wave-autonomous path (stride 1 only)
     int wave_chunks = 0;
-    size_t valu_off = 0;  // [chunk][ch][tap][cout] rows for the vector-ALU path (3x3/s1 with a supported cout), else 0
-    bool has_valu = false;
     size_t split_off = 0; // fp16 hi/mid fragments for the split path (3x3/s1 and 1x1), else 0
     int split_chunks = 0;
     bool has_split = false;
@@ -251,10 +249,9 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                 if ((need & 2) && ch.p0 == 1) ch.p0 = 2;
             }
             if (g_conv_force.kind == 1) ch = g_conv_force;
-            if (g_conv_force.kind == 3 && p->conv[i].has_valu && !need) ch = g_conv_force;
             if (g_conv_force.kind == 4 && p->conv[i].has_split && (!need || o.k == 1)) ch = g_conv_force;
             if (ch.kind == 4 && (!p->conv[i].has_split || (need && o.k != 1) || !p->opt_split)) ch = ConvChoice{1, 0, 0, 0};
-            if (ch.kind == 3 && (!p->conv[i].has_valu || need)) ch = ConvChoice{1, 0, 0, 0};
+            if (ch.kind == 3) ch = ConvChoice{1, 0, 0, 0};   // (kind 3 was conv_valu, removed in round 3: selected by no table row)
             // pf_debug_force_conv(5, ..): launches that cannot read S4 (fp32 sources) still have to be able to WRITE it
             if (g_conv_force.kind == 5) ch = ConvChoice{1, 0, 0, 0};
         }
@@ -342,13 +339,6 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.nchunks = p->conv[i].split_chunks;
             set_chunks(o.k == 1 ? 32 : 8);
             rc = o.k == 1 ? launch_conv_split1(a, ch.p0, B, s) : launch_conv_split(a, ch.p0, ch.p1, B, s);
-            if (rc != PF_EUNSUPPORTED) return rc;
-            ch = ConvChoice{1, 0, 0, 0};
-        }
-        if (ch.kind == 3) {
-            a.wpk = p->dev_weights + p->conv[i].valu_off;
-            set_chunks(kValuKc);
-            rc = launch_conv_valu(a, ch.p0 == 1 ? 1 : 2, B, s);
             if (rc != PF_EUNSUPPORTED) return rc;
             ch = ConvChoice{1, 0, 0, 0};
         }
@@ -765,13 +755,6 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
             c.has_front = true;
             host.resize(host.size() + s4_packed_floats(&rg, 1, (int)o.cout, 3, 0));
             pack_conv_weights_s4(wsplit, (int)o.cin, (int)o.cout, 3, &rg, 1, 0, host.data() + c.front_off);
-        }
-        if (o.k == 3 && o.stride == 1 && conv_valu_supports((int)o.cout)) {
-            host.resize(align_up(host.size(), 16), 0.f);
-            c.valu_off = host.size();
-            c.has_valu = true;
-            host.resize(host.size() + valu_packed_floats(src_ch, (int)o.n_src, (int)o.cout));
-            pack_conv_weights_valu(wts + o.w_off, (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, host.data() + c.valu_off);
         }
         if (o.stride == 1) {
             c.wave_chunks = wave_chunks(src_ch, (int)o.n_src, (int)o.k);

@@ -200,34 +200,6 @@ def test_valu_remainder_path(cin, cout, h, w, force_conv):
     net.close()
 
 
-@pytest.mark.parametrize('rows', [1, 2])
-@pytest.mark.parametrize('cin,cout,h,w', [(48, 10, 24, 64), (58, 18, 17, 128), (16, 24, 9, 68), (91, 28, 20, 72),
-                                          (7, 16, 5, 60), (33, 30, 8, 64), (20, 32, 3, 132)])
-def test_vector_alu_conv(cin, cout, h, w, rows, force_conv):
-    """conv_valu (3x3/s1 on v_pk_fma_f32 with scalar-cache weights): three input ranges in swapped order so the K
-    chunking of every range (granularity 1, chunks of 4) and the edge tiles in both directions are exercised."""
-    from helpers import MiniNet, MiniSpec
-    from panoptic_forecasting_amd import hardnet_arch as arch
-    g = torch.Generator().manual_seed(cin * 7 + cout)
-    x = torch.randn(2, cin, h, w, generator=g)
-    spec = MiniSpec(cin)
-    a, bch = cin // 3, cin - cin // 3
-    spec.conv('c', [arch.Src(0, bch, a), arch.Src(0, 0, bch)], cout, 3)
-    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
-    bias = torch.randn(cout, generator=g)
-    force_conv(3, rows, 0, 0)
-    from panoptic_forecasting_amd import lib as pflib
-    pflib.profile(True)
-    net = MiniNet(spec, {'c': (wt, bias)}).run(x.cuda())
-    labels = [r['label'] for r in pflib.profile_results()]
-    pflib.profile(False)
-    assert any('conv_valu_kernel' in l for l in labels), labels     # the forced kernel really ran
-    ref = F.relu(F.conv2d(torch.cat([x[:, bch:], x[:, :bch]], 1), wt, bias, padding=1))
-    err = (net.tensor('c').cpu() - ref).abs().max().item()
-    assert err <= _tol(ref), (err, _tol(ref))
-    net.close()
-
-
 @pytest.mark.parametrize('nt,wide', [(1, 0), (2, 0), (3, 0), (1, 1), (2, 1), (3, 1)])
 @pytest.mark.parametrize('cin,cout,h,w', [(48, 10, 24, 64), (58, 18, 17, 128), (91, 28, 20, 72), (7, 16, 5, 60),
                                           (33, 46, 9, 36), (163, 46, 16, 32), (16, 24, 40, 96)])

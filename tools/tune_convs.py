@@ -32,7 +32,7 @@ model.load_state_dict(bench.calibrated_state_dict())
 batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
 
 CONFIGS = [(0, 0, 0, 0)] + [(1, wm, nt, 0) for wm in (4, 2, 1) for nt in (1, 2, 3, 4) if not (wm == 1 and nt > 2)] + \
-          [(2, mh, nt, wk) for mh in (1, 2, 4) for nt in (1, 2) for wk in (2, 4, 8, 16)] + [(3, 1, 0, 0), (3, 2, 0, 0)] + \
+          [(2, mh, nt, wk) for mh in (1, 2, 4) for nt in (1, 2) for wk in (2, 4, 8, 16)] + \
           ([(4, nt, wd, 0) for nt in (1, 2, 3, 4) for wd in (0, 1)] if os.environ.get('PF_TUNE_SPLIT', '1') != '0' else [])
 
 
