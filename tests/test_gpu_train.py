@@ -229,11 +229,14 @@ def test_bgmodel_training_loss_is_a_drop_in_for_the_reference_loop():
             assert abs(float(total) - z['grad_norm'][0]) <= 0.1 * z['grad_norm'][0]      # see _oracle_grads on conditioning
             grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
             g64, r32, bars, _ = _oracle_grads(sd, inputs, labels, '64x128')
-            coef = min(1.0, 5.0 / (z['grad_norm'][0] + 1e-6))     # the fixture holds the reference's CLIPPED fp32 gradients
+            # both sides hold CLIPPED gradients, each scaled by its own 5 / (total norm + 1e-6) - and the total norm is a sum over
+            # the ill-conditioned encoder tensors too (it may differ by a few per cent): compare the gradients before clipping
+            coef_ref = min(1.0, 5.0 / (z['grad_norm'][0] + 1e-6)), min(1.0, 5.0 / (float(total) + 1e-6))
             for name in z.files:
                 if name.startswith('grad::'):
                     k = name[6:]
-                    assert _rel(grads[k].cpu(), torch.from_numpy(z[name])) <= bars[k] + 1.5 * _rel(r32['grads'][k], g64[k]), name
+                    d = _rel(grads[k].cpu() / coef_ref[1], torch.from_numpy(z[name]) / coef_ref[0])
+                    assert d <= bars[k] + 1.5 * _rel(r32['grads'][k], g64[k]), (name, d)
         opt.step()
         opt.zero_grad()
         ref = hardnet_ref.bg_train_step(osd, inputs, labels, momentum_bufs=bufs)
