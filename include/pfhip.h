@@ -212,7 +212,7 @@ int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void 
  *                   (fp32 itself: 2^-24); beyond 65504 the forward raises PF_STATUS_RANGE (above) instead of clamping;
  *                   0 = every convolution on fp32 MFMA / fp32 VALU;
  *   "range_guard"   (default 1) the PF_STATUS_RANGE checks of the split path (a compare per stored value); 0 removes them;
- *   "fuse_front"    (default 0) base.1 (3x3 s1, 16 -> 24) and base.2 (3x3 s2, 24 -> 32) as ONE kernel on a packed-pair stem output, the
+ *   "fuse_front"    (default 0; 1 | 2 = two tilings) base.1 (3x3 s1, 16 -> 24) and base.2 (3x3 s2, 24 -> 32) as ONE kernel on a packed-pair stem output, the
  *                   tensor between them kept in LDS (csrc/conv_front.hip): same results (tests/test_gpu_bg_model.py), 39 % fewer
  *                   front-end bytes, but 1.00 ms against 0.82 ms for the two separate kernels per 16 frames in its first form
  *                   (weights re-fetched from L2 by every workgroup, 2.5 waves per SIMD): off until it wins;

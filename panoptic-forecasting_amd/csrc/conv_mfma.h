@@ -240,7 +240,7 @@ struct FrontArgs {
 };
 
 bool conv_front_supports(int c0, int c1, int c2, int h1, int w1);
-int launch_conv_front(const FrontArgs &a, int B, hipStream_t s);
+int launch_conv_front(const FrontArgs &a, int variant, int B, hipStream_t s);   // variant = plan option fuse_front (1 | 2)
 
 // Kernel/shape choice for one stride-1 conv (conv_select.cpp): kind 1 = conv_dma (p0 = WM, p1 = NT),
 // kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK), (kind 3 was conv_valu: the whole 3x3 conv on v_pk_fma_f32, measured and removed - DESIGN.md 3.2),

@@ -475,7 +475,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                          n1.cout, n2.cout, o2.h, o2.w);
                 prof_set_tag(tag);
             }
-            if ((rc = launch_conv_front(f, B, s))) return rc;
+            if ((rc = launch_conv_front(f, p->opt_fuse_front, B, s))) return rc;
             fmt[o.dst] = 1;            // pf_hardnet_tensor_read unpacks the stem output
             p->last_fmt = fmt;
             i += 2;

@@ -91,7 +91,7 @@ def test_fused_front_end_vs_oracle(h, w, b):
     cu = {k: v.cuda() for k, v in inp.items()}
     cu['seg'] = cu['seg'].to(torch.uint8)                 # 255 = void stays 255
     outs = {}
-    for fuse in (1, 0):
+    for fuse in (1, 2, 0):     # 1: 2 x 32 tiles, weights from L2; 2: 2 x 16 tiles, weights resident in LDS; 0: three kernels
         m = _model(h, w, fuse_front=fuse)
         pflib.profile(True)
         outs[fuse] = m.predict(cu, None)
@@ -105,7 +105,8 @@ def test_fused_front_end_vs_oracle(h, w, b):
         assert m.range_status() == 0
         assert (outs[fuse]['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max() <= LOGIT_TOL
         assert (outs[fuse]['seg'].cpu() == ref['seg']).float().mean().item() >= AGREE
-    assert (outs[1]['orig_size_logits'] - outs[0]['orig_size_logits']).abs().max().item() <= 1e-4
+    for fuse in (1, 2):
+        assert (outs[fuse]['orig_size_logits'] - outs[0]['orig_size_logits']).abs().max().item() <= 1e-4
 
 
 @pytest.mark.parametrize('h,w,b', [(256, 512, 1), (160, 224, 2)])
