@@ -451,26 +451,24 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
 #endif
 }
 
-int g_s4_lds_pad = 0;   // experiment (pf_set_option "s4_lds_pad"): extra LDS bytes per 3x3 workgroup = fewer resident workgroups per CU
-
 template <int NT, int TW_>
 static int launch_s4_cfg(const ConvArgs &a0, int B, hipStream_t s) {
     using C = S4Cfg<NT, TW_>;
     ConvArgs a = a0;
     a.tilesX = (a.Wout + C::TW - 1) / C::TW;
     a.tilesY = (a.Hout + C::TH - 1) / C::TH;
-    static int attr_set = -1;
-    if (attr_set != g_s4_lds_pad) {
+    static bool attr_set = false;
+    if (!attr_set) {
         PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s4_kernel<NT, TW_>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES + g_s4_lds_pad));
-        attr_set = g_s4_lds_pad;
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_set = true;
     }
     char label[96];
     snprintf(label, sizeof(label), "void pf::conv_s4_kernel<%d, %d>(pf::ConvArgs)", NT, TW_);
     const double px = (double)B * a.Hout * a.Wout;
     ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * 9,
                  4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * 9));
-    hipLaunchKernelGGL((conv_s4_kernel<NT, TW_>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(256), C::LDS_BYTES + g_s4_lds_pad, s, a);
+    hipLaunchKernelGGL((conv_s4_kernel<NT, TW_>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(256), C::LDS_BYTES, s, a);
     PF_LAUNCH_CHECK("conv_s4_kernel");
     return PF_OK;
 }

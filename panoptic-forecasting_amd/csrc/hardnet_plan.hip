@@ -65,7 +65,6 @@ namespace pf {
 int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_split = 1, g_opt_packed_acts = 1, g_opt_tag_ops = 0;
 int g_opt_range_guard = 1, g_opt_fuse_front = 0;   // fuse_front: built and bit-checked, measured slower than the three kernels (profiles/r03_experiments.md)
 extern int g_opt_use_tuned;
-extern int g_s4_lds_pad;
 }
 
 extern "C" int pf_set_option(const char *name, int value) {
@@ -79,7 +78,6 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "range_guard")) g_opt_range_guard = value;
     else if (!strcmp(name, "fuse_front")) g_opt_fuse_front = value;
     else if (!strcmp(name, "profile_tag_ops")) g_opt_tag_ops = value;
-    else if (!strcmp(name, "s4_lds_pad")) g_s4_lds_pad = value < 0 ? 0 : value;   // experiment: profiles/r03_experiments.md
     else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);
     return PF_OK;
 }
