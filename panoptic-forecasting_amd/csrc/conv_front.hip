@@ -29,6 +29,15 @@ typedef split_x4 fr_h4;
 typedef __attribute__((address_space(3))) void *fr_lds_ptr_t;
 [[maybe_unused]] constexpr unsigned kFrOob = 0x80000000u;
 
+#ifndef PF_PROBE
+#define PF_PROBE 0
+#endif
+#if PF_PROBE   // shader-clock stamps of every wave of one workgroup in the middle of the grid (tools/probe_front.py): slot 8 wave + i
+#define FR_PROBE(i) do { if (lane == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.z == gridDim.z / 2 && a.probe) a.probe[8 * wave + (i)] = clock64(); } while (0)
+#else
+#define FR_PROBE(i) do { } while (0)
+#endif
+
 template <int TW2_, bool WLDS_>
 struct FrontCfg {
     static constexpr int TH2 = 2, TW2 = TW2_;          // output tile of the stride-2 conv
@@ -87,6 +96,7 @@ __global__ __launch_bounds__(320, 3) void conv_front_kernel(FrontArgs a) {   // 
     xcd_tile_order(a.tilesX * a.tilesY, tile_lin, dummy);
     const int tileY = tile_lin / a.tilesX, tileX = tile_lin - tileY * a.tilesX, b = blockIdx.z;
     const int oy0 = tileY * C::TH2, ox0 = tileX * C::TW2;
+    FR_PROBE(0);
     const int yr0 = 2 * oy0 - 1, yc0 = 2 * ox0 - 1;      // intermediate region origin (stride-1 coordinates)
     const int xr0 = yr0 - 1, xc0 = yc0 - 1;              // stem window origin; xc0 = 2 ox0 - 2 is even
 
@@ -142,7 +152,9 @@ __global__ __launch_bounds__(320, 3) void conv_front_kernel(FrontArgs a) {   // 
     FrW wcur;
     if (!C::WLDS) wcur = load_w1(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window (and the weights) have landed
+    FR_PROBE(1);
     __syncthreads();
+    FR_PROBE(2);
     if (C::WLDS) wcur = load_w1(0);
     {
         const int r = wave;
@@ -155,13 +167,21 @@ __global__ __launch_bounds__(320, 3) void conv_front_kernel(FrontArgs a) {   // 
             h = fr_join(*reinterpret_cast<const fr_h4 *>(p), *reinterpret_cast<const fr_h4 *>(p + C::XPLANE));
             md = fr_join(*reinterpret_cast<const fr_h4 *>(p + C::C0G * C::XPLANE), *reinterpret_cast<const fr_h4 *>(p + (C::C0G + 1) * C::XPLANE));
         };
-        auto mfma3 = [&](const FrW &w, int m, const fr_h8 &fh, const fr_h8 &fm) {
+        // the three products of one weight block with all M-tiles: product by product, so that consecutive matrix instructions
+        // never hit the same accumulator (a dependent v_mfma pair waits out the first one's latency)
+        auto mfmas = [&](const FrW &w, const fr_h8 (&fh)[C::MT1], const fr_h8 (&fm)[C::MT1]) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                acc[m][n] = PF_MFMA_SPLIT(w.h[n], fm, acc[m][n]);
-                acc[m][n] = PF_MFMA_SPLIT(w.m[n], fh, acc[m][n]);
-                acc[m][n] = PF_MFMA_SPLIT(w.h[n], fh, acc[m][n]);
-            }
+            for (int m = 0; m < C::MT1; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = PF_MFMA_SPLIT(w.h[n], fm[m], acc[m][n]);
+#pragma unroll
+            for (int m = 0; m < C::MT1; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = PF_MFMA_SPLIT(w.m[n], fh[m], acc[m][n]);
+#pragma unroll
+            for (int m = 0; m < C::MT1; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = PF_MFMA_SPLIT(w.h[n], fh[m], acc[m][n]);
         };
         int blk = 0;
 #pragma unroll
@@ -170,12 +190,10 @@ __global__ __launch_bounds__(320, 3) void conv_front_kernel(FrontArgs a) {   // 
             for (int s = 0; s < 2; ++s) {
                 const FrW wnext = load_w1(blk + 1);   // (the block after the last full one is the collected block)
                 const int ky = s == 0 ? ky0 : ky1, kx = s == 0 ? kx0 : kx1;
+                fr_h8 fh[C::MT1], fm[C::MT1];
 #pragma unroll
-                for (int m = 0; m < C::MT1; ++m) {
-                    fr_h8 fh, fm;
-                    xfrag(rd, ky, kx, m, fh, fm);
-                    mfma3(wcur, m, fh, fm);
-                }
+                for (int m = 0; m < C::MT1; ++m) xfrag(rd, ky, kx, m, fh[m], fm[m]);
+                mfmas(wcur, fh, fm);
                 wcur = wnext;
                 ++blk;
             }
@@ -184,8 +202,8 @@ __global__ __launch_bounds__(320, 3) void conv_front_kernel(FrontArgs a) {   // 
                 for (int m = 0; m < C::MT1; ++m) xfrag(rd, 2, 2, m, col_h[m], col_m[m]);
             }
         }
-#pragma unroll
-        for (int m = 0; m < C::MT1; ++m) mfma3(wcur, m, col_h[m], col_m[m]);
+        mfmas(wcur, col_h, col_m);
+        FR_PROBE(3);
 
         // ---- 3. bias, ReLU, zero outside the image, split, -> LDS (odd / even columns in separate planes)
         const int gy = yr0 + r;
@@ -219,7 +237,9 @@ __global__ __launch_bounds__(320, 3) void conv_front_kernel(FrontArgs a) {   // 
     }
     FrW w2;
     if (!C::WLDS) w2 = load_w2(0);
+    FR_PROBE(4);
     __syncthreads();
+    FR_PROBE(5);
     if (C::WLDS) w2 = load_w2(0);
 
     // ---- 4. second conv (stride 2): waves 0..3.  TW2 = 32: wave = (output row, 16-pixel half), both cout tiles;
@@ -227,9 +247,11 @@ __global__ __launch_bounds__(320, 3) void conv_front_kernel(FrontArgs a) {   // 
     if (wave < 4) {
         constexpr int NN = C::NN2;
         const int ry = wave >> 1, hx = NN == 2 ? (wave & 1) : 0, n0 = NN == 2 ? 0 : (wave & 1);
-        fr_f32x4 acc2[NN];
+        // one accumulator PER PRODUCT (summed at the end): with 1-2 cout tiles per wave the three products of a block would
+        // otherwise be a dependent chain on one register quad
+        fr_f32x4 acc2[NN][3];
 #pragma unroll
-        for (int n = 0; n < NN; ++n) acc2[n] = fr_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NN; ++n) acc2[n][0] = acc2[n][1] = acc2[n][2] = fr_f32x4{0.f, 0.f, 0.f, 0.f};
         // local column 2 (16 hx + i) + kx: kx = 0, 2 -> the j-even plane (slots i, i + 1), kx = 1 -> the j-odd plane (slot i)
         auto yfrag = [&](int rd, int ky, int kx, fr_h8 &h, fr_h8 &md) {
             const int slot = 16 * hx + li + (kx >> 1);
@@ -242,9 +264,9 @@ __global__ __launch_bounds__(320, 3) void conv_front_kernel(FrontArgs a) {   // 
 #pragma unroll
             for (int n = 0; n < NN; ++n) {
                 const fr_h8 wh = NN == 2 ? w.h[n] : (n0 ? w.h[1] : w.h[0]), wm = NN == 2 ? w.m[n] : (n0 ? w.m[1] : w.m[0]);
-                acc2[n] = PF_MFMA_SPLIT(wh, fm, acc2[n]);
-                acc2[n] = PF_MFMA_SPLIT(wm, fh, acc2[n]);
-                acc2[n] = PF_MFMA_SPLIT(wh, fh, acc2[n]);
+                acc2[n][0] = PF_MFMA_SPLIT(wh, fm, acc2[n][0]);
+                acc2[n][1] = PF_MFMA_SPLIT(wm, fh, acc2[n][1]);
+                acc2[n][2] = PF_MFMA_SPLIT(wh, fh, acc2[n][2]);
             }
         };
         fr_h8 col_h = zero8, col_m = zero8;
@@ -263,6 +285,7 @@ __global__ __launch_bounds__(320, 3) void conv_front_kernel(FrontArgs a) {   // 
             if (g == rd) yfrag(rd, 2, 2, col_h, col_m);
         }
         mfma3(w2, col_h, col_m);
+        FR_PROBE(6);
 
         // ---- 5. bias, ReLU, range guard, store: lane (g, i) = couts 4g..4g+3 of output pixel (oy0 + ry, ox0 + 16 hx + i)
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) the compiler can see: nothing left to protect inside the stores (conv_s4.hip)
@@ -279,7 +302,7 @@ __global__ __launch_bounds__(320, 3) void conv_front_kernel(FrontArgs a) {   // 
                 const int co = n * 16 + 4 * g;
                 if (co >= a.C2 + 2) continue;
                 const fr_f32x4 b4 = *reinterpret_cast<const fr_f32x4 *>(bias_lds + 32 + n * 16 + 4 * g);
-                fr_f32x4 v = acc2[nn];
+                fr_f32x4 v = (acc2[nn][0] + acc2[nn][1]) + acc2[nn][2];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v[q] = v[q] * a.scale2 + b4[q];
@@ -319,6 +342,7 @@ __global__ __launch_bounds__(320, 3) void conv_front_kernel(FrontArgs a) {   // 
             range_commit(a.status, vmax);
         }
     }
+    FR_PROBE(7);
 #endif
 }
 

@@ -237,6 +237,7 @@ struct FrontArgs {
     int H1, W1, H2, W2, C1, C2, relu1, relu2;
     int tilesX, tilesY;
     unsigned *status;
+    long long *probe;       // PF_PROBE builds only (tools/probe_front.py), else nullptr
 };
 
 bool conv_front_supports(int c0, int c1, int c2, int h1, int w1);

@@ -467,6 +467,8 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             f.H1 = out.h; f.W1 = out.w; f.H2 = o2.h; f.W2 = o2.w;
             f.C1 = (int)n1.cout; f.C2 = (int)n2.cout; f.relu1 = (int)n1.relu; f.relu2 = (int)n2.relu;
             f.status = status;
+            static const bool front_probe = ab_env("PF_PROBE") != nullptr;
+            f.probe = front_probe ? probe_buffer() : nullptr;
             if (tag_ops && prof_enabled()) {
                 char tag[96];
                 snprintf(tag, sizeof(tag), "%02zu+%02zu %s+%s %u->%u->%u %dx%d", i + 1, i + 2, p->tensors[n1.dst].name, p->tensors[n2.dst].name, o.cout,
