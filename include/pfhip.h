@@ -212,10 +212,10 @@ int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void 
  *                   (fp32 itself: 2^-24); beyond 65504 the forward raises PF_STATUS_RANGE (above) instead of clamping;
  *                   0 = every convolution on fp32 MFMA / fp32 VALU;
  *   "range_guard"   (default 1) the PF_STATUS_RANGE checks of the split path (a compare per stored value); 0 removes them;
- *   "fuse_front"    (default 0; 1 | 2 = two tilings) base.1 (3x3 s1, 16 -> 24) and base.2 (3x3 s2, 24 -> 32) as ONE kernel on a packed-pair stem output, the
- *                   tensor between them kept in LDS (csrc/conv_front.hip): same results (tests/test_gpu_bg_model.py), 39 % fewer
- *                   front-end bytes, but 1.00 ms against 0.82 ms for the two separate kernels per 16 frames in its first form
- *                   (weights re-fetched from L2 by every workgroup, 2.5 waves per SIMD): off until it wins;
+ *   "fuse_front"    (default 1) base.1 (3x3 s1, 16 -> 24) and base.2 (3x3 s2, 24 -> 32) as ONE kernel on a packed-pair stem output, the
+ *                   tensor between them kept in LDS (csrc/conv_front.hip: workgroups march down 31-column strips): same results
+ *                   (tests/test_gpu_bg_model.py), 39 % fewer front-end bytes, 0.42 ms against 0.83 ms for the two separate kernels
+ *                   per 16 frames at 1024x2048; 0 = stem -> conv_split -> conv_dma stride 2;
  *   "profile_tag_ops" (default 0; process-wide only) pf_profile_* records carry one label per op of the table (tools/);
  *   "valu_remainder" (default 1) trailing cout % 16 <= 8 channels of a conv_dma layer on the vector ALU. */
 int pf_set_option(const char *name, int value);

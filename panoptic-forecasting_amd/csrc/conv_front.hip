@@ -1,379 +1,503 @@
-// The 512x1024 front end in one pass: base.1 (3x3, stride 1) and base.2 (3x3, stride 2) of FC-HarDNet (hardnet.py:274-283)
-// as ONE kernel - the tensor between them (24 channels at half resolution: 100 MB per 1024x2048 frame, written and read back,
-// 39 % of the bytes the three front-end kernels moved) never leaves LDS.
+// The 512x1024 front end in one pass: base.1 (3x3, stride 1, 16 -> 24) and base.2 (3x3, stride 2, 24 -> 32) of FC-HarDNet
+// (hardnet.py:274-283) as ONE kernel - the tensor between them (24 channels at half resolution: 100 MB per 1024x2048 frame,
+// written and read back, 39 % of the bytes the three front-end kernels moved) never leaves LDS.  Plan option fuse_front (on).
 //
-// Round 2 ran stem -> conv_split<2, 64> (438 us per 16 frames, 3.1 TB/s of algorithmic bytes: bound by the fabric) ->
-// conv_dma stride 2 (332 us, fp32 MFMA): 1.09 ms of a 7.2 ms step.  Here the stem writes the packed-pair layout of
-// conv_mfma.h (two fp16 terms per value, [B][2][C/4][H][W][4]) and a workgroup of 5 waves produces a 2 x 32-pixel tile of
-// the stride-2 conv's output:
-//   1. the 7 x 68-pixel window of the stem output it needs arrives by LDS-DMA (8 planes = 2 terms x 4 channel groups; out-of-
-//      image pieces land as zeros = the first conv's padding);
-//   2. wave r computes row r of the 5 x 65 intermediate region (5 M-tiles of 16 pixels x 2 cout tiles) with the dense-tap
-//      scheme of conv_s4.hip (two full matrix instructions per 8 channels + the collected ninth tap), weights straight from
-//      L2 into registers one block ahead (no LDS space);
-//   3. bias, ReLU, zero outside the image (the second conv's padding), split into the two fp16 terms, and into LDS - odd and
-//      even columns in separate planes, so that a lane's stride-2 pixel (2 ox + kx) is a stride-1 slot for the second conv;
-//   4. waves 0..3 compute one 16-pixel M-tile x 2 cout tiles of the stride-2 conv from those planes;
-//   5. bias, ReLU, range guard, packed-pair (or fp32 NCHW) store.
-// The intermediate region is recomputed at tile borders (5 rows for 4, 65 columns for 64: 1.27x the first conv's flops).
-// Arithmetic per layer is that of conv_s4.hip: three fp16 products per fp32 multiply, fp32 accumulation, round-to-nearest
-// split (operand bound 2^-23), weights pre-scaled by a power of two.
+// The stem writes the packed-pair layout of conv_mfma.h (two fp16 terms per value, [B][2][C/4][H][W][4]).  A workgroup (4 waves)
+// owns a strip of 31 output columns of one frame and MARCHES DOWN it, two output rows per step:
+//   * stem rows live in a ring of three 4-row blocks in LDS; the block of step s + 1 is fetched by LDS-DMA while step s
+//     computes (no exposed window latency; every stem row is read once per strip: 66/62 of the tensor);
+//   * the first conv computes only the 4 NEW intermediate rows of a step (the fifth is the last row of the step before and stays
+//     in LDS): 4 x 63 pixels = 252 = 15.75 M-tiles of 16 LINEARISED pixels (a tile may wrap from one row into the next) = 4 per
+//     wave - strips of 31 columns exist for this: 32 would need 4 x 65 = 16.25 tiles.  Dense-tap scheme of conv_s4.hip (two
+//     full matrix instructions per 8 channels + the collected ninth tap);
+//   * its weights (5 blocks x 2 cout tiles, 80 registers) stay in registers for the whole strip - two waves per SIMD, 216
+//     registers; the second conv's (7 blocks, one cout tile per wave) are loaded from L2 between the M-tiles of the split
+//     phase and have arrived by the time the barrier behind it is passed;
+//   * bias, ReLU, zero outside the image (= the second conv's padding), round-to-nearest split, and into LDS with odd and even
+//     columns in separate halves of a row, so that a lane's stride-2 pixel (2 ox + kx) is a stride-1 slot for the second conv;
+//   * a step's results are stored at the START of the next step, so that the wait for the next window block (vmcnt counts
+//     stores on gfx950) never waits for stores that were just issued.
+// A strip is cut into vertical segments to fill the chip; a segment starts with one masked step (peeled) that only produces
+// the intermediate row above its first output row.  Arithmetic per layer is that of conv_s4.hip: three fp16 products per fp32
+// multiply, fp32 accumulation, round-to-nearest split (operand bound 2^-23), weights pre-scaled by a power of two, range guard.
+//
+// History (profiles/r03_experiments.md): the first form computed one 2 x 32 output tile per workgroup (5 waves, 7 x 68 window,
+// weights from L2 or LDS): correct, 1.00 / 1.19 ms per 16 frames against 0.46 + 0.36 ms for conv_split + conv_dma - every tile
+// one dependent chain at 2.5 waves per SIMD (tools/probe_front.py: 22 000 clocks per tile, the matrix pipe busy for 7 000).
+// This form: 0.42 ms.
 #include "conv_epilogue.h"
 #include "pf_prof.h"
+#include <type_traits>
 
 namespace pf {
 
-typedef float fr_f32x4 __attribute__((ext_vector_type(4)));
-typedef split_x8 fr_h8;
-typedef split_x4 fr_h4;
-typedef __attribute__((address_space(3))) void *fr_lds_ptr_t;
-[[maybe_unused]] constexpr unsigned kFrOob = 0x80000000u;
+typedef float fm_f32x4 __attribute__((ext_vector_type(4)));
+typedef split_x8 fm_h8;
+typedef split_x4 fm_h4;
+typedef __attribute__((address_space(3))) void *fm_lds_ptr_t;
+[[maybe_unused]] constexpr unsigned kFmOob = 0x80000000u;
 
 #ifndef PF_PROBE
 #define PF_PROBE 0
 #endif
-#if PF_PROBE   // shader-clock stamps of every wave of one workgroup in the middle of the grid (tools/probe_front.py): slot 8 wave + i
-#define FR_PROBE(i) do { if (lane == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.z == gridDim.z / 2 && a.probe) a.probe[8 * wave + (i)] = clock64(); } while (0)
+#if PF_PROBE   // shader-clock stamps of one workgroup in the middle of the grid, steps 2.. (tools/probe_front.py): slot 16 wave + i
+#define FM_PROBE(i) do { if (lane == 0 && step == 5 && blockIdx.x == gridDim.x / 2 && blockIdx.z == gridDim.z / 2 && a.probe) a.probe[16 * wave + (i)] = clock64(); } while (0)
 #else
-#define FR_PROBE(i) do { } while (0)
+#define FM_PROBE(i) do { } while (0)
 #endif
 
-template <int TW2_, bool WLDS_>
 struct FrontCfg {
-    static constexpr int TH2 = 2, TW2 = TW2_;          // output tile of the stride-2 conv
-    static constexpr bool WLDS = WLDS_;                // both weight sets resident in LDS (DMA at workgroup start) instead of read from L2 per block
-    static constexpr int YR = 2 * TH2 + 1;             // rows of the intermediate region (5)
-    static constexpr int YC = 2 * TW2 + 1;             // ... and columns (65 / 33)
-    static constexpr int MT1 = (YC + 15) / 16;         // M-tiles per intermediate row (the last holds one column)
-    static constexpr int XR = YR + 2, XC = YC + 3;     // stem window: 7 rows x 68 / 36 pixels (starts at an even column)
-    static constexpr int XPIECES = XR * (XC / 2);      // 16-B pieces (2 pixels x 4 channels of one term) per plane
-    static constexpr int XPLANE = XPIECES * 16;        // bytes
-    static constexpr int C0G = 4, C1G = 6;             // channel groups of the stem output (16) and of the intermediate (24)
-    static constexpr int XBYTES = 2 * C0G * XPLANE;    // [term][group] planes
-    static constexpr int YSA = TW2 + 1, YSB = TW2;     // slots per row of the odd-column (local j even) / even-column plane
-    static constexpr int YPA = YR * YSA * 8, YPAIR = YR * (YSA + YSB) * 8;   // bytes: first plane, both planes of a (term, group)
-    static constexpr int YBYTES = 2 * C1G * YPAIR;
-    static constexpr int NB1 = 5, NB2 = 7;             // weight blocks per cout tile: s4_blocks_total(2 rounds), (3 rounds)
-    static constexpr int WBLK = 2 * 64 * 16;           // one block of one tile: [term][lane][8 fp16]
-    static constexpr int W1BYTES = WLDS ? 2 * NB1 * WBLK : 0, W2BYTES = WLDS ? 2 * NB2 * WBLK : 0;
-    static constexpr int W1_OFF = XBYTES + YBYTES, W2_OFF = W1_OFF + W1BYTES;
-    static constexpr int BIAS_OFF = W2_OFF + W2BYTES;  // 2 x 32 floats
+    static constexpr int TW2 = 31;                      // output columns of a strip
+    static constexpr int YC = 2 * TW2 + 1;              // intermediate columns (63)
+    static constexpr int NPX1 = 4 * YC;                 // new intermediate pixels per step (252)
+    static constexpr int NPX2 = 2 * TW2;                // outputs per step (62)
+    static constexpr int XC = YC + 3;                   // stem window columns (66, starts at an even column)
+    static constexpr int XROWP = XC / 2;                // 16-B pieces (2 pixels x 4 channels of one term) per row
+    static constexpr int XROW = XROWP * 16;             // bytes per row of one plane (528)
+    static constexpr int XBPLANE = 4 * XROW;            // one (term, group) plane of a 4-row block (2112)
+    static constexpr int XBLK = 8 * XBPLANE;            // [term][group] planes of a block (16896)
+    static constexpr int XPIECES = XBLK / 16;           // 1056
+    static constexpr int XRING = 3 * XBLK;
+    static constexpr int YSA = TW2 + 1, YSB = TW2;      // slots of the even-column / odd-column half of an intermediate row
+    static constexpr int YROW = (YSA + YSB) * 8;        // 504
+    static constexpr int YPLANE = 5 * YROW;             // rows 0..2 of the step, carried row of even / odd steps
+    static constexpr int YBYTES = 12 * YPLANE;          // [term][6 groups]
+    static constexpr int X_OFF = YBYTES;                // LDS: [intermediate | window ring | bias]: the intermediate planes at offset 0 keep every
+    static constexpr int BIAS_OFF = XRING + YBYTES;     // ds_write / ds_read offset of the split phase and the second conv inside the 16-bit immediate
     static constexpr int LDS_BYTES = BIAS_OFF + 256;
-    static constexpr int NTHR = 64 * YR;               // one wave per intermediate row
-    static constexpr int XP = 2 * C0G * XPIECES, W1P = W1BYTES / 16, W2P = W2BYTES / 16;   // 16-B pieces
-    static constexpr int NDMA = (XP + W1P + W2P + NTHR - 1) / NTHR;
-    static constexpr int NN2 = TW2 / 16;               // cout tiles per wave in the second conv (waves 0..3 = M-tile x NN2 tiles)
+    static constexpr int NB1 = 5, NB2 = 7;              // weight blocks per cout tile (conv_s4.hip: s4_blocks_total(2), (3))
+    static constexpr int NIT = (XPIECES + 255) / 256;   // DMA instructions per thread and block
 };
 
-__device__ __forceinline__ fr_h8 fr_join(fr_h4 lo, fr_h4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+// range_acc (conv_mfma.h) in two instructions: max3 with |.| source modifiers (written with fmaxf / fabsf hipcc quiets every input first: 7)
+__device__ __forceinline__ float fm_range(float m, const fm_f32x4 &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(x0), "v"(x1));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(x2), "v"(x3));
+#endif
+    return m;
+}
+__device__ __forceinline__ fm_h8 fm_join(fm_h4 lo, fm_h4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
-// one block of packed weights for both cout tiles: [tile][block][term][lane][8 fp16]; from LDS or straight from L2
-struct FrW {
-    fr_h8 h[2], m[2];
-};
-template <typename P>
-__device__ __forceinline__ FrW fr_load_w(P w, int nblocks, int blk, int lane) {
-    FrW r;
-    P p = w + ((size_t)blk * 2 * 64 + lane) * 16;
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        r.h[n] = *reinterpret_cast<const fr_h8 *>(p + (size_t)n * nblocks * 2 * 64 * 16);
-        r.m[n] = *reinterpret_cast<const fr_h8 *>(p + (size_t)n * nblocks * 2 * 64 * 16 + 64 * 16);
-    }
-    return r;
+// split_terms4 (conv_mfma.h) in 6 instructions instead of 10: mid = fp16(x - hi) is one mixed-precision FMA per value
+// (v_fma_mixlo/mixhi_f16: hi read as fp16, x as fp32, the exact fp32 difference rounded to nearest even into one half of the
+// result register) instead of convert-back, subtract, convert.  Same bits: x - hi is exact in fp32 either way.
+__device__ __forceinline__ void fm_split4(const fm_f32x4 &v, fm_h4 &hi, fm_h4 &mid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const split_x2 h0 = __builtin_convertvector(f32x2{v[0], v[1]}, split_x2), h1 = __builtin_convertvector(f32x2{v[2], v[3]}, split_x2);
+    unsigned m0, m1;
+    const unsigned h0u = __builtin_bit_cast(unsigned, h0), h1u = __builtin_bit_cast(unsigned, h1);
+    const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(m0) : "v"(h0u), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m0) : "v"(h0u), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(m1) : "v"(h1u), "v"(x2));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m1) : "v"(h1u), "v"(x3));
+    const split_x2 q0 = __builtin_bit_cast(split_x2, m0), q1 = __builtin_bit_cast(split_x2, m1);
+    hi = fm_h4{h0[0], h0[1], h1[0], h1[1]};
+    mid = fm_h4{q0[0], q0[1], q1[0], q1[1]};
+#endif
 }
 
-template <int TW2_, bool WLDS_>
-__global__ __launch_bounds__(320, 3) void conv_front_kernel(FrontArgs a) {   // 2 workgroups of 5 waves per CU: up to 3 waves on a SIMD
+__global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using C = FrontCfg<TW2_, WLDS_>;
+    using C = FrontCfg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *xs = smem, *ys = smem + C::XBYTES;
+    unsigned char *xs = smem + C::X_OFF, *ys = smem;
+    static_assert(C::X_OFF % 16 == 0, "DMA destinations are 16-B aligned");
     float *bias_lds = reinterpret_cast<float *>(smem + C::BIAS_OFF);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile_lin, dummy;
-    xcd_tile_order(a.tilesX * a.tilesY, tile_lin, dummy);
-    const int tileY = tile_lin / a.tilesX, tileX = tile_lin - tileY * a.tilesX, b = blockIdx.z;
-    const int oy0 = tileY * C::TH2, ox0 = tileX * C::TW2;
-    FR_PROBE(0);
-    const int yr0 = 2 * oy0 - 1, yc0 = 2 * ox0 - 1;      // intermediate region origin (stride-1 coordinates)
-    const int xr0 = yr0 - 1, xc0 = yc0 - 1;              // stem window origin; xc0 = 2 ox0 - 2 is even
-
-    // ---- 1. stem window (and, WLDS, both weight sets) -> LDS in one DMA burst; bias values of both convs.  The LDS regions
-    //      [window | intermediate | weights 1 | weights 2] are one piece-indexed target: piece p goes to byte 16 p past its region's base
-    {
-        const size_t plane_bytes = (size_t)a.H1 * a.W1 * 8;
-        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(reinterpret_cast<const char *>(a.x) + (size_t)b * 2 * C::C0G * plane_bytes), 0, 0x7FFFFFFF, 0x00020000);
-        const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w1, 0, 0x7FFFFFFF, 0x00020000);
-        const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, 0x7FFFFFFF, 0x00020000);
-        constexpr int XPAD = (C::XP + 63) / 64 * 64, W1PAD = (C::W1P + 63) / 64 * 64;   // every DMA instruction of a wave stays inside one region
-        constexpr int TOTAL = XPAD + W1PAD + C::W2P, NIT = (TOTAL + C::NTHR - 1) / C::NTHR;
-        static_assert(C::W1P % 64 == 0 && C::W2P % 64 == 0, "weight regions are whole DMA instructions");
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int p0 = it * C::NTHR + wave * 64, p = p0 + lane;     // p0 uniform
-            if (p0 >= TOTAL) break;
-            if (p0 < XPAD) {
-                const int pl = p / C::XPIECES, q = p - pl * C::XPIECES;
-                const int row = q / (C::XC / 2), cp = q - row * (C::XC / 2);
-                const int gy = xr0 + row, gx = xc0 + 2 * cp;
-                const bool ok = p < C::XP && gy >= 0 && gy < a.H1 && gx >= 0 && gx < a.W1;
-                const unsigned off = ok ? (unsigned)(pl * plane_bytes) + (unsigned)(gy * a.W1 + gx) * 8u : kFrOob;
-                if (p < C::XP) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (fr_lds_ptr_t)(xs + p0 * 16), 16, off, 0, 0, 0);
-            } else if (p0 < XPAD + W1PAD) {
-                const int q0 = p0 - XPAD;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w1rs, (fr_lds_ptr_t)(smem + C::W1_OFF + q0 * 16), 16, (unsigned)(q0 + lane) * 16u, 0, 0, 0);
-            } else {
-                const int q0 = p0 - XPAD - W1PAD;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rs, (fr_lds_ptr_t)(smem + C::W2_OFF + q0 * 16), 16, (unsigned)(q0 + lane) * 16u, 0, 0, 0);
-            }
-        }
-        if (wave == 0) {
-            const __amdgpu_buffer_rsrc_t b1 = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias1, 0, 0x7FFFFFFF, 0x00020000);
-            const __amdgpu_buffer_rsrc_t b2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias2, 0, 0x7FFFFFFF, 0x00020000);
-            if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(b1, (fr_lds_ptr_t)bias_lds, 4, (unsigned)lane * 4u, 0, 0, 0);
-            if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(b2, (fr_lds_ptr_t)(bias_lds + 32), 4, (unsigned)lane * 4u, 0, 0, 0);
-        }
-    }
     const int g = lane >> 4, li = lane & 15;
-    // tap of lane group g in the two full instructions / the collected tap (conv_s4.hip): (ky, kx)
-    const int ky0 = g >> 1, kx0 = g & 1, ky1 = g < 2 ? 2 : g - 2, kx1 = g < 2 ? g : 2;
-    const fr_h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned char *w1l = smem + C::W1_OFF, *w2l = smem + C::W2_OFF;
-    auto load_w1 = [&](int blk) { return C::WLDS ? fr_load_w(w1l, C::NB1, blk, lane) : fr_load_w(reinterpret_cast<const char *>(a.w1), C::NB1, blk, lane); };
-    auto load_w2 = [&](int blk) { return C::WLDS ? fr_load_w(w2l, C::NB2, blk, lane) : fr_load_w(reinterpret_cast<const char *>(a.w2), C::NB2, blk, lane); };
+    const int strip = (int)blockIdx.x % a.tilesX, seg = (int)blockIdx.x / a.tilesX, b = blockIdx.z;
+    const int ox0 = strip * C::TW2, oyA = seg * a.seg_steps * 2;
+    const int nsteps = min(a.seg_steps, (a.H2 - oyA + 1) / 2);   // steps of this segment (2 output rows each)
+    const int yc0 = 2 * ox0 - 1, xc0 = yc0 - 1;                  // first intermediate / stem column of the strip (xc0 even)
 
-    // ---- 2. first conv: wave r = row r of the intermediate region, MT1 M-tiles x 2 cout tiles
-    fr_f32x4 acc[C::MT1][2];
+    // ---- window blocks: block k (k = 0 is the block of the masked first step) = stem rows 2 oyA - 3 + 4k .. + 3
+    const size_t plane_bytes = (size_t)a.H1 * a.W1 * 8;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(reinterpret_cast<const char *>(a.x) + (size_t)b * 8 * plane_bytes), 0, 0x7FFFFFFF, 0x00020000);
+    // this thread's pieces of a block (piece p = it * 256 + tid -> plane, row, piece of the row): byte offset in row 0 of the image
+    // (a multiple of 16) | row, or out of range when the column is outside the image
+    unsigned dma_pk[C::NIT];
 #pragma unroll
-    for (int m = 0; m < C::MT1; ++m) acc[m][0] = acc[m][1] = fr_f32x4{0.f, 0.f, 0.f, 0.f};
-    FrW wcur;
-    if (!C::WLDS) wcur = load_w1(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window (and the weights) have landed
-    FR_PROBE(1);
-    __syncthreads();
-    FR_PROBE(2);
-    if (C::WLDS) wcur = load_w1(0);
-    {
-        const int r = wave;
-        fr_h8 col_h[C::MT1], col_m[C::MT1];
+    for (int it = 0; it < C::NIT; ++it) {
+        const int p = it * 256 + tid, pl = p / (4 * C::XROWP), rem = p - pl * (4 * C::XROWP);
+        const int row = rem / C::XROWP, cp = rem - row * C::XROWP, gx = xc0 + 2 * cp;
+        dma_pk[it] = (p < C::XPIECES && gx >= 0 && gx < a.W1) ? ((unsigned)(pl * plane_bytes) + (unsigned)gx * 8u) | (unsigned)row : kFmOob;
+    }
+    const unsigned row_bytes = (unsigned)a.W1 * 8u;
+    auto issue_block = [&](int k, int slot) {
+        const int r0 = 2 * oyA - 3 + 4 * k;
 #pragma unroll
-        for (int m = 0; m < C::MT1; ++m) col_h[m] = col_m[m] = zero8;
-        auto xfrag = [&](int rd, int ky, int kx, int m, fr_h8 &h, fr_h8 &md) {
-            // entries 2 rd, 2 rd + 1 of term 0 / 1: plane (term * 4 + entry)
-            const unsigned char *p = xs + ((r + ky) * C::XC + 16 * m + li + kx) * 8 + (2 * rd) * C::XPLANE;
-            h = fr_join(*reinterpret_cast<const fr_h4 *>(p), *reinterpret_cast<const fr_h4 *>(p + C::XPLANE));
-            md = fr_join(*reinterpret_cast<const fr_h4 *>(p + C::C0G * C::XPLANE), *reinterpret_cast<const fr_h4 *>(p + (C::C0G + 1) * C::XPLANE));
-        };
-        // the three products of one weight block with all M-tiles: product by product, so that consecutive matrix instructions
-        // never hit the same accumulator (a dependent v_mfma pair waits out the first one's latency)
-        auto mfmas = [&](const FrW &w, const fr_h8 (&fh)[C::MT1], const fr_h8 (&fm)[C::MT1]) {
-#pragma unroll
-            for (int m = 0; m < C::MT1; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = PF_MFMA_SPLIT(w.h[n], fm[m], acc[m][n]);
-#pragma unroll
-            for (int m = 0; m < C::MT1; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = PF_MFMA_SPLIT(w.m[n], fh[m], acc[m][n]);
-#pragma unroll
-            for (int m = 0; m < C::MT1; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = PF_MFMA_SPLIT(w.h[n], fh[m], acc[m][n]);
-        };
-        int blk = 0;
-#pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const FrW wnext = load_w1(blk + 1);   // (the block after the last full one is the collected block)
-                const int ky = s == 0 ? ky0 : ky1, kx = s == 0 ? kx0 : kx1;
-                fr_h8 fh[C::MT1], fm[C::MT1];
-#pragma unroll
-                for (int m = 0; m < C::MT1; ++m) xfrag(rd, ky, kx, m, fh[m], fm[m]);
-                mfmas(wcur, fh, fm);
-                wcur = wnext;
-                ++blk;
-            }
-            if (g == rd) {   // the ninth tap of this round's entries: K-slice rd of the collected instruction
-#pragma unroll
-                for (int m = 0; m < C::MT1; ++m) xfrag(rd, 2, 2, m, col_h[m], col_m[m]);
-            }
+        for (int it = 0; it < C::NIT; ++it) {
+            const bool whole = (it + 1) * 256 <= C::XPIECES;          // every thread has a piece in this pass
+            if (!whole && it * 256 + wave * 64 >= C::XPIECES) break;   // uniform
+            const int gy = r0 + (int)(dma_pk[it] & 3u);
+            const bool ok = (dma_pk[it] != kFmOob) & ((unsigned)gy < (unsigned)a.H1);
+            const unsigned off = ok ? (dma_pk[it] & ~3u) + (unsigned)gy * row_bytes : kFmOob;
+            if (whole || it * 256 + tid < C::XPIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (fm_lds_ptr_t)(xs + slot * C::XBLK + (it * 256 + wave * 64) * 16), 16, off, 0, 0, 0);
         }
-        mfmas(wcur, col_h, col_m);
-        FR_PROBE(3);
+    };
+    issue_block(0, 0);
+    if (wave == 0) {
+        const __amdgpu_buffer_rsrc_t b1 = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias1, 0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t b2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias2, 0, 0x7FFFFFFF, 0x00020000);
+        if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(b1, (fm_lds_ptr_t)bias_lds, 4, (unsigned)lane * 4u, 0, 0, 0);
+        if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(b2, (fm_lds_ptr_t)(bias_lds + 32), 4, (unsigned)lane * 4u, 0, 0, 0);
+    }
 
-        // ---- 3. bias, ReLU, zero outside the image, split, -> LDS (odd / even columns in separate planes)
-        const int gy = yr0 + r;
-        const bool row_in = gy >= 0 && gy < a.H1;
+    // ---- first conv's weights: resident.  [tile][block][term][lane][8 fp16]
+    fm_h8 w1h[C::NB1][2], w1m[C::NB1][2];
+    {
+        const char *wp = reinterpret_cast<const char *>(a.w1) + lane * 16;
 #pragma unroll
-        for (int m = 0; m < C::MT1; ++m) {
-            const int j = 16 * m + li;                   // local column of this lane's pixel
-            if (j >= C::YC) continue;
-            const int gx = yc0 + j;
-            const bool in = row_in && gx >= 0 && gx < a.W1;
+        for (int k = 0; k < C::NB1; ++k)
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const int gi = n * 4 + g;                // channel group of the intermediate tensor
-                if (gi >= C::C1G) continue;
-                const fr_f32x4 b4 = *reinterpret_cast<const fr_f32x4 *>(bias_lds + n * 16 + 4 * g);
-                fr_f32x4 v = acc[m][n];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[q] = v[q] * a.scale1 + b4[q];
-                    if (a.relu1) v[q] = fmaxf(v[q], 0.f);
-                    v[q] = in ? v[q] : 0.f;              // the second conv's zero padding
-                }
-                range_commit(a.status, range_acc(0.f, v[0], v[1], v[2], v[3]));   // (rare path: never taken in range)
-                fr_h4 hi, mid;
-                split_terms4(v, hi, mid);
-                unsigned char *p = ys + (size_t)gi * C::YPAIR + ((j & 1) ? C::YPA + (r * C::YSB + (j >> 1)) * 8 : (r * C::YSA + (j >> 1)) * 8);
-                *reinterpret_cast<fr_h4 *>(p) = hi;
-                *reinterpret_cast<fr_h4 *>(p + C::C1G * C::YPAIR) = mid;
+                w1h[k][n] = *reinterpret_cast<const fm_h8 *>(wp + ((size_t)(n * C::NB1 + k) * 2 + 0) * 1024);
+                w1m[k][n] = *reinterpret_cast<const fm_h8 *>(wp + ((size_t)(n * C::NB1 + k) * 2 + 1) * 1024);
             }
-        }
     }
-    FrW w2;
-    if (!C::WLDS) w2 = load_w2(0);
-    FR_PROBE(4);
-    __syncthreads();
-    FR_PROBE(5);
-    if (C::WLDS) w2 = load_w2(0);
+    const int n2 = wave & 1;   // the second conv: this wave's cout tile, M-tiles 2 (wave >> 1), + 1
+    // (buffer loads: uniform resource + the lane's 32-bit offset + a scalar block offset - with plain pointers hipcc keeps one
+    // 64-bit per-lane address per block alive across the loop: 22 registers)
+    const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(reinterpret_cast<const char *>(a.w2) + (size_t)n2 * C::NB2 * 2048), 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned w2lane = (unsigned)lane * 16u;
 
-    // ---- 4. second conv (stride 2): waves 0..3.  TW2 = 32: wave = (output row, 16-pixel half), both cout tiles;
-    //      TW2 = 16: wave = (output row, cout tile)
-    if (wave < 4) {
-        constexpr int NN = C::NN2;
-        const int ry = wave >> 1, hx = NN == 2 ? (wave & 1) : 0, n0 = NN == 2 ? 0 : (wave & 1);
-        // one accumulator PER PRODUCT (summed at the end): with 1-2 cout tiles per wave the three products of a block would
-        // otherwise be a dependent chain on one register quad
-        fr_f32x4 acc2[NN][3];
+    // ---- per-lane geometry, PACKED: the loop derives everything it needs from these few registers in every step (a few dozen
+    //      vector instructions) behind an opaque copy - left to itself the compiler hoists every derived offset and mask out of
+    //      the loop and the kernel no longer fits 256 registers beside its resident weights.
+    //      first conv: M-tile m of this wave = linearised pixels 64 wave + 16 m + li of the 4 x 63 new rows: q | column << 2 | valid << 8 | ... << 9
+    int qc_pack[4];
 #pragma unroll
-        for (int n = 0; n < NN; ++n) acc2[n][0] = acc2[n][1] = acc2[n][2] = fr_f32x4{0.f, 0.f, 0.f, 0.f};
-        // local column 2 (16 hx + i) + kx: kx = 0, 2 -> the j-even plane (slots i, i + 1), kx = 1 -> the j-odd plane (slot i)
-        auto yfrag = [&](int rd, int ky, int kx, fr_h8 &h, fr_h8 &md) {
-            const int slot = 16 * hx + li + (kx >> 1);
-            const unsigned char *p = ys + (size_t)(2 * rd) * C::YPAIR +
-                                     ((kx & 1) ? C::YPA + ((2 * ry + ky) * C::YSB + slot) * 8 : ((2 * ry + ky) * C::YSA + slot) * 8);
-            h = fr_join(*reinterpret_cast<const fr_h4 *>(p), *reinterpret_cast<const fr_h4 *>(p + C::YPAIR));
-            md = fr_join(*reinterpret_cast<const fr_h4 *>(p + C::C1G * C::YPAIR), *reinterpret_cast<const fr_h4 *>(p + (C::C1G + 1) * C::YPAIR));
-        };
-        auto mfma3 = [&](const FrW &w, const fr_h8 &fh, const fr_h8 &fm) {
-#pragma unroll
-            for (int n = 0; n < NN; ++n) {
-                const fr_h8 wh = NN == 2 ? w.h[n] : (n0 ? w.h[1] : w.h[0]), wm = NN == 2 ? w.m[n] : (n0 ? w.m[1] : w.m[0]);
-                acc2[n][0] = PF_MFMA_SPLIT(wh, fm, acc2[n][0]);
-                acc2[n][1] = PF_MFMA_SPLIT(wm, fh, acc2[n][1]);
-                acc2[n][2] = PF_MFMA_SPLIT(wh, fh, acc2[n][2]);
-            }
-        };
-        fr_h8 col_h = zero8, col_m = zero8;
-        int blk = 0;
-#pragma unroll
-        for (int rd = 0; rd < 3; ++rd) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const FrW wnext = load_w2(blk + 1);
-                fr_h8 fh, fm;
-                yfrag(rd, s == 0 ? ky0 : ky1, s == 0 ? kx0 : kx1, fh, fm);
-                mfma3(w2, fh, fm);
-                w2 = wnext;
-                ++blk;
-            }
-            if (g == rd) yfrag(rd, 2, 2, col_h, col_m);
-        }
-        mfma3(w2, col_h, col_m);
-        FR_PROBE(6);
-
-        // ---- 5. bias, ReLU, range guard, store: lane (g, i) = couts 4g..4g+3 of output pixel (oy0 + ry, ox0 + 16 hx + i)
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) the compiler can see: nothing left to protect inside the stores (conv_s4.hip)
-        const int oy = oy0 + ry, ox = ox0 + 16 * hx + li;
-        if (oy < a.H2 && ox < a.W2) {
-            const size_t hw = (size_t)a.H2 * a.W2, pix = (size_t)oy * a.W2 + ox;
-            const size_t term = (size_t)a.dst_c4 * hw * 8;
-            const bool mis = (a.dst_choff & 2) != 0;
-            float vmax = 0.f;
-            typedef split_x2 h2;
-#pragma unroll
-            for (int nn = 0; nn < NN; ++nn) {
-                const int n = n0 + nn;
-                const int co = n * 16 + 4 * g;
-                if (co >= a.C2 + 2) continue;
-                const fr_f32x4 b4 = *reinterpret_cast<const fr_f32x4 *>(bias_lds + 32 + n * 16 + 4 * g);
-                fr_f32x4 v = (acc2[nn][0] + acc2[nn][1]) + acc2[nn][2];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[q] = v[q] * a.scale2 + b4[q];
-                    if (a.relu2) v[q] = fmaxf(v[q], 0.f);
-                }
-                vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
-                if (a.dst_fmt) {
-                    fr_h4 hi, mid;
-                    split_terms4(v, hi, mid);
-                    const int chb = a.dst_choff + co;
-                    const bool ok0 = chb < a.dst_limit, ok1 = chb + 2 < a.dst_limit;
-                    char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
-                    if (!mis) {
-                        if (ok1) {
-                            *reinterpret_cast<fr_h4 *>(p) = hi;
-                            *reinterpret_cast<fr_h4 *>(p + term) = mid;
-                        } else if (ok0) {
-                            *reinterpret_cast<h2 *>(p) = h2{hi[0], hi[1]};
-                            *reinterpret_cast<h2 *>(p + term) = h2{mid[0], mid[1]};
-                        }
-                    } else {
-                        if (ok0) {
-                            *reinterpret_cast<h2 *>(p + 4) = h2{hi[0], hi[1]};
-                            *reinterpret_cast<h2 *>(p + 4 + term) = h2{mid[0], mid[1]};
-                        }
-                        if (ok1) {
-                            *reinterpret_cast<h2 *>(p + hw * 8) = h2{hi[2], hi[3]};
-                            *reinterpret_cast<h2 *>(p + hw * 8 + term) = h2{mid[2], mid[3]};
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (co + q < a.C2) a.dst[((size_t)b * a.dst_ctotal + a.dst_choff + co + q) * hw + pix] = v[q];
-                }
-            }
-            range_commit(a.status, vmax);
-        }
+    for (int m = 0; m < 4; ++m) {
+        const int p = 64 * wave + 16 * m + li, pv = min(p, C::NPX1 - 1), q = pv / C::YC;
+        const int c = pv - q * C::YC;
+        qc_pack[m] = q | (c << 2) | ((p < C::NPX1) << 8) | ((((c & 1) ? C::YSA * 8 : 0) + (c >> 1) * 8) << 9);   // + byte offset of the column in an intermediate row
     }
-    FR_PROBE(7);
+    //      second conv: pixels 16 mt + li of the 2 x 31 outputs of a step: row | column << 1 | valid << 6
+    int rc_pack[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = 16 * (2 * (wave >> 1) + j) + li, pv = min(p, C::NPX2 - 1), ry = pv / C::TW2;
+        rc_pack[j] = ry | ((pv - ry * C::TW2) << 1) | ((p < C::NPX2) << 6);
+    }
+
+    // results of the previous step, stored at the start of the next one
+    fm_f32x4 pend[2];
+    int pend_oy = -1;
+    pend[0] = pend[1] = fm_f32x4{0.f, 0.f, 0.f, 0.f};
+    // stores go through a buffer resource of the frame with 32-bit offsets computed in the step (no 64-bit per-lane pointers
+    // kept alive across the loop)
+    const unsigned hw2 = (unsigned)(a.H2 * a.W2), term2 = (unsigned)a.dst_c4 * hw2 * 8u;
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(reinterpret_cast<char *>(a.dst) + (size_t)b * (a.dst_fmt ? 2 * (size_t)term2 : (size_t)a.dst_ctotal * hw2 * 4)), 0, 0x7FFFFFFF, 0x00020000);
+    typedef unsigned fm_u2 __attribute__((ext_vector_type(2)));
+    // every lane of this wave stores whole 4-channel units of a packed tensor (uniform): no per-lane channel tests
+    const bool whole_units = a.dst_fmt && (a.dst_choff & 3) == 0 && a.dst_choff + n2 * 16 + 16 <= a.dst_limit && n2 * 16 + 16 <= a.C2 + 2;
+    auto store_pending = [&](const int (&rc)[2], int gq) {
+        if (pend_oy < 0) return;   // uniform
+        const int co = n2 * 16 + 4 * gq;
+        if (whole_units) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int oy = pend_oy + (rc[j] & 1), ox = ox0 + ((rc[j] >> 1) & 31);
+                fm_h4 hi, mid;
+                fm_split4(pend[j], hi, mid);
+                const unsigned off = (unsigned)(oy * a.W2 + ox) * 8u + (unsigned)((a.dst_choff + co) >> 2) * hw2 * 8u;
+                if (((rc[j] >> 6) != 0) & (oy < a.H2) & (ox < a.W2)) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fm_u2, hi), drs, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fm_u2, mid), drs, off, term2, 0);
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oy = pend_oy + (rc[j] & 1), ox = ox0 + ((rc[j] >> 1) & 31);
+            if (!(rc[j] >> 6) || oy >= a.H2 || ox >= a.W2 || co >= a.C2 + 2) continue;
+            const unsigned pix = (unsigned)(oy * a.W2 + ox);
+            const fm_f32x4 v = pend[j];
+            if (a.dst_fmt) {
+                fm_h4 hi, mid;
+                fm_split4(v, hi, mid);
+                const fm_u2 hu = __builtin_bit_cast(fm_u2, hi), mu = __builtin_bit_cast(fm_u2, mid);
+                const int chb = a.dst_choff + co;
+                const bool k0 = chb < a.dst_limit, k1 = chb + 2 < a.dst_limit;
+                const unsigned off = pix * 8u + (unsigned)(chb >> 2) * hw2 * 8u;
+                if (k1) {            // (the plan only fuses a destination range that starts on a channel group: dst_choff % 4 == 0)
+                    __builtin_amdgcn_raw_buffer_store_b64(hu, drs, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(mu, drs, off, term2, 0);
+                } else if (k0) {
+                    __builtin_amdgcn_raw_buffer_store_b32(hu[0], drs, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(mu[0], drs, off, term2, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float vr = v[r];
+                    if (co + r < a.C2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vr), drs, ((unsigned)(a.dst_choff + co + r) * hw2 + pix) * 4u, 0, 0);
+                }
+            }
+        }
+    };
+
+    // one wait the compiler's wait-count pass can see, for the resident weights: the loop's own waits are inline asm, and a load the
+    // pass believes pending would be protected by s_waitcnt vmcnt(n) in front of its first use in EVERY step - a wait that, in
+    // the loop, falls on the window block just requested
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    float vmax = 0.f;
+    int cur = 0, prev = 2, next = 1;        // ring slots of the window blocks of this step, the one before, the one after
+    // step -1 = the masked first step (intermediate row 2 oyA - 1 only); step s >= 0 = output rows oyA + 2 s, + 1
+    auto run_step = [&](auto first_c, const int step) {
+        constexpr bool FIRST = decltype(first_c)::value;   // the masked first step of the segment (peeled: the steady-state body carries none of its tests)
+        FM_PROBE(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the block (and, first time, the bias values) have landed
+        __syncthreads();                                    // everyone's have; everyone is done with the previous step's LDS reads
+        FM_PROBE(1);
+        if (step + 1 < nsteps) issue_block(step + 2, next);
+        FM_PROBE(2);
+        int gq = g, qc[4], rc[2];
+        asm volatile("" : "+v"(gq));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            qc[m] = qc_pack[m];
+            asm volatile("" : "+v"(qc[m]));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            rc[j] = rc_pack[j];
+            asm volatile("" : "+v"(rc[j]));
+        }
+        store_pending(rc, gq);
+        pend_oy = -1;
+        FM_PROBE(3);
+        // taps of lane group g in the two full instructions and the collected one (conv_s4.hip)
+        const int kyt[3] = {gq >> 1, gq < 2 ? 2 : gq - 2, 2}, kxt[3] = {gq & 1, gq < 2 ? gq : 2, 2};
+        const int sp = step & 1;                            // slot 3 + sp holds this step's last row, 3 + (sp ^ 1) the carried one
+        const int yr0 = 2 * oyA + 4 * step;                 // first new intermediate row
+
+        // ---- first conv: 4 M-tiles x 2 cout tiles per wave
+        fm_f32x4 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = fm_f32x4{0.f, 0.f, 0.f, 0.f};
+        // byte offset of the lane's fragment of (M-tile, tap): stem row d = q - 1 + ky relative to the step's first new row is in the
+        // previous block (d < 1) or in this one
+        int xoff[4][3];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int d = (qc[m] & 3) - 1 + kyt[t];
+                xoff[m][t] = (d < 1 ? prev * C::XBLK + (d + 3) * C::XROW : cur * C::XBLK + (d - 1) * C::XROW) + (((qc[m] >> 2) & 63) + kxt[t]) * 8 +
+                             (t == 2 ? (gq & 1) * 2 * C::XBPLANE : 0);
+            }
+        auto xfrag = [&](int m, int t, int rd, fm_h8 &h, fm_h8 &md) {
+            const unsigned char *p = xs + xoff[m][t] + rd * 2 * C::XBPLANE;
+            h = fm_join(*reinterpret_cast<const fm_h4 *>(p), *reinterpret_cast<const fm_h4 *>(p + C::XBPLANE));
+            md = fm_join(*reinterpret_cast<const fm_h4 *>(p + 4 * C::XBPLANE), *reinterpret_cast<const fm_h4 *>(p + 5 * C::XBPLANE));
+        };
+        // 10 units of (weight block, M-tile pair); the fragments of unit u + 1 are read while the matrix instructions of unit u
+        // issue (two waves per SIMD do not hide an LDS round trip per unit: tools/probe_front.py)
+        auto mfmas1 = [&](int k, int m0, const fm_h8 (&fh)[2], const fm_h8 (&fmd)[2]) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m0 + m][n] = PF_MFMA_SPLIT(w1h[k][n], fmd[m], acc[m0 + m][n]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m0 + m][n] = PF_MFMA_SPLIT(w1m[k][n], fh[m], acc[m0 + m][n]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m0 + m][n] = PF_MFMA_SPLIT(w1h[k][n], fh[m], acc[m0 + m][n]);
+        };
+        FM_PROBE(4);
+        {
+            fm_h8 fh[2][2], fmd[2][2];
+            auto load_unit = [&](int u, int buf) {
+                const int k = u >> 1, m0 = (u & 1) * 2;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) xfrag(m0 + m, k < 4 ? (k & 1) : 2, k < 4 ? (k >> 1) : 0, fh[buf][m], fmd[buf][m]);
+            };
+            load_unit(0, 0);
+#pragma unroll
+            for (int u = 0; u < 2 * C::NB1; ++u) {
+                if (u + 1 < 2 * C::NB1) load_unit(u + 1, (u + 1) & 1);
+                mfmas1(u >> 1, (u & 1) * 2, fh[u & 1], fmd[u & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        FM_PROBE(5);
+
+        // the second conv's weights for this step: loaded from L2 BETWEEN the M-tiles of the split phase below (a block costs 8
+        // registers and every finished M-tile frees 8 accumulators: all seven blocks in front of the phase do not fit beside the
+        // resident first-conv weights), used after the next barrier
+        fm_h8 w2h[C::NB2], w2m[C::NB2];
+        auto load_w2 = [&](int k) {
+            if (FIRST) return;
+            w2h[k] = __builtin_bit_cast(fm_h8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, w2lane, k * 2048, 0));
+            w2m[k] = __builtin_bit_cast(fm_h8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, w2lane, k * 2048 + 1024, 0));
+        };
+        load_w2(0);
+        load_w2(1);
+
+        // ---- bias, ReLU, zero outside the image (= the second conv's padding), split, -> LDS by column parity
+        const float lo1 = a.relu1 ? 0.f : -__builtin_inff();
+        fm_f32x4 b1v[2];
+        b1v[0] = *reinterpret_cast<const fm_f32x4 *>(bias_lds + 4 * gq);
+        b1v[1] = *reinterpret_cast<const fm_f32x4 *>(bias_lds + 16 + 4 * gq);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int q = qc[m] & 3, c = (qc[m] >> 2) & 63;
+            const bool live = ((qc[m] >> 8) & 1) && !(FIRST && q != 3);
+            const int slot = q == 3 ? 3 + sp : q;
+            const int gy = yr0 + q, gx = yc0 + c;
+            // outside the image the value is the second conv's zero padding: median(v, lo, hi) with lo = hi = 0 there, (ReLU floor, +inf) inside
+            const bool in = ((unsigned)gy < (unsigned)a.H1) & ((unsigned)gx < (unsigned)a.W1);
+            const float lom = in ? lo1 : 0.f, him = in ? __builtin_inff() : 0.f;
+            unsigned char *row = ys + slot * C::YROW + (qc[m] >> 9) + gq * C::YPLANE;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int gi = n * 4 + gq;
+                fm_f32x4 v = acc[m][n];
+                v = __builtin_elementwise_fma(v, fm_f32x4{a.scale1, a.scale1, a.scale1, a.scale1}, b1v[n]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], lom, him);
+                if (gi >= 6 || !live) continue;
+                vmax = fm_range(vmax, v);
+                fm_h4 hi, mid;
+                fm_split4(v, hi, mid);
+                *reinterpret_cast<fm_h4 *>(row + n * 4 * C::YPLANE) = hi;
+                *reinterpret_cast<fm_h4 *>(row + (6 + n * 4) * C::YPLANE) = mid;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (m == 0) load_w2(2);
+            if (m == 1) { load_w2(3); load_w2(4); }
+            if (m == 2) load_w2(5);
+            if (m == 3) load_w2(6);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        FM_PROBE(6);
+        __syncthreads();
+        FM_PROBE(7);
+        if (FIRST) {
+            prev = cur; cur = next; next = next == 2 ? 0 : next + 1;
+            return;
+        }
+
+        // ---- second conv (stride 2): 2 M-tiles of this wave's cout tile; one accumulator per product
+        fm_f32x4 acc2[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc2[j][0] = acc2[j][1] = acc2[j][2] = fm_f32x4{0.f, 0.f, 0.f, 0.f};
+        // intermediate row e = 2 ry + ky - 1 relative to the step's first new row: -1 = the carried row, 3 = this step's last row
+        int yoff[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int e = 2 * (rc[j] & 1) + kyt[t] - 1;
+                yoff[j][t] = (e < 0 ? 3 + (sp ^ 1) : e == 3 ? 3 + sp : e) * C::YROW + ((kxt[t] & 1) ? C::YSA * 8 : 0) +
+                             (((rc[j] >> 1) & 31) + (kxt[t] >> 1)) * 8 + (t == 2 ? min(gq, 2) * 2 * C::YPLANE : 0);
+            }
+        auto yfrag = [&](int j, int t, int rd, fm_h8 &h, fm_h8 &md) {
+            const unsigned char *p = ys + yoff[j][t] + rd * 2 * C::YPLANE;
+            h = fm_join(*reinterpret_cast<const fm_h4 *>(p), *reinterpret_cast<const fm_h4 *>(p + C::YPLANE));
+            md = fm_join(*reinterpret_cast<const fm_h4 *>(p + 6 * C::YPLANE), *reinterpret_cast<const fm_h4 *>(p + 7 * C::YPLANE));
+        };
+        {
+            fm_h8 fh[2][2], fmd[2][2];
+            auto load_blk = [&](int k, int buf) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) yfrag(j, k < 6 ? (k & 1) : 2, k < 6 ? (k >> 1) : 0, fh[buf][j], fmd[buf][j]);
+            };
+            load_blk(0, 0);
+#pragma unroll
+            for (int k = 0; k < C::NB2; ++k) {
+                if (k + 1 < C::NB2) load_blk(k + 1, (k + 1) & 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc2[j][0] = PF_MFMA_SPLIT(w2h[k], fmd[k & 1][j], acc2[j][0]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc2[j][1] = PF_MFMA_SPLIT(w2m[k], fh[k & 1][j], acc2[j][1]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc2[j][2] = PF_MFMA_SPLIT(w2h[k], fh[k & 1][j], acc2[j][2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        FM_PROBE(8);
+        {
+            const float lo2 = a.relu2 ? 0.f : -__builtin_inff();
+            const fm_f32x4 b4 = *reinterpret_cast<const fm_f32x4 *>(bias_lds + 32 + n2 * 16 + 4 * gq);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                fm_f32x4 v = (acc2[j][0] + acc2[j][1]) + acc2[j][2];
+                v = __builtin_elementwise_max(__builtin_elementwise_fma(v, fm_f32x4{a.scale2, a.scale2, a.scale2, a.scale2}, b4), fm_f32x4{lo2, lo2, lo2, lo2});
+                if (rc[j] >> 6) vmax = fm_range(vmax, v);
+                pend[j] = v;
+            }
+            pend_oy = oyA + 2 * step;
+        }
+        FM_PROBE(9);
+        prev = cur; cur = next; next = next == 2 ? 0 : next + 1;
+    };
+    run_step(std::true_type{}, -1);
+    for (int step = 0; step < nsteps; ++step) run_step(std::false_type{}, step);
+    store_pending(rc_pack, g);
+    range_commit(a.status, vmax);
 #endif
 }
 
-// shapes this kernel is built for: 16 -> C1 <= 24 -> C2 <= 32 channels, 3x3 stride 1 then 3x3 stride 2, even width
-bool conv_front_supports(int c0, int c1, int c2, int h1, int w1) { return c0 == 16 && c1 == 24 && c2 <= 32 && c2 > 16 && (w1 & 3) == 0 && h1 >= 2; }
+// shapes this kernel is built for: 16 -> 24 -> (16, 32] channels, 3x3 stride 1 then 3x3 stride 2, width % 4 == 0 (16-B pieces), 32-bit offsets
+bool conv_front_supports(int c0, int c1, int c2, int h1, int w1) {
+    return c0 == 16 && c1 == 24 && c2 <= 32 && c2 > 16 && (w1 & 3) == 0 && h1 >= 2 && (long long)h1 * w1 < (1ll << 24);
+}
 
-template <int TW2_, bool WLDS_>
-static int launch_front_cfg(const FrontArgs &a0, int B, hipStream_t s) {
-    using C = FrontCfg<TW2_, WLDS_>;
+// strips of 31 output columns x segments of `seg_steps` steps (2 output rows each) x frames.  The segment count is the one that
+// fills the chip's workgroup slots (2 per CU) best, counting the masked first step of every segment as lost work
+int launch_conv_front(const FrontArgs &a0, int B, hipStream_t s) {
+    using C = FrontCfg;
     static_assert(C::LDS_BYTES <= 81920, "two workgroups per CU");
     FrontArgs a = a0;
     a.tilesX = (a.W2 + C::TW2 - 1) / C::TW2;
-    a.tilesY = (a.H2 + C::TH2 - 1) / C::TH2;
+    const int steps = (a.H2 + 1) / 2;
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = 2 * cus;
+    }
+    int best = 1;
+    double best_eff = 0.0;
+    for (int nseg = 1; nseg <= steps && nseg <= 64; ++nseg) {
+        const int seg_steps = (steps + nseg - 1) / nseg, used = (steps + seg_steps - 1) / seg_steps;
+        if (used != nseg) continue;
+        const long items = (long)a.tilesX * nseg * B;
+        const long rounds = (items + slots - 1) / slots;
+        const double eff = (double)items / (double)(rounds * slots) * steps / (double)(nseg * (seg_steps + 1));
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best = nseg;
+        }
+    }
+    a.seg_steps = (steps + best - 1) / best;
+    a.tilesY = (steps + a.seg_steps - 1) / a.seg_steps;
     static bool attr_set = false;
     if (!attr_set) {
-        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_front_kernel<TW2_, WLDS_>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         C::LDS_BYTES));
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
     }
-    char label[96];
-    snprintf(label, sizeof(label), "void pf::conv_front_kernel<%d, %d>(pf::FrontArgs)", TW2_, (int)WLDS_);
     const double px1 = (double)B * a.H1 * a.W1, px2 = (double)B * a.H2 * a.W2;
-    ProfScope ps(s, label, 2.0 * 9 * (px1 * 16 * a.C1 + px2 * a.C1 * a.C2), 4.0 * (px1 * 16 + px2 * a.C2 + 9.0 * (16 * a.C1 + a.C1 * a.C2)));
-    hipLaunchKernelGGL((conv_front_kernel<TW2_, WLDS_>), dim3(a.tilesX * a.tilesY, 1, B), dim3(C::NTHR), C::LDS_BYTES, s, a);
+    ProfScope ps(s, "pf::conv_front_kernel(pf::FrontArgs)", 2.0 * 9 * (px1 * 16 * a.C1 + px2 * a.C1 * a.C2),
+                 4.0 * (px1 * 16 + px2 * a.C2 + 9.0 * (16 * a.C1 + a.C1 * a.C2)));
+    hipLaunchKernelGGL(conv_front_kernel, dim3(a.tilesX * a.tilesY, 1, B), dim3(256), C::LDS_BYTES, s, a);
     PF_LAUNCH_CHECK("conv_front_kernel");
     return PF_OK;
-}
-
-// variant 1: 2 x 32 output tiles, weights from L2 one block ahead; variant 2: 2 x 16 tiles, both weight sets resident in LDS
-int launch_conv_front(const FrontArgs &a, int variant, int B, hipStream_t s) {
-    return variant == 2 ? launch_front_cfg<16, true>(a, B, s) : launch_front_cfg<32, false>(a, B, s);
 }
 
 }  // namespace pf

@@ -235,13 +235,14 @@ struct FrontArgs {
     float *dst;             // [B][dst_ctotal][H2][W2] fp32 or packed pairs
     int dst_fmt, dst_c4, dst_ctotal, dst_choff, dst_limit;
     int H1, W1, H2, W2, C1, C2, relu1, relu2;
-    int tilesX, tilesY;
+    int tilesX, tilesY;     // strips x vertical segments (set by the launcher)
+    int seg_steps;          // steps (2 output rows each) per segment (set by the launcher)
     unsigned *status;
     long long *probe;       // PF_PROBE builds only (tools/probe_front.py), else nullptr
 };
 
 bool conv_front_supports(int c0, int c1, int c2, int h1, int w1);
-int launch_conv_front(const FrontArgs &a, int variant, int B, hipStream_t s);   // variant = plan option fuse_front (1 | 2)
+int launch_conv_front(const FrontArgs &a, int B, hipStream_t s);
 
 // Kernel/shape choice for one stride-1 conv (conv_select.cpp): kind 1 = conv_dma (p0 = WM, p1 = NT),
 // kind 2 = conv_wave (p0 = MH, p1 = NT, p2 = WK), (kind 3 was conv_valu: the whole 3x3 conv on v_pk_fma_f32, measured and removed - DESIGN.md 3.2),

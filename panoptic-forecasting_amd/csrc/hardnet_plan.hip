@@ -63,7 +63,7 @@ struct pf_plan {
 
 namespace pf {
 int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_split = 1, g_opt_packed_acts = 1, g_opt_tag_ops = 0;
-int g_opt_range_guard = 1, g_opt_fuse_front = 0;   // fuse_front: built and bit-checked, measured slower than the three kernels (profiles/r03_experiments.md)
+int g_opt_range_guard = 1, g_opt_fuse_front = 1;   // fuse_front: conv_front.hip (0: stem -> conv_split -> conv_dma stride 2, three kernels)
 extern int g_opt_use_tuned;
 }
 
@@ -415,7 +415,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                     n1.src[0].ch == p->tensors[o.dst].channels && n1.dst_choff == 0 && n1.cout == p->tensors[n1.dst].channels &&
                     p->readers[o.dst] == 1 && p->readers[n1.dst] == 1 && n1.relu && p->conv[i + 1].has_s4 && p->conv[i + 1].s4_rounds == 2 &&
                     n2.kind == OP_CONV && n2.k == 3 && n2.stride == 2 && n2.n_src == 1 && n2.src[0].tensor == n1.dst && n2.src[0].choff == 0 &&
-                    n2.src[0].ch == n1.cout && p->conv[i + 2].has_front && (n2.dst_choff & 1) == 0 &&
+                    n2.src[0].ch == n1.cout && p->conv[i + 2].has_front && (n2.dst_choff & 3) == 0 &&
                     conv_front_supports((int)o.cout, (int)n1.cout, (int)n2.cout, out.h, out.w) && stem_writes_s4(probe) && g_conv_force.kind == 0;
         }
         if (front) {
@@ -475,7 +475,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                          n1.cout, n2.cout, o2.h, o2.w);
                 prof_set_tag(tag);
             }
-            if ((rc = launch_conv_front(f, p->opt_fuse_front, B, s))) return rc;
+            if ((rc = launch_conv_front(f, B, s))) return rc;
             fmt[o.dst] = 1;            // pf_hardnet_tensor_read unpacks the stem output
             p->last_fmt = fmt;
             i += 2;

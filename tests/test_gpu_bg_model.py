@@ -91,13 +91,13 @@ def test_fused_front_end_vs_oracle(h, w, b):
     cu = {k: v.cuda() for k, v in inp.items()}
     cu['seg'] = cu['seg'].to(torch.uint8)                 # 255 = void stays 255
     outs = {}
-    for fuse in (1, 2, 0):     # 1: 2 x 32 tiles, weights from L2; 2: 2 x 16 tiles, weights resident in LDS; 0: three kernels
+    for fuse in (1, 0):        # 1: conv_front.hip; 0: three kernels
         m = _model(h, w, fuse_front=fuse)
         pflib.profile(True)
         outs[fuse] = m.predict(cu, None)
         labels = [r['label'] for r in pflib.profile_results()]
         pflib.profile(False)
-        assert any('conv_front_kernel' in l for l in labels) == bool(fuse), labels
+        assert any('conv_front_' in l for l in labels) == bool(fuse), labels
         for tap in ('base.0', 'base.2'):
             got = view_tensor(m._get_plan(), m._ws, tap, b, h, w).cpu()
             err = (got - taps[tap]).abs().max().item()
@@ -105,7 +105,7 @@ def test_fused_front_end_vs_oracle(h, w, b):
         assert m.range_status() == 0
         assert (outs[fuse]['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max() <= LOGIT_TOL
         assert (outs[fuse]['seg'].cpu() == ref['seg']).float().mean().item() >= AGREE
-    for fuse in (1, 2):
+    for fuse in (1,):
         assert (outs[fuse]['orig_size_logits'] - outs[0]['orig_size_logits']).abs().max().item() <= 1e-4
 
 

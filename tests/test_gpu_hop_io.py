@@ -89,14 +89,22 @@ def test_file_hop_equals_in_register_hop(tmp_path):
         assert hop_io.read_png(depths[0]).dtype == np.uint16
         samples.append(hop_io.load_bg_inputs(labels, depth_pngs=depths, min_depth=0.1, max_depth=200))
     batch = hop_io.collate(samples)
-    bg = build_model(dict(base, task='bg', model=mp))
-    bg.load_state_dict(sd)
-    two_stage = bg.predict(batch, None)
-    fused = build_model(dict(base, task='bg_forecast', model=dict(mp, return_logits=True)))
-    fused.load_state_dict(sd)
-    one = fused.predict(inp, None)
-    assert torch.equal(two_stage['seg'].long(), one['seg'].long())
-    assert torch.equal(two_stage['orig_size_logits'], one['orig_size_logits'])
+    # the file path hands the network dense int64 labels (stem -> three front-end kernels), the in-register path u8 labels (stem ->
+    # conv_front.hip): with the fused front end switched off both run the same kernels on the same bits - equal bit for bit;
+    # with the default plan the two front ends agree to the network's tolerance
+    for fuse in (0, 1):
+        bg = build_model(dict(base, task='bg', model=dict(mp, fuse_front=fuse)))
+        bg.load_state_dict(sd)
+        two_stage = bg.predict(batch, None)
+        fused = build_model(dict(base, task='bg_forecast', model=dict(mp, return_logits=True, fuse_front=fuse)))
+        fused.load_state_dict(sd)
+        one = fused.predict(inp, None)
+        if fuse == 0:
+            assert torch.equal(two_stage['seg'].long(), one['seg'].long())
+            assert torch.equal(two_stage['orig_size_logits'], one['orig_size_logits'])
+        else:
+            assert (two_stage['seg'].long() == one['seg'].long()).float().mean().item() >= 0.9999
+            assert (two_stage['orig_size_logits'] - one['orig_size_logits']).abs().max().item() <= 1e-4
 
 
 def test_export_driver_with_reference_flags(tmp_path):
