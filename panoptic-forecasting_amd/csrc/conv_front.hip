@@ -129,18 +129,20 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
         dma_pk[it] = (p < C::XPIECES && gx >= 0 && gx < a.W1) ? ((unsigned)(pl * plane_bytes) + (unsigned)gx * 8u) | (unsigned)row : kFmOob;
     }
     const unsigned row_bytes = (unsigned)a.W1 * 8u;
-    auto issue_block = [&](int k, int slot) {
+    // pass `it` of block k (a DMA instruction per wave)
+    auto issue_part = [&](int k, int slot, int it) {
         const int r0 = 2 * oyA - 3 + 4 * k;
+        const bool whole = (it + 1) * 256 <= C::XPIECES;            // every thread has a piece in this pass
+        if (!whole && it * 256 + wave * 64 >= C::XPIECES) return;   // uniform
+        const int gy = r0 + (int)(dma_pk[it] & 3u);
+        const bool ok = (dma_pk[it] != kFmOob) & ((unsigned)gy < (unsigned)a.H1);
+        const unsigned off = ok ? (dma_pk[it] & ~3u) + (unsigned)gy * row_bytes : kFmOob;
+        if (whole || it * 256 + tid < C::XPIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (fm_lds_ptr_t)(xs + slot * C::XBLK + (it * 256 + wave * 64) * 16), 16, off, 0, 0, 0);
+    };
+    auto issue_block = [&](int k, int slot) {
 #pragma unroll
-        for (int it = 0; it < C::NIT; ++it) {
-            const bool whole = (it + 1) * 256 <= C::XPIECES;          // every thread has a piece in this pass
-            if (!whole && it * 256 + wave * 64 >= C::XPIECES) break;   // uniform
-            const int gy = r0 + (int)(dma_pk[it] & 3u);
-            const bool ok = (dma_pk[it] != kFmOob) & ((unsigned)gy < (unsigned)a.H1);
-            const unsigned off = ok ? (dma_pk[it] & ~3u) + (unsigned)gy * row_bytes : kFmOob;
-            if (whole || it * 256 + tid < C::XPIECES)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (fm_lds_ptr_t)(xs + slot * C::XBLK + (it * 256 + wave * 64) * 16), 16, off, 0, 0, 0);
-        }
+        for (int it = 0; it < C::NIT; ++it) issue_part(k, slot, it);
     };
     issue_block(0, 0);
     if (wave == 0) {
@@ -200,12 +202,12 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
     typedef unsigned fm_u2 __attribute__((ext_vector_type(2)));
     // every lane of this wave stores whole 4-channel units of a packed tensor (uniform): no per-lane channel tests
     const bool whole_units = a.dst_fmt && (a.dst_choff & 3) == 0 && a.dst_choff + n2 * 16 + 16 <= a.dst_limit && n2 * 16 + 16 <= a.C2 + 2;
-    auto store_pending = [&](const int (&rc)[2], int gq) {
+    auto store_pending = [&](const int (&rc)[2], int gq, int j0, int j1) {   // M-tiles j0 .. j1 - 1 of the previous step
         if (pend_oy < 0) return;   // uniform
         const int co = n2 * 16 + 4 * gq;
         if (whole_units) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = j0; j < j1; ++j) {
                 const int oy = pend_oy + (rc[j] & 1), ox = ox0 + ((rc[j] >> 1) & 31);
                 fm_h4 hi, mid;
                 fm_split4(pend[j], hi, mid);
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
             return;
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = j0; j < j1; ++j) {
             const int oy = pend_oy + (rc[j] & 1), ox = ox0 + ((rc[j] >> 1) & 31);
             if (!(rc[j] >> 6) || oy >= a.H2 || ox >= a.W2 || co >= a.C2 + 2) continue;
             const unsigned pix = (unsigned)(oy * a.W2 + ox);
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the block (and, first time, the bias values) have landed
         __syncthreads();                                    // everyone's have; everyone is done with the previous step's LDS reads
         FM_PROBE(1);
-        if (step + 1 < nsteps) issue_block(step + 2, next);
+        if (step + 1 < nsteps) issue_block(step + 2, next);   // as early as possible: a block takes ~4 000 clocks to land under load
         FM_PROBE(2);
         int gq = g, qc[4], rc[2];
         asm volatile("" : "+v"(gq));
@@ -274,8 +276,6 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
             rc[j] = rc_pack[j];
             asm volatile("" : "+v"(rc[j]));
         }
-        store_pending(rc, gq);
-        pend_oy = -1;
         FM_PROBE(3);
         // taps of lane group g in the two full instructions and the collected one (conv_s4.hip)
         const int kyt[3] = {gq >> 1, gq < 2 ? 2 : gq - 2, 2}, kxt[3] = {gq & 1, gq < 2 ? gq : 2, 2};
@@ -289,12 +289,13 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
         // byte offset of the lane's fragment of (M-tile, tap): stem row d = q - 1 + ky relative to the step's first new row is in the
         // previous block (d < 1) or in this one
         int xoff[4][3];
+        const int xprev = __builtin_amdgcn_readfirstlane(prev * C::XBLK + 3 * C::XROW), xcur = __builtin_amdgcn_readfirstlane(cur * C::XBLK - C::XROW);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int d = (qc[m] & 3) - 1 + kyt[t];
-                xoff[m][t] = (d < 1 ? prev * C::XBLK + (d + 3) * C::XROW : cur * C::XBLK + (d - 1) * C::XROW) + (((qc[m] >> 2) & 63) + kxt[t]) * 8 +
+                xoff[m][t] = (d < 1 ? xprev : xcur) + __mul24(d, C::XROW) + (((qc[m] >> 2) & 63) + kxt[t]) * 8 +
                              (t == 2 ? (gq & 1) * 2 * C::XBPLANE : 0);
             }
         auto xfrag = [&](int m, int t, int rd, fm_h8 &h, fm_h8 &md) {
@@ -331,8 +332,13 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
             for (int u = 0; u < 2 * C::NB1; ++u) {
                 if (u + 1 < 2 * C::NB1) load_unit(u + 1, (u + 1) & 1);
                 mfmas1(u >> 1, (u & 1) * 2, fh[u & 1], fmd[u & 1]);
+                // the previous step's results go out between the units: right behind the DMA instructions above, the stores of all eight
+                // waves of a CU queue up in front of the one address unit (1 700 clocks per wave with no matrix instruction issued)
+                if (u == 3) store_pending(rc, gq, 0, 1);
+                if (u == 6) store_pending(rc, gq, 1, 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            pend_oy = -1;
         }
         FM_PROBE(5);
 
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
             // outside the image the value is the second conv's zero padding: median(v, lo, hi) with lo = hi = 0 there, (ReLU floor, +inf) inside
             const bool in = ((unsigned)gy < (unsigned)a.H1) & ((unsigned)gx < (unsigned)a.W1);
             const float lom = in ? lo1 : 0.f, him = in ? __builtin_inff() : 0.f;
-            unsigned char *row = ys + slot * C::YROW + (qc[m] >> 9) + gq * C::YPLANE;
+            unsigned char *row = ys + __mul24(slot, C::YROW) + (qc[m] >> 9) + __mul24(gq, C::YPLANE);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int gi = n * 4 + gq;
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int e = 2 * (rc[j] & 1) + kyt[t] - 1;
-                yoff[j][t] = (e < 0 ? 3 + (sp ^ 1) : e == 3 ? 3 + sp : e) * C::YROW + ((kxt[t] & 1) ? C::YSA * 8 : 0) +
+                yoff[j][t] = __mul24(e < 0 ? 3 + (sp ^ 1) : e == 3 ? 3 + sp : e, C::YROW) + ((kxt[t] & 1) ? C::YSA * 8 : 0) +
                              (((rc[j] >> 1) & 31) + (kxt[t] >> 1)) * 8 + (t == 2 ? min(gq, 2) * 2 * C::YPLANE : 0);
             }
         auto yfrag = [&](int j, int t, int rd, fm_h8 &h, fm_h8 &md) {
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
     };
     run_step(std::true_type{}, -1);
     for (int step = 0; step < nsteps; ++step) run_step(std::false_type{}, step);
-    store_pending(rc_pack, g);
+    store_pending(rc_pack, g, 0, 2);
     range_commit(a.status, vmax);
 #endif
 }
