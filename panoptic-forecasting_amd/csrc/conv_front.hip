@@ -69,36 +69,8 @@ struct FrontCfg {
     static constexpr int NIT = (XPIECES + 255) / 256;   // DMA instructions per thread and block
 };
 
-// range_acc (conv_mfma.h) in two instructions: max3 with |.| source modifiers (written with fmaxf / fabsf hipcc quiets every input first: 7)
-__device__ __forceinline__ float fm_range(float m, const fm_f32x4 &v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
-    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(x0), "v"(x1));
-    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(x2), "v"(x3));
-#endif
-    return m;
-}
 __device__ __forceinline__ fm_h8 fm_join(fm_h4 lo, fm_h4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
-// split_terms4 (conv_mfma.h) in 6 instructions instead of 10: mid = fp16(x - hi) is one mixed-precision FMA per value
-// (v_fma_mixlo/mixhi_f16: hi read as fp16, x as fp32, the exact fp32 difference rounded to nearest even into one half of the
-// result register) instead of convert-back, subtract, convert.  Same bits: x - hi is exact in fp32 either way.
-__device__ __forceinline__ void fm_split4(const fm_f32x4 &v, fm_h4 &hi, fm_h4 &mid) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const split_x2 h0 = __builtin_convertvector(f32x2{v[0], v[1]}, split_x2), h1 = __builtin_convertvector(f32x2{v[2], v[3]}, split_x2);
-    unsigned m0, m1;
-    const unsigned h0u = __builtin_bit_cast(unsigned, h0), h1u = __builtin_bit_cast(unsigned, h1);
-    const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(m0) : "v"(h0u), "v"(x0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m0) : "v"(h0u), "v"(x1));
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(m1) : "v"(h1u), "v"(x2));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m1) : "v"(h1u), "v"(x3));
-    const split_x2 q0 = __builtin_bit_cast(split_x2, m0), q1 = __builtin_bit_cast(split_x2, m1);
-    hi = fm_h4{h0[0], h0[1], h1[0], h1[1]};
-    mid = fm_h4{q0[0], q0[1], q1[0], q1[1]};
-#endif
-}
 
 __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -210,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
             for (int j = j0; j < j1; ++j) {
                 const int oy = pend_oy + (rc[j] & 1), ox = ox0 + ((rc[j] >> 1) & 31);
                 fm_h4 hi, mid;
-                fm_split4(pend[j], hi, mid);
+                split_terms4(pend[j], hi, mid);
                 const unsigned off = (unsigned)(oy * a.W2 + ox) * 8u + (unsigned)((a.dst_choff + co) >> 2) * hw2 * 8u;
                 if (((rc[j] >> 6) != 0) & (oy < a.H2) & (ox < a.W2)) {
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fm_u2, hi), drs, off, 0, 0);
@@ -227,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
             const fm_f32x4 v = pend[j];
             if (a.dst_fmt) {
                 fm_h4 hi, mid;
-                fm_split4(v, hi, mid);
+                split_terms4(v, hi, mid);
                 const fm_u2 hu = __builtin_bit_cast(fm_u2, hi), mu = __builtin_bit_cast(fm_u2, mid);
                 const int chb = a.dst_choff + co;
                 const bool k0 = chb < a.dst_limit, k1 = chb + 2 < a.dst_limit;
@@ -377,9 +349,9 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], lom, him);
                 if (gi >= 6 || !live) continue;
-                vmax = fm_range(vmax, v);
+                vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
                 fm_h4 hi, mid;
-                fm_split4(v, hi, mid);
+                split_terms4(v, hi, mid);
                 *reinterpret_cast<fm_h4 *>(row + n * 4 * C::YPLANE) = hi;
                 *reinterpret_cast<fm_h4 *>(row + (6 + n * 4) * C::YPLANE) = mid;
             }
@@ -444,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
             for (int j = 0; j < 2; ++j) {
                 fm_f32x4 v = (acc2[j][0] + acc2[j][1]) + acc2[j][2];
                 v = __builtin_elementwise_max(__builtin_elementwise_fma(v, fm_f32x4{a.scale2, a.scale2, a.scale2, a.scale2}, b4), fm_f32x4{lo2, lo2, lo2, lo2});
-                if (rc[j] >> 6) vmax = fm_range(vmax, v);
+                if (rc[j] >> 6) vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
                 pend[j] = v;
             }
             pend_oy = oyA + 2 * step;

@@ -89,19 +89,30 @@ typedef split_t split_x2 __attribute__((ext_vector_type(2)));
 typedef split_t split_x4 __attribute__((ext_vector_type(4)));
 typedef split_t split_x8 __attribute__((ext_vector_type(8)));
 constexpr float kSplitMaxAbs = 65504.f;   // largest |x| the pair represents (to 2^-23)
-// two values at a time: {hi0, hi1}, {mid0, mid1}; v_cvt_pk_f16_f32 (gfx950) rounds to nearest even, two values per issue
+// two values at a time: {hi0, hi1}, {mid0, mid1}.  hi: v_cvt_pk_f16_f32 (gfx950) rounds to nearest even, two values per issue.
+// mid = fp16(x - hi): one mixed-precision FMA per value (v_fma_mixlo / mixhi_f16: hi read as fp16, x as fp32, the fp32 difference
+// - exact - rounded to nearest even into one half of the result register) - 3 instructions per pair where convert back, subtract,
+// convert takes 5; the same bits (tests/test_gpu_conv.py::test_s4_layout_round_trip pins the device's patterns to the host's)
 __device__ __forceinline__ void split_terms2(float x0, float x1, split_x2 &hi, split_x2 &mid) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 x = {x0, x1};
-    hi = __builtin_convertvector(x, split_x2);
-    mid = __builtin_convertvector(x - __builtin_convertvector(hi, f32x2), split_x2);
+    hi = __builtin_convertvector(f32x2{x0, x1}, split_x2);
+    const unsigned hu = __builtin_bit_cast(unsigned, hi);
+    unsigned mu;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(mu) : "v"(hu), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(mu) : "v"(hu), "v"(x1));
+    mid = __builtin_bit_cast(split_x2, mu);
 #endif
 }
 // range guard: m = running max |v| of what a lane stores; one compare + (never taken) branch at the end.  NaN cannot arise
 // from finite guarded inputs (products <= 65504 * 2^15, K <= a few thousand: the fp32 accumulators cannot overflow)
+// (two v_max3_f32 with |.| source modifiers; written with fmaxf / fabsf hipcc quiets every input first: 7 instructions)
 __device__ __forceinline__ float range_acc(float m, float a, float b, float c, float d) {
-    return fmaxf(fmaxf(m, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(d)));
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(c), "v"(d));
+#endif
+    return m;
 }
 __device__ __forceinline__ void range_commit(unsigned *status, float m) {
 #if defined(__HIP_DEVICE_COMPILE__)

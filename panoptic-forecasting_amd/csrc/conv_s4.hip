@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
         const size_t hw = (size_t)a.Hout * a.Wout;
         const size_t term = (size_t)a.dst_c4 * hw * 8;
         const bool mis = (a.dst_choff & 2) != 0;   // the range starts in the middle of a group (uniform)
+        const float relu_lo = a.relu ? 0.f : -__builtin_inff();
         float vmax = 0.f;                          // range guard of the operand split (conv_mfma.h)
         typedef split_x2 h2;
         // one pixel's 4 channels (group tails, ranges that start in the middle of a group)
@@ -386,10 +387,7 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
                 s4_f32x4 v = acc[m][n];
                 const s4_f32x4 b4 = *reinterpret_cast<const s4_f32x4 *>(bias_lds + n * 16 + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = v[r] * a.acc_scale + b4[r];
-                    if (a.relu) v[r] = fmaxf(v[r], 0.f);
-                }
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r] * a.acc_scale + b4[r], relu_lo);   // relu_lo = 0 or -inf: one max, no select
                 vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
                 if (a.dst_fmt) {
                     store_px(co, pix, v);
@@ -416,12 +414,8 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
                 const s4_f32x4 b4 = *reinterpret_cast<const s4_f32x4 *>(bias_lds + n * 16 + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v0[r] = v0[r] * a.acc_scale + b4[r];   // acc_scale = 2^-k of the weight scaling: exact
-                    v1[r] = v1[r] * a.acc_scale + b4[r];
-                    if (a.relu) {
-                        v0[r] = fmaxf(v0[r], 0.f);
-                        v1[r] = fmaxf(v1[r], 0.f);
-                    }
+                    v0[r] = fmaxf(v0[r] * a.acc_scale + b4[r], relu_lo);   // acc_scale = 2^-k of the weight scaling: exact
+                    v1[r] = fmaxf(v1[r] * a.acc_scale + b4[r], relu_lo);
                 }
                 vmax = range_acc(range_acc(vmax, v0[0], v0[1], v0[2], v0[3]), v1[0], v1[1], v1[2], v1[3]);
                 const int chb = a.dst_choff + co;
@@ -667,6 +661,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : (NT == 3 ? 3 : 2)) void conv_s4_
         const bool mis = (a.dst_choff & 2) != 0;
         typedef split_x2 h2;
         float vmax = 0.f;   // range guard of the operand split (conv_mfma.h)
+        const float relu_lo1 = a.relu ? 0.f : -__builtin_inff();
         // finished values of pixel (rr, q), cout tile n
         auto finish = [&](int rr, int q, int n, const int (&o0)[2], const int (&o1)[2], const float (&lx1)[2], float hy1) {
             s4_f32x4 v = acc[rr * 2 + q][n];
@@ -681,7 +676,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : (NT == 3 ? 3 : 2)) void conv_s4_
                     const float t1 = lx0 * chan[o1[q]] + lx1[q] * chan[o1[q] + 1];
                     v[r] += hy0 * t0 + hy1 * t1;
                 }
-                if (a.relu) v[r] = fmaxf(v[r], 0.f);
+                v[r] = fmaxf(v[r], relu_lo1);
             }
             vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
             return v;
