@@ -291,48 +291,12 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m0 + m][n] = PF_MFMA_SPLIT(w1h[k][n], fh[m], acc[m0 + m][n]);
         };
-        FM_PROBE(4);
-        {
-            fm_h8 fh[2][2], fmd[2][2];
-            auto load_unit = [&](int u, int buf) {
-                const int k = u >> 1, m0 = (u & 1) * 2;
-#pragma unroll
-                for (int m = 0; m < 2; ++m) xfrag(m0 + m, k < 4 ? (k & 1) : 2, k < 4 ? (k >> 1) : 0, fh[buf][m], fmd[buf][m]);
-            };
-            load_unit(0, 0);
-#pragma unroll
-            for (int u = 0; u < 2 * C::NB1; ++u) {
-                if (u + 1 < 2 * C::NB1) load_unit(u + 1, (u + 1) & 1);
-                mfmas1(u >> 1, (u & 1) * 2, fh[u & 1], fmd[u & 1]);
-                // the previous step's results go out between the units: right behind the DMA instructions above, the stores of all eight
-                // waves of a CU queue up in front of the one address unit (1 700 clocks per wave with no matrix instruction issued)
-                if (u == 3) store_pending(rc, gq, 0, 1);
-                if (u == 6) store_pending(rc, gq, 1, 2);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            pend_oy = -1;
-        }
-        FM_PROBE(5);
-
-        // the second conv's weights for this step: loaded from L2 BETWEEN the M-tiles of the split phase below (a block costs 8
-        // registers and every finished M-tile frees 8 accumulators: all seven blocks in front of the phase do not fit beside the
-        // resident first-conv weights), used after the next barrier
-        fm_h8 w2h[C::NB2], w2m[C::NB2];
-        auto load_w2 = [&](int k) {
-            if (FIRST) return;
-            w2h[k] = __builtin_bit_cast(fm_h8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, w2lane, k * 2048, 0));
-            w2m[k] = __builtin_bit_cast(fm_h8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, w2lane, k * 2048 + 1024, 0));
-        };
-        load_w2(0);
-        load_w2(1);
-
-        // ---- bias, ReLU, zero outside the image (= the second conv's padding), split, -> LDS by column parity
+        // ---- bias, ReLU, zero outside the image (= the second conv's padding), split, -> LDS by column parity: one (M-tile, cout tile)
         const float lo1 = a.relu1 ? 0.f : -__builtin_inff();
         fm_f32x4 b1v[2];
         b1v[0] = *reinterpret_cast<const fm_f32x4 *>(bias_lds + 4 * gq);
         b1v[1] = *reinterpret_cast<const fm_f32x4 *>(bias_lds + 16 + 4 * gq);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        auto split_unit = [&](int m, int n) {
             const int q = qc[m] & 3, c = (qc[m] >> 2) & 63;
             const bool live = ((qc[m] >> 8) & 1) && !(FIRST && q != 3);
             const int slot = q == 3 ? 3 + sp : q;
@@ -341,27 +305,66 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
             const bool in = ((unsigned)gy < (unsigned)a.H1) & ((unsigned)gx < (unsigned)a.W1);
             const float lom = in ? lo1 : 0.f, him = in ? __builtin_inff() : 0.f;
             unsigned char *row = ys + __mul24(slot, C::YROW) + (qc[m] >> 9) + __mul24(gq, C::YPLANE);
+            fm_f32x4 v = acc[m][n];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int gi = n * 4 + gq;
-                fm_f32x4 v = acc[m][n];
-                v = __builtin_elementwise_fma(v, fm_f32x4{a.scale1, a.scale1, a.scale1, a.scale1}, b1v[n]);
+            for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(__builtin_fmaf(v[r], a.scale1, b1v[n][r]), lom, him);
+            if (n * 4 + gq >= 6 || !live) return;
+            vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
+            fm_h4 hi, mid;
+            split_terms4(v, hi, mid);
+            *reinterpret_cast<fm_h4 *>(row + n * 4 * C::YPLANE) = hi;
+            *reinterpret_cast<fm_h4 *>(row + (6 + n * 4) * C::YPLANE) = mid;
+        };
+        // the second conv's weights for this step: loaded from L2 between the last split units (a block costs 8 registers and every
+        // finished unit frees 4 accumulators: all seven blocks at once do not fit beside the resident first-conv weights), used
+        // after the next barrier
+        fm_h8 w2h[C::NB2], w2m[C::NB2];
+        auto load_w2 = [&](int k) {
+            if (FIRST) return;
+            w2h[k] = __builtin_bit_cast(fm_h8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, w2lane, k * 2048, 0));
+            w2m[k] = __builtin_bit_cast(fm_h8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, w2lane, k * 2048 + 1024, 0));
+        };
+        FM_PROBE(4);
+        {
+            // 10 units: M-tile pair 0 through its 5 weight blocks, then pair 1 - and while pair 1's matrix instructions issue, the
+            // finished accumulators of pair 0 go through bias / split / LDS in their shadow (the split phase of all four M-tiles
+            // behind the last matrix instruction was 2 400 of a step's 10 400 clocks)
+            fm_h8 fh[2][2], fmd[2][2];
+            auto load_unit = [&](int u, int buf) {
+                const int k = u % C::NB1, m0 = (u / C::NB1) * 2;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], lom, him);
-                if (gi >= 6 || !live) continue;
-                vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
-                fm_h4 hi, mid;
-                split_terms4(v, hi, mid);
-                *reinterpret_cast<fm_h4 *>(row + n * 4 * C::YPLANE) = hi;
-                *reinterpret_cast<fm_h4 *>(row + (6 + n * 4) * C::YPLANE) = mid;
+                for (int m = 0; m < 2; ++m) xfrag(m0 + m, k < 4 ? (k & 1) : 2, k < 4 ? (k >> 1) : 0, fh[buf][m], fmd[buf][m]);
+            };
+            load_unit(0, 0);
+#pragma unroll
+            for (int u = 0; u < 2 * C::NB1; ++u) {
+                if (u + 1 < 2 * C::NB1) load_unit(u + 1, (u + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);   // the reads of the next unit go out BEFORE this unit's matrix instructions (hipcc sinks them to the last two otherwise)
+                mfmas1(u % C::NB1, (u / C::NB1) * 2, fh[u & 1], fmd[u & 1]);
+                // the previous step's results go out between the units: right behind the DMA instructions above, the stores of all eight
+                // waves of a CU queue up in front of the one address unit (1 700 clocks per wave with no matrix instruction issued)
+                if (u == 1) store_pending(rc, gq, 0, 1);
+                if (u == 3) store_pending(rc, gq, 1, 2);
+                if (u >= 5 && u <= 8) split_unit((u - 5) >> 1, (u - 5) & 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (m == 0) load_w2(2);
-            if (m == 1) { load_w2(3); load_w2(4); }
-            if (m == 2) load_w2(5);
-            if (m == 3) load_w2(6);
-            __builtin_amdgcn_sched_barrier(0);
+            pend_oy = -1;
         }
+        FM_PROBE(5);
+        load_w2(0);
+        load_w2(1);
+        split_unit(2, 0);
+        split_unit(2, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w2(2);
+        load_w2(3);
+        load_w2(4);
+        __builtin_amdgcn_sched_barrier(0);
+        split_unit(3, 0);
+        split_unit(3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w2(5);
+        load_w2(6);
         FM_PROBE(6);
         __syncthreads();
         FM_PROBE(7);
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
 #pragma unroll
             for (int k = 0; k < C::NB2; ++k) {
                 if (k + 1 < C::NB2) load_blk(k + 1, (k + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc2[j][0] = PF_MFMA_SPLIT(w2h[k], fmd[k & 1][j], acc2[j][0]);
 #pragma unroll
