@@ -76,7 +76,9 @@ def test_stage_by_stage_vs_oracle():
     assert (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max() <= LOGIT_TOL
 
 
-@pytest.mark.parametrize('h,w,b', [(128, 192, 1), (96, 160, 2), (256, 512, 1), (72, 264, 1)])
+# (204, 96, 3): one partial strip (24 of 31 columns), an odd number of output rows (51: the last step stores one row), 3 frames;
+# (72, 264): 3 strips, 18 rows; (256, 512): segments of unequal length
+@pytest.mark.parametrize('h,w,b', [(128, 192, 1), (96, 160, 2), (256, 512, 1), (72, 264, 1), (204, 96, 3)])
 def test_fused_front_end_vs_oracle(h, w, b):
     """conv_front.hip: base.1 + base.2 as one kernel on the packed-pair stem output (u8 labels select the stem variant that
     writes it).  The stem output and base.2 against the oracle's taps, the logits against the oracle, and against the same
