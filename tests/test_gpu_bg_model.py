@@ -77,7 +77,8 @@ def test_stage_by_stage_vs_oracle():
 
 
 # (204, 96, 3): one partial strip (24 of 31 columns), an odd number of output rows (51: the last step stores one row), 3 frames;
-# (72, 264): 3 strips, 18 rows; (256, 512): segments of unequal length
+# (72, 264): 3 strips, 18 rows; (256, 512): segments of unequal length.  (An odd number of stem rows never reaches the kernel: the stem
+# variant that writes packed pairs handles 2 x 2 outputs per lane and is only chosen for even sizes.)
 @pytest.mark.parametrize('h,w,b', [(128, 192, 1), (96, 160, 2), (256, 512, 1), (72, 264, 1), (204, 96, 3)])
 def test_fused_front_end_vs_oracle(h, w, b):
     """conv_front.hip: base.1 + base.2 as one kernel on the packed-pair stem output (u8 labels select the stem variant that
