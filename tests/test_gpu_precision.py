@@ -194,3 +194,38 @@ def test_whole_network_out_of_range_checkpoint_reruns_in_fp32_or_raises():
     i.load_state_dict(sd_bad)
     i.predict(cuda_inp, None)
     assert i.bg.range_status() & 1 and i.bg.range_reruns == 0
+
+
+def test_overflow_inside_the_fused_front_end_is_flagged():
+    """base.1's output never leaves LDS in conv_front.hip - it is still a tensor a split kernel reads (base.2, inside the same
+    kernel), so its producer must guard it: with base.1's BatchNorm affine scaled by 1e5 the stem output stays in range and the
+    overflow arises INSIDE the fused kernel.  Default policy: one re-run on the fp32 matrix instructions, result = oracle;
+    'ignore': the status word carries the flag and the fused kernel is what ran."""
+    import test_gpu_bg_forecast as t
+    from panoptic_forecasting_amd import lib as pflib
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.registry import build_model
+    h, w = 128, 256
+    sd = dict(t._sd())
+    for k in ('model.base.1.norm.weight', 'model.base.1.norm.bias'):
+        assert k in sd, [q for q in sd if 'base.1.' in q]
+        sd[k] = sd[k] * 1e5
+    inp = synth.make_inputs(b=1, h=h, w=w, seed=6, gap_len=3)
+    cuda_inp = {k: v.cuda() for k, v in inp.items()}
+    i = build_model(_bg_params(h, w, 15.0, on_range_overflow='ignore'))
+    i.load_state_dict(sd)
+    pflib.profile(True)
+    i.predict(cuda_inp, None)
+    labels = [r['label'] for r in pflib.profile_results()]
+    pflib.profile(False)
+    assert any('conv_front' in l for l in labels), labels
+    assert i.bg.range_status() & 1 and i.bg.range_reruns == 0
+    m = build_model(_bg_params(h, w, 15.0))
+    m.load_state_dict(sd)
+    out = m.predict(cuda_inp, None)
+    assert m.bg.range_reruns == 1
+    ref, _, _ = t.oracle_pipeline(sd, inp, h, w)
+    scale = ref['orig_size_logits'].abs().max().item()
+    err = (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max().item()
+    assert err <= 1e-4 * (1.0 + scale), (err, scale)
+    _report('overflow_inside_conv_front', {'max_abs_logit': scale, 'err_after_fp32_rerun': err, 'reruns': m.bg.range_reruns})
