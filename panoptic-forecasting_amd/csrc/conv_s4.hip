@@ -85,12 +85,14 @@ __device__ __forceinline__ bool s4_entry(const ConvArgs &a, int e, int b, size_t
     return e - e0 < gn;
 }
 
-template <int NT, int TW_>
+template <int NT, int TW_, int TH_ = 8>
 struct S4Cfg {
-    static constexpr int TW = TW_, TH = 8, MTR = TW / 16, MP = 2 * MTR;   // 4 waves x MP M-tiles = 8 rows x TW pixels
+    static constexpr int TW = TW_, TH = TH_, MTR = TW / 16, MP = 2 * MTR;   // TH / 2 waves x MP M-tiles = TH rows x TW pixels
+    static constexpr int NW = TH / 2, NTHR = 64 * NW;                       // TH = 16: 8 waves share the stage (half the weight bytes per MAC, halo 1.27 instead of 1.41)
     static constexpr int IW = TW + 4, IH = TH + 2;                        // halo tile, 2-pixel apron left/right (16-B pieces)
     static constexpr int ROWP = IW / 2, PIECES = IH * ROWP;               // 16-B pieces per (term, entry) plane
-    static constexpr int NDMA = (PIECES + 63) / 64;                       // DMA instructions per plane (one wave per plane)
+    static constexpr int NDMA_ALL = (PIECES + 63) / 64;                   // DMA instructions per plane ...
+    static constexpr int NDMA = (NDMA_ALL + NW / 4 - 1) / (NW / 4);       // ... of which a wave issues this many (NW / 4 waves per plane)
     // COLREG (the <2, 32> and <3, 32> shapes): the collected-tap block (a third of a flush round's weights, used once in four
     // rounds) does NOT pass through LDS - its fragments are loaded straight into registers right before the flush products -
     // and the planes hold exactly their pieces: 38.5 instead of 48 KB (NT = 2) / 46.5 instead of 60 KB (NT = 3) per workgroup
@@ -100,12 +102,12 @@ struct S4Cfg {
     // shapes cannot reach their next workgroup this way (<1, 32> would need 102 registers: 16 spills in the main loop, +35 %;
     // <4, 32> and the 8x64 shapes stay at 2) and keep the third block in LDS, where it costs no exposed load
     static constexpr bool COLREG = (NT == 2 || NT == 3) && TW_ == 32;
-    static constexpr int PLANE = COLREG ? PIECES * 16 : NDMA * 64 * 16;   // bytes (lanes past the last piece are masked off)
+    static constexpr int PLANE = COLREG ? PIECES * 16 : NDMA_ALL * 64 * 16;   // bytes (lanes past the last piece are masked off)
     static constexpr int ABUF = 4 * PLANE;                                // [term][entry] per stage
     static constexpr int WBLK = 2 * 64 * 16;                              // one instruction's weights of one cout tile: [term][lane][8 fp16]
     static constexpr int BPT = COLREG ? 2 : 3;                            // blocks per cout tile in LDS: instr 0, instr 1[, collected tap]
     static constexpr int WBUF = NT * BPT * WBLK;                          // [nt][block][term][lane]
-    static constexpr int WPIECES = WBUF / 16, NITW = (WPIECES + 255) / 256;
+    static constexpr int WPIECES = WBUF / 16, NITW = (WPIECES + NTHR - 1) / NTHR;
     static constexpr size_t STAGES_BYTES = 2 * (size_t)ABUF + 2 * (size_t)WBUF;
     static constexpr size_t LDS_BYTES = STAGES_BYTES + NT * 16 * sizeof(float);   // + the bias values of the workgroup's couts
 };
@@ -114,10 +116,10 @@ struct S4Cfg {
 __host__ __device__ inline int s4_blocks_before(int r) { return 2 * r + r / 4; }
 __host__ __device__ inline int s4_blocks_total(int rounds) { return 2 * rounds + (rounds + 3) / 4; }
 
-template <int NT, int TW_>
-__global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT == 3) ? 3 : 2) void conv_s4_kernel(ConvArgs a) {
+template <int NT, int TW_, int TH_>
+__global__ __launch_bounds__(32 * TH_, TH_ == 16 ? 2 : (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT == 3) ? 3 : 2) void conv_s4_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using C = S4Cfg<NT, TW_>;
+    using C = S4Cfg<NT, TW_, TH_>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,10 +139,11 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
         for (int n = 0; n < NT; ++n) acc[m][n] = s4_f32x4{0.f, 0.f, 0.f, 0.f};
 
     // this lane's pieces of the plane its wave fetches: byte offset inside a group plane, or out of range
+    const int w4 = wave & 3, jb = (wave >> 2) * C::NDMA;   // this wave's plane of a stage and its first DMA instruction of that plane
     unsigned poff[C::NDMA];
 #pragma unroll
     for (int j = 0; j < C::NDMA; ++j) {
-        const int p = j * 64 + lane, row = p / C::ROWP, cp = p - row * C::ROWP;
+        const int p = (jb + j) * 64 + lane, row = p / C::ROWP, cp = p - row * C::ROWP;
         const int gy = iy0 + row, gx = ix0 + 2 * cp;
         poff[j] = (p < C::PIECES && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? (unsigned)(gy * a.Win + gx) * 8u : kS4Oob;
     }
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
     bool wcol[C::NITW];                    // piece of the collected-tap block (BPT = 3 only): fetched in flush rounds only
 #pragma unroll
     for (int it = 0; it < C::NITW; ++it) {
-        const int p = it * 256 + tid, n = p / (C::BPT * 2 * 64), rem = p - n * (C::BPT * 2 * 64);
+        const int p = it * C::NTHR + tid, n = p / (C::BPT * 2 * 64), rem = p - n * (C::BPT * 2 * 64);
         woff[it] = (p < C::WPIECES && tile0 + n < a.ntiles) ? ((unsigned)(tile0 + n) * (unsigned)nblocks * (2 * 64) + (unsigned)rem) * 16u : kS4Oob;
         wcol[it] = rem >= 2 * 2 * 64;
     }
@@ -197,21 +200,21 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
         // activations: wave w fetches plane (term = w >> 1, entry = 2 r + (w & 1))
         const char *base;
         unsigned goff, tstride;
-        areal = s4_entry(a, 2 * r + (wave & 1), b, plane_bytes, base, goff, tstride);
+        areal = s4_entry(a, 2 * r + (w4 & 1), b, plane_bytes, base, goff, tstride);
         ars = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7FFFFFFF, 0x00020000);
-        asoff = goff + (unsigned)(wave >> 1) * tstride;
+        asoff = goff + (unsigned)(w4 >> 1) * tstride;
     };
     auto is_flush = [&](int r) { return (r & 3) == 3 || r == nrounds - 1; };
     auto issue_part = [&](int r, int stage, int j) {
-        if (j * 64 + lane < C::PIECES)   // the plane holds exactly its pieces: lanes past the last one write nothing
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (s4_lds_ptr_t)(abuf(stage) + wave * C::PLANE + j * 1024), 16,
+        if ((jb + j) * 64 + lane < C::PIECES)   // the plane holds exactly its pieces: lanes past the last one write nothing
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (s4_lds_ptr_t)(abuf(stage) + w4 * C::PLANE + (jb + j) * 1024), 16,
                                                      areal ? poff[j] : kS4Oob, asoff, 0, 0);
         unsigned char *wdst = wbuf(stage);
         const bool flush = is_flush(r);
 #pragma unroll
         for (int it = j; it < C::NITW; it += C::NDMA)
-            if (it * 256 + tid < C::WPIECES && (flush || !wcol[it]))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (s4_lds_ptr_t)(wdst + (it * 256 + wave * 64) * 16), 16, woff[it],
+            if (it * C::NTHR + tid < C::WPIECES && (flush || !wcol[it]))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (s4_lds_ptr_t)(wdst + (it * C::NTHR + wave * 64) * 16), 16, woff[it],
                                                          (unsigned)s4_blocks_before(r) * C::WBLK, 0, 0);
     };
     // part j of the next stage goes out after MFMA group S4_ISSUE_FIRST + j * S4_ISSUE_STEP of the round (6 HALVES groups)
@@ -445,24 +448,25 @@ __global__ __launch_bounds__(256, (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT 
 #endif
 }
 
-template <int NT, int TW_>
+template <int NT, int TW_, int TH_ = 8>
 static int launch_s4_cfg(const ConvArgs &a0, int B, hipStream_t s) {
-    using C = S4Cfg<NT, TW_>;
+    using C = S4Cfg<NT, TW_, TH_>;
     ConvArgs a = a0;
     a.tilesX = (a.Wout + C::TW - 1) / C::TW;
     a.tilesY = (a.Hout + C::TH - 1) / C::TH;
     static bool attr_set = false;
     if (!attr_set) {
-        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s4_kernel<NT, TW_>),
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s4_kernel<NT, TW_, TH_>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_set = true;
     }
     char label[96];
-    snprintf(label, sizeof(label), "void pf::conv_s4_kernel<%d, %d>(pf::ConvArgs)", NT, TW_);
+    if (TH_ == 8) snprintf(label, sizeof(label), "void pf::conv_s4_kernel<%d, %d>(pf::ConvArgs)", NT, TW_);
+    else snprintf(label, sizeof(label), "void pf::conv_s4_kernel<%d, %d, %d>(pf::ConvArgs)", NT, TW_, TH_);
     const double px = (double)B * a.Hout * a.Wout;
     ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * 9,
                  4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * 9));
-    hipLaunchKernelGGL((conv_s4_kernel<NT, TW_>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(256), C::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_s4_kernel<NT, TW_, TH_>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(C::NTHR), C::LDS_BYTES, s, a);
     PF_LAUNCH_CHECK("conv_s4_kernel");
     return PF_OK;
 }
@@ -830,6 +834,10 @@ int launch_conv_s4(const ConvArgs &a, int ks, int nt, int wide, int B, hipStream
     if (ks == 3) {
         if (a.pool || a.res || a.no_bias) return fail(PF_EUNSUPPORTED, "conv_s4 3x3: no fused epilogue stages");
         if (a.chunk_begin != 0 || a.chunk_end != a.nchunks) return fail(PF_EUNSUPPORTED, "conv_s4 3x3: whole K range only");
+        if (wide == 2) {   // 16x32-pixel tiles, 8 waves
+            if (nt == 1) return launch_s4_cfg<1, 32, 16>(a, B, s);
+            return launch_s4_cfg<2, 32, 16>(a, B, s);
+        }
         if (wide) {
             if (nt == 1) return launch_s4_cfg<1, 64>(a, B, s);
             if (nt == 2) return launch_s4_cfg<2, 64>(a, B, s);

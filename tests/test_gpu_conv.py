@@ -383,7 +383,7 @@ def _block_ref(x, P, h, w):
     return {'t0': t0, 'L2': l2, 'out': out, 'p': p, 'c6': c6, 'c7': c7, 'c8': c8}
 
 
-@pytest.mark.parametrize('nt,wide', [(1, 0), (2, 0), (3, 0), (1, 1), (2, 1)])
+@pytest.mark.parametrize('nt,wide', [(1, 0), (2, 0), (3, 0), (1, 1), (2, 1), (1, 2), (2, 2)])   # wide 1: 8x64 tiles, 2: 16x32 tiles on 8 waves
 @pytest.mark.parametrize('h,w,b', [(16, 64, 2), (24, 40, 1), (34, 136, 1)])
 def test_packed_activation_block(h, w, b, nt, wide, force_conv):
     """Every tensor between the first and the last conv lives in the packed-pair layout; the S4 3x3 kernel (LDS-DMA halo
@@ -401,6 +401,7 @@ def test_packed_activation_block(h, w, b, nt, wide, force_conv):
     labels = [r['label'] for r in pflib.profile_results()]
     pflib.profile(False)
     assert sum('conv_s4_kernel' in l for l in labels) >= 1, labels
+    assert any('32, 16>' in l for l in labels) == (wide == 2), labels
     for tag in ('+pool', '+res', 'lowres-half'):
         assert any('conv_s4_1x1_kernel' in l and tag in l for l in labels), (tag, labels)
     ref = _block_ref(x, P, h, w)
