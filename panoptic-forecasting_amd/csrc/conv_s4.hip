@@ -139,7 +139,8 @@ __global__ __launch_bounds__(32 * TH_, TH_ == 16 ? 2 : (TW_ == 32 && NT <= 2) ? 
         for (int n = 0; n < NT; ++n) acc[m][n] = s4_f32x4{0.f, 0.f, 0.f, 0.f};
 
     // this lane's pieces of the plane its wave fetches: byte offset inside a group plane, or out of range
-    const int w4 = wave & 3, jb = (wave >> 2) * C::NDMA;   // this wave's plane of a stage and its first DMA instruction of that plane
+    // this wave's plane of a stage and its first DMA instruction of that plane (4 waves: one plane each, all of it)
+    const int w4 = C::NW == 4 ? wave : (wave & 3), jb = C::NW == 4 ? 0 : (wave >> 2) * C::NDMA;
     unsigned poff[C::NDMA];
 #pragma unroll
     for (int j = 0; j < C::NDMA; ++j) {
