@@ -434,7 +434,7 @@ def test_s4_four_cout_tiles(h, w, b, force_conv):
     net = MiniNet(spec, P).run(x.cuda())
     labels = [r['label'] for r in pflib.profile_results()]
     pflib.profile(False)
-    assert any('conv_s4_kernel<4, 32>' in l for l in labels), labels
+    assert any('conv_s4_kernel<4, 32, 8>' in l for l in labels), labels
     D = {k: (v[0].double(), v[1].double()) for k, v in P.items()}
     t0r = F.relu(F.conv2d(x.double(), *D['t0'], padding=1))
     c1r = F.relu(F.conv2d(t0r, *D['c1'], padding=1))
