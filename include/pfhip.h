@@ -94,7 +94,7 @@ int pf_hardnet_workspace(const pf_plan *plan, int B, int H, int W, size_t *bytes
 /* Status of a forward.  The first 4 bytes of a forward's workspace are a status word: cleared when the forward starts,
  * bits raised by its kernels, final once the stream has run the forward.
  *   PF_STATUS_RANGE  a tensor that feeds the two-term fp16 operand path (option "split_f16") held a value with
- *                    |x| > 65504 (or NaN): fp16 pairs cannot represent it, so the outputs of THIS forward are not to be
+ *                    |x| > 65504 (inf included; NaN in a caller-provided input): fp16 pairs cannot represent it, so the outputs of THIS forward are not to be
  *                    used.  The reference's fp32 Conv2d (hardnet.py:16-25) has no such limit: re-run the forward with
  *                    plan option "split_f16" = 0 (what BGModel does by default, bg_model.py `on_range_overflow`) or fail.
  *                    Never raised by fp32-only plans.  FC-HarDNet activations behind folded BatchNorm are O(1..100).
