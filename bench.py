@@ -27,7 +27,8 @@ At N=1 the same line also carries (driver-timed, same process):
     cpu_baseline  the oracle pipeline on the host cores: at the best torch thread count of a short sweep (`value`) and on all of
                   them (`value_all_cores`)
     range_overflow  false = no forward of the timed region met an activation outside the range of the fp16-pair path
-                  (PF_STATUS_RANGE, include/pfhip.h); a true here would invalidate the run and bench.py exits non-zero
+                  (PF_STATUS_RANGE / PF_STATUS_RANGE_LOW, include/pfhip.h; read from the workspaces' sticky status words after the
+                  timed region); a true here would invalidate the run and bench.py exits non-zero
 """
 import argparse
 import glob
@@ -77,10 +78,10 @@ def model_params(**model_kw):
                    'final_h': H, 'final_w': W, 'emulate_disk_hop': True, 'seg_is_label_id': True,
                    # every frame gets the sentinel the reference gives it at batch size 1 (outputs independent of how the
                    # frames are batched and sharded; the reference's batch-global max couples the samples of a call)
-                   'per_sample_sentinel': True,
-                   # the status word of every workspace is read ONCE after the timed region (range_overflow in the JSON
-                   # line) instead of with every predict (a stream synchronisation per call)
-                   'on_range_overflow': 'ignore'}}
+                   'per_sample_sentinel': True}}
+    # on_range_overflow keeps its default ('rerun'): predict() enqueues and never waits; eager runs check every forward's
+    # status words lazily (pinned copy + event), captured graphs OR them into the workspace's sticky word, which is read
+    # once after the timed region (range_overflow in the JSON line)
     p['model'].update(model_kw)
     return p
 
@@ -89,13 +90,11 @@ TERM = {'short': dict(gap_len=3, predicted=False), 'mid': dict(gap_len=9, predic
 
 
 def make_batch(b, seed0, device, term='short'):
-    from panoptic_forecasting_amd.pc_transform_model import host_inverse
     parts = [synth.make_inputs(b=1, t=T, h=H, w=W, seed=seed0 + i, **TERM[term]) for i in range(b)]
     inp = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
-    # camera inverses are per-sequence constants prepared with the inputs (host LAPACK); a caller that
-    # does not pass them pays one cached host inverse per distinct camera (pc_transform_model.InverseCache)
-    inp['intrinsics_inv'] = host_inverse(inp['intrinsics'])
-    inp['extrinsics_inv'] = host_inverse(inp['extrinsics'])
+    # the batch dict is exactly the reference's (no pre-computed camera inverses): the model inverts K and E on the host
+    # (LAPACK, like the reference) once per distinct camera tensor and afterwards hits its cache without touching the
+    # stream (pc_transform_model.InverseCache) - the warm-up steps pay it, the timed region and the captured graph do not
     return {k: v.to(device) for k, v in inp.items()}
 
 
@@ -275,6 +274,7 @@ class Workload:
                         self.models[i].predict(self.subs[i], None)
                 torch.cuda.current_stream().wait_stream(st)
                 torch.cuda.synchronize()
+                self.models[i].bg.settle()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self.out[i] = self.models[i].predict(self.subs[i], None)
@@ -297,6 +297,8 @@ class Workload:
                     self.step()
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
+            for m in self.models:
+                m.bg.settle()       # the eager warm-up forwards are checked (and their tensors released) before the capture
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = self.step()
@@ -386,8 +388,15 @@ class Workload:
         return pfdist.max_over_ranks(time.perf_counter() - t0, dev) if barrier else time.perf_counter() - t0
 
     def range_overflow(self):
-        """True if any forward since the last check raised PF_STATUS_RANGE in its workspace (include/pfhip.h)"""
-        return any(bool(m.bg.range_status() & 1) for m in self.models)
+        """OR of the sticky status words of the workspaces (include/pfhip.h: every forward ORs its final status into the
+        sticky word, only the host clears it): non-zero = some forward since the last call met values outside the range of the
+        fp16-pair path (PF_STATUS_RANGE = 1: |x| > 65504; PF_STATUS_RANGE_LOW = 2: a tensor of tiny values).  Eager forwards
+        that were flagged have been re-run on the fp32 MFMA by then (counted in range_reruns)."""
+        st = 0
+        for m in self.models:
+            m.bg.settle()
+            st |= m.bg.range_status_sticky(clear=True)
+        return st
 
     def outputs(self):
         return {k: torch.cat([o[k] for o in self.out]) for k in self.out[0]}
@@ -570,6 +579,7 @@ def main():
     frames = world * B * R * args.steps
     value = frames / elapsed
     overflow = wl.range_overflow()
+    reruns = sum(m.bg.range_reruns for m in wl.models)
     # every rank's own step time and device identity: a straggler, or two ranks on one device, shows in the N > 1 line
     ident = pfdist.device_identity(local)
     per_rank = pfdist.gather_objects({'rank': rank, 'ms_per_step': 1e3 * wl.local_s / args.steps, 'device': ident})
@@ -581,6 +591,8 @@ def main():
     gt = torch.from_numpy(synth.ID2TRAINID).to(dev)[wl.batch['seg'][:, T - 1].long()].long()
     acc = pfpq.pq_accumulate(out['seg'].long(), gt, 11)
     allacc = pfdist.gather_accumulators(acc)
+    if int(allacc.shape[0]) != args.gpus:
+        raise SystemExit('bench.py: the PQ all-gather returned %d rank(s), --gpus %d' % (int(allacc.shape[0]), args.gpus))
     pq_synth = pfpq.pq_from_acc(allacc.sum(0))['pq']
 
     # ---- per-kernel timing pass (eager, hipEvents on the launch stream) -> roofline of the dominant kernel + whole step
@@ -637,7 +649,7 @@ def main():
             dt = leg.timed(leg_steps, args.warmup, dev)
             by_batch[str(b)] = {'value': b * leg_steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / leg_steps,
                                 'steps': leg_steps, 'streams': 1}
-            overflow = overflow or leg.range_overflow()
+            overflow = overflow | leg.range_overflow()
             del leg
             torch.cuda.empty_cache()
         if not args.fp32_mfma_only:
@@ -667,17 +679,26 @@ def main():
                          'f32 (accumulation, strided / low-resolution convs: fp32 MFMA; tuned 3x3 and 1x1 layers: every fp32 operand '
                          'as two round-to-nearest fp16 terms hi + mid, |x - hi - mid| <= 2^-23 |x| + 2^-25 for |x| <= 65504 (fp32 '
                          'rounding itself: 2^-24; proven in tests/test_host_logic.py::test_split_operand_bound), 3 products on '
-                         'the fp16 MFMA (the dropped mid*mid <= 2^-22 of a product), fp32 accumulate; |x| > 65504 raises '
-                         'PF_STATUS_RANGE and the forward is re-run on fp32 MFMA: see range_overflow)', 'data': 'synthetic',
-                'range_overflow': bool(overflow),
+                         'the fp16 MFMA (the dropped mid*mid <= 2^-22 of a product), fp32 accumulate; stored channels are pre-scaled '
+                         'by powers of two chosen from the folded weights; a value beyond 65504 raises PF_STATUS_RANGE, a tensor whose '
+                         'maximum is below 2^-6 raises PF_STATUS_RANGE_LOW, and a flagged forward is re-run on fp32 MFMA: see '
+                         'range_overflow)', 'data': 'synthetic',
+                'range_overflow': bool(overflow), 'range_status_sticky': int(overflow), 'range_reruns': int(reruns),
                 'config': {'workload': ('configs[1]: bg short-term forecast, 3 frames in, dt=3' if args.term == 'short' else
                                         'configs[2]: bg mid-term forecast, 3 frames in, dt=9, predicted-odometry ego chain') +
                                        ', 1024x2048, random-init calibrated weights; step = 3 warp/splats + HarDNet + upsample/argmax',
                            'frames_per_gpu_per_step': B * R, 'resident_frames_per_gpu': B, 'passes_per_step': R, 'streams': S, 'launch': ('hipGraph per sub-batch on free-running streams, offset %g ms' % args.free_run) if (args.free_run is not None and use_graph and S > 1)
                            else (('hipGraph replay' if use_graph else 'eager') + (', sub-batches staggered (software pipeline across the passes of a step)' if (args.stagger and S > 1) else '')),
+                           'model': "registry.build_model(task 'bg_forecast') with default execution options: on_range_overflow = 'rerun' "
+                                    '(asynchronous status check; inside the captured graph every forward ORs its status into the sticky word '
+                                    'read after the timed region), camera inverses computed and cached by the model',
+                           'sentinel': 'per sample (model.per_sample_sentinel = True: outputs independent of batching / sharding; the '
+                                       "reference's batch-global max+1 couples the samples of a predict call)",
+                           'inputs': '%d resident synthetic frames per GPU, the same frames replayed every pass (%.1f GB of inputs, more '
+                                     'than the 256 MB Infinity Cache)' % (B, B * 37.75e6 / 1e9),
                            'sharding': 'batch over %d rank(s), no data-path collective' % world,
                            'world': joined, 'device': torch.cuda.get_device_name(local),
-                           'backend': 'nccl (RCCL)' if pfdist.is_dist() else 'single process'},
+                           'backend': pfdist.backend_description()},
                 'per_rank_ms': [r['ms_per_step'] for r in per_rank],
                 'per_rank_ms_min_max': [min(r['ms_per_step'] for r in per_rank), max(r['ms_per_step'] for r in per_rank)],
                 'devices': [r['device'] for r in per_rank],
@@ -689,8 +710,8 @@ def main():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if overflow:
-        raise SystemExit('bench.py: PF_STATUS_RANGE was raised inside the timed region: the fp16-pair path met |x| > 65504; '
-                         'the number above is not a valid measurement')
+        raise SystemExit('bench.py: range status %d was raised inside the timed region (1: the fp16-pair path met |x| > 65504, '
+                         '2: a tensor of tiny values); the number above is not a valid measurement' % overflow)
 
 
 if __name__ == '__main__':

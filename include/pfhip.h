@@ -91,19 +91,39 @@ int pf_hardnet_plan_create(const void *blob_host, size_t bytes, int in_ch, int n
 void pf_hardnet_plan_destroy(pf_plan *plan);
 int pf_hardnet_workspace(const pf_plan *plan, int B, int H, int W, size_t *bytes);
 
-/* Status of a forward.  The first 4 bytes of a forward's workspace are a status word: cleared when the forward starts,
- * bits raised by its kernels, final once the stream has run the forward.
- *   PF_STATUS_RANGE  a tensor that feeds the two-term fp16 operand path (option "split_f16") held a value with
- *                    |x| > 65504 (inf included; NaN in a caller-provided input): fp16 pairs cannot represent it, so the outputs of THIS forward are not to be
- *                    used.  The reference's fp32 Conv2d (hardnet.py:16-25) has no such limit: re-run the forward with
- *                    plan option "split_f16" = 0 (what BGModel does by default, bg_model.py `on_range_overflow`) or fail.
- *                    Never raised by fp32-only plans.  FC-HarDNet activations behind folded BatchNorm are O(1..100).
- * A caller that manages streams itself reads the word with its outputs (it is ordinary device memory); pf_hardnet_status
- * is the convenience form: it copies the word to the host and SYNCHRONISES `stream` (the only call of this library that
- * waits for the device). */
+/* Status of a forward.  The first PF_WS_STATUS_BYTES of a forward's workspace are its status block.  Word 0 is the status
+ * word of the LAST FINISHED forward: written once, by the launch that ends a forward (its kernels collect their flags in a
+ * private word of the block), so it is final once the stream has run the forward and stays readable while the next one runs.
+ * Word 1 (PF_WS_STICKY_OFFSET) is STICKY: every forward ORs its final status word into it and only the host clears it
+ * (pf_hardnet_status_sticky(clear = 1), pf_hardnet_status_reset) - the word to read after a hipGraph replay or an eager loop
+ * that ran several forwards through one workspace.  The caller ZEROES THE BLOCK ONCE after allocating the workspace
+ * (pf_hardnet_status_reset, or a memset): forwards do not start with a memset, the ending launch leaves the block ready for
+ * the next one.
+ *   PF_STATUS_RANGE      a tensor that feeds the two-term fp16 operand path (option "split_f16") held a value with
+ *                        |x| > 65504 (inf included; NaN in a caller-provided input or produced by the stem): fp16 pairs cannot
+ *                        represent it, so the outputs of THIS forward are not to be used.
+ *   PF_STATUS_RANGE_LOW  the largest |x| a launch stored into such a tensor was non-zero and below 2^-6: the pair keeps an
+ *                        absolute 2^-25 below |x| = 0.25, so a tensor of tiny values would lose relative precision that fp32
+ *                        keeps.  (Unflagged: every operand within 2^-23 |x| + 2^-25 and 2^-25 <= 2^-19 of the tensor's maximum.)
+ *                        Plan creation already stores every channel multiplied by a power of two that puts its expected
+ *                        magnitude at 8 (an exact re-parameterisation of the folded weights, option "normalize_ranges"), so this
+ *                        fires only for data far from what the weights suggest.
+ * Either bit: the reference's fp32 Conv2d (hardnet.py:16-25) has no such limits - re-run the forward with plan option
+ * "split_f16" = 0 (what BGModel does by default, bg_model.py `on_range_overflow`) or fail.  Never raised by fp32-only plans.
+ * A caller that manages streams itself reads the words with its outputs (ordinary device memory; BGModel copies them to pinned
+ * host memory behind every forward and checks them lazily); pf_hardnet_status / pf_hardnet_status_sticky are the convenience
+ * forms: they copy a word to the host and SYNCHRONISE `stream` (the only calls of this library that wait for the device).
+ * pf_hardnet_range_maxima: max |stored value| per op of the plan's table in the last forward (0 for ops that keep none), a
+ * diagnostic for the guard (synchronises). */
 #define PF_STATUS_RANGE 1u
+#define PF_STATUS_RANGE_LOW 2u
 #define PF_WS_STATUS_OFFSET 0
+#define PF_WS_STICKY_OFFSET 4
+#define PF_WS_STATUS_BYTES 2048
 int pf_hardnet_status(const void *ws, unsigned *status, void *stream);
+int pf_hardnet_status_sticky(void *ws, unsigned *status, int clear, void *stream);
+int pf_hardnet_status_reset(void *ws, void *stream);
+int pf_hardnet_range_maxima(const pf_plan *plan, const void *ws, float *maxima, int cap, int *n_ops, void *stream);
 
 /* hop_flags: emulate the reference's on-disk hop between the two tasks on the fly */
 #define PF_HOP_NONE 0
@@ -208,9 +228,14 @@ int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void 
  *                   two fp16 terms hi + mid (22 significand bits; weights pre-scaled by an exact power of two per conv),
  *                   three products on v_mfma_f32_16x16x32_f16, fp32 accumulation - single layers within 2e-5*(1+max|ref|)
  *                   of fp64 like the fp32 kernels, whole-network logits within 1e-4 either way.  Operand bound: both terms
- *                   are rounded to nearest even, |x - hi - mid| <= 2^-23 |x| (+ 2^-25 absolute below 0.25) for |x| <= 65504
- *                   (fp32 itself: 2^-24); beyond 65504 the forward raises PF_STATUS_RANGE (above) instead of clamping;
+ *                   are rounded to nearest even, |x - hi - mid| <= 2^-23 |x| + 2^-25 for |x| <= 65504 (fp32 itself: 2^-24 |x|);
+ *                   beyond 65504 the forward raises PF_STATUS_RANGE, and a tensor whose largest value is below 2^-6 (where the
+ *                   absolute term would dominate) raises PF_STATUS_RANGE_LOW (above) - never a silent loss in either direction;
  *                   0 = every convolution on fp32 MFMA / fp32 VALU;
+ *   "normalize_ranges" (default 1; process-wide only, read when a plan is created) every activation channel is stored
+ *                   multiplied by a power of two chosen from the folded weights so that its expected magnitude is 8 (producer
+ *                   rows * s, consumer columns / s: bit-identical fp32 arithmetic, fp16-pair range centred on the data; a
+ *                   checkpoint re-parameterised across a BatchNorm runs on the same stored values); 0 = store raw values;
  *   "range_guard"   (default 1) the PF_STATUS_RANGE checks of the split path (a compare per stored value); 0 removes them;
  *   "fuse_front"    (default 1) base.1 (3x3 s1, 16 -> 24) and base.2 (3x3 s2, 24 -> 32) as ONE kernel on a packed-pair stem output, the
  *                   tensor between them kept in LDS (csrc/conv_front.hip: workgroups march down 31-column strips): same results

@@ -14,7 +14,7 @@ mask = d>0, clamp to [min_depth, max_depth]) so outputs match the two-stage refe
 import torch
 
 from .model_api import BaseModel
-from .bg_model import BGModel
+from .bg_model import BGModel, LazyResult
 from .pc_transform_model import WarpSplat
 
 PF_HOP_TRAINID_LUT = 1
@@ -57,11 +57,11 @@ class BGForecastModel(BaseModel):
         if self.seg_is_label_id:
             hop |= PF_HOP_TRAINID_LUT
         mask = None if (hop & PF_HOP_DEPTH_U16) else (depth_w > 0)
-        seg, logits, orig = self.bg.run(seg_w, depth_w, mask, want_logits=self.return_logits is True,
-                                        want_orig=bool(self.return_logits), hop_flags=hop, seg_dtype=torch.uint8)
+        (seg, logits, orig), token = self.bg.run_async(seg_w, depth_w, mask, want_logits=self.return_logits is True,
+                                                       want_orig=bool(self.return_logits), hop_flags=hop, seg_dtype=torch.uint8)
         out = {'seg': seg, 'warped_seg': seg_w, 'warped_depth': depth_w}
         if logits is not None:
             out['logits'] = logits
         if orig is not None:
             out['orig_size_logits'] = orig
-        return out
+        return LazyResult(out, self.bg, token)     # nothing waited for: the range check happens on first access

@@ -23,7 +23,55 @@ from .pc_transform_model import _as_u8
 PLAN_OPTIONS = {'split_f16': 'split_f16', 'split_bf16': 'split_f16', 'fuse_pool': 'fuse_pool', 'fuse_upsample': 'fuse_upsample',
                 'use_tuned_table': 'use_tuned_table', 'valu_remainder': 'valu_remainder', 'conv_table_batch': 'table_batch',
                 'range_guard': 'range_guard', 'fuse_front': 'fuse_front'}
-PF_STATUS_RANGE = 1   # include/pfhip.h
+PF_STATUS_RANGE, PF_STATUS_RANGE_LOW = 1, 2          # include/pfhip.h
+PF_STATUS_ANY = PF_STATUS_RANGE | PF_STATUS_RANGE_LOW
+PF_WS_STATUS_BYTES = 2048
+
+
+class _Pending:
+    """One enqueued forward whose status words are on their way to pinned host memory."""
+    __slots__ = ('slot', 'event', 'args', 'outs', 'done')
+
+
+class LazyResult(dict):
+    """``predict``'s result dict.  The forward behind it was only ENQUEUED (the reference's ``predict`` is asynchronous
+    too, bg_model.py:91-102); its status words (include/pfhip.h) follow the outputs to pinned host memory, and the first
+    access of a value waits for that one forward and applies ``on_range_overflow`` - a flagged forward is re-run on the
+    fp32 matrix instructions INTO THE SAME output tensors before the caller sees them, or raises.  Keys can be listed
+    without waiting."""
+
+    def __init__(self, data, model, token):
+        super().__init__(data)
+        self._model, self._token = model, token
+
+    def _resolve(self):
+        if self._token is not None:
+            token, self._token = self._token, None
+            self._model._resolve(token)
+
+    def __getitem__(self, k):
+        self._resolve()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        self._resolve()
+        return super().get(k, default)
+
+    def items(self):
+        self._resolve()
+        return super().items()
+
+    def values(self):
+        self._resolve()
+        return super().values()
+
+    def pop(self, *a):
+        self._resolve()
+        return super().pop(*a)
+
+    def copy(self):
+        self._resolve()
+        return dict(self)
 
 
 class _Node(nn.Module):
@@ -113,16 +161,22 @@ class BGModel(BaseModel):
         # for batches of n, so a frame's logits do not depend on the size of the batch it arrives in.
         self.plan_options = {c_name: int(params['model'][key]) for key, c_name in PLAN_OPTIONS.items()
                              if params['model'].get(key) is not None}
-        # What to do when a forward on the two-term fp16 operand path met an activation it cannot represent (|x| > 65504;
-        # include/pfhip.h PF_STATUS_RANGE - the reference's fp32 Conv2d, hardnet.py:16-25, has no such limit):
-        #   'rerun' (default) run that forward again on the fp32 matrix instructions (split_f16 = 0) and return its outputs;
+        # What to do when a forward on the two-term fp16 operand path met activations the pair cannot represent as well as
+        # fp32 does: |x| > 65504 (PF_STATUS_RANGE) or a tensor of tiny values, max |x| < 2^-6 (PF_STATUS_RANGE_LOW; include/
+        # pfhip.h - the reference's fp32 Conv2d, hardnet.py:16-25, has neither limit):
+        #   'rerun' (default) run that forward again on the fp32 matrix instructions (split_f16 = 0) into the same outputs;
         #   'raise'  raise PfError;  'ignore'  return whatever the kernels produced (range_status() still tells).
-        # The check reads one word back with the outputs (a stream synchronisation per predict); under hipGraph capture it
-        # is skipped and the caller reads range_status() after the replay (bench.py does).
+        # Nothing synchronises in predict(): the status words follow the outputs to pinned host memory (a captured copy +
+        # an event) and are checked when the caller first touches a result (LazyResult) or by the next predict() once the
+        # event has fired.  Under hipGraph capture the copy is skipped: the kernels OR every forward's status into the
+        # workspace's sticky word, which check_range() reads after the replays (bench.py does).
         self.on_range_overflow = params['model'].get('on_range_overflow', 'rerun')
         if self.on_range_overflow not in ('rerun', 'raise', 'ignore'):
             raise ValueError("model.on_range_overflow must be 'rerun', 'raise' or 'ignore'")
         self.range_reruns = 0
+        self._pending = []          # enqueued forwards not checked yet, oldest first
+        self._pinned = None         # [ring, 2] int32 pinned: (status word, sticky word) per in-flight forward
+        self._ring_next = 0
         self._plan = None
         self._ws = None
         self._norm = None
@@ -138,6 +192,8 @@ class BGModel(BaseModel):
 
     def invalidate(self):
         """Drop the device plan (call after mutating parameters by hand)."""
+        if self._pending:
+            self._drain()
         if self._plan is not None:
             _lib.load().pf_hardnet_plan_destroy(self._plan)
         self._plan = None
@@ -145,6 +201,7 @@ class BGModel(BaseModel):
 
     def __del__(self):
         try:
+            self._pending = []      # nobody can look at those results any more; never wait on the device in a destructor
             self.invalidate()
         except Exception:
             pass
@@ -169,38 +226,132 @@ class BGModel(BaseModel):
         need = ctypes.c_size_t()
         _lib.check(L.pf_hardnet_workspace(self._get_plan(), b, h, w, ctypes.byref(need)), 'pf_hardnet_workspace')
         if self._ws is None or self._ws.numel() < need.value or self._ws.device != device:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.PfError('bg forward: the workspace must exist before stream capture (run one forward first)')
+            self._drain()
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+            self._ws[:PF_WS_STATUS_BYTES].zero_()     # status block: the sticky word is only ever cleared by the host
         return self._ws
 
+    def _guarded(self):
+        return not (self.on_range_overflow == 'ignore' or self.plan_options.get('split_f16', 1) == 0
+                    or self.plan_options.get('range_guard', 1) == 0)
+
     def range_status(self):
-        """Status word of the last forward in this model's workspace (synchronises): PF_STATUS_RANGE set = that forward
-        met |activation| > 65504 on the fp16-pair path and its outputs must not be used."""
+        """Status word of the LAST forward in this model's workspace (synchronises): PF_STATUS_RANGE / PF_STATUS_RANGE_LOW
+        set = that forward met values outside what the fp16-pair path represents and its outputs must not be used."""
         if self._ws is None:
             return 0
         return int(self._ws[:4].view(torch.int32).item())
 
+    def range_status_sticky(self, clear=False):
+        """OR of the status words of every forward through this workspace since the last clear (synchronises) - what to
+        read after hipGraph replays or an eager loop of several forwards."""
+        if self._ws is None:
+            return 0
+        w = self._ws[4:8].view(torch.int32)
+        v = int(w.item())
+        if clear:
+            w.zero_()
+        return v
+
+    def check_range(self, clear=True):
+        """After hipGraph replays (where predict() can neither wait nor re-run): raises PfError if any forward since the last
+        clear was flagged, unless ``on_range_overflow == 'ignore'``.  Returns the sticky status."""
+        self._drain()
+        v = self.range_status_sticky(clear)
+        if (v & PF_STATUS_ANY) and self._guarded():
+            raise _lib.PfError('bg forward: status %d (PF_STATUS_RANGE = 1: |activation| > 65504, PF_STATUS_RANGE_LOW = 2: a tensor of '
+                               'tiny values) on the two-term fp16 operand path inside a captured graph: the outputs of the flagged '
+                               'replays are not usable; run eagerly (re-run on fp32) or with model.split_f16 = 0' % v)
+        return v
+
+    def range_maxima(self):
+        """{op name: max |stored value|} of the last forward (diagnostic of the range guard; synchronises)."""
+        L, plan = _lib.load(), self._get_plan()
+        names = [op.name for op in self.model.spec.ops]
+        buf = (ctypes.c_float * len(names))()
+        n = ctypes.c_int()
+        _lib.check(L.pf_hardnet_range_maxima(plan, self._ws.data_ptr(), buf, len(names), ctypes.byref(n), _lib.stream_ptr()),
+                   'pf_hardnet_range_maxima')
+        return {names[i]: float(buf[i]) for i in range(n.value)}
+
     # ---- device forward ---------------------------------------------------------------------
-    def run(self, inps, depths, depth_masks, want_logits=True, want_orig=True, hop_flags=0, seg_dtype=torch.int64):
-        """``pf_bg_forward`` / ``pf_hardnet_forward_dense`` -> (seg, logits|None, orig|None), with the range check of the
-        fp16-pair path (``on_range_overflow``)."""
-        out = self._run_once(inps, depths, depth_masks, want_logits, want_orig, hop_flags, seg_dtype)
-        if (self.on_range_overflow == 'ignore' or self.plan_options.get('split_f16', 1) == 0
-                or self.plan_options.get('range_guard', 1) == 0 or torch.cuda.is_current_stream_capturing()):
-            return out
-        if not (self.range_status() & PF_STATUS_RANGE):
-            return out
+    _RING = 32
+
+    def _resolve(self, token):
+        """Wait for ONE forward's status words and apply the policy (see LazyResult)."""
+        if token.done:
+            return
+        token.event.synchronize()
+        token.done = True
+        if token in self._pending:
+            self._pending.remove(token)
+        status = int(self._pinned[token.slot, 0])
+        args, outs = token.args, token.outs
+        token.args = token.outs = None
+        if not (status & PF_STATUS_ANY):
+            return
         if self.on_range_overflow == 'raise':
-            raise _lib.PfError('bg forward: an activation exceeded 65504, the range of the two-term fp16 operand path '
-                               "(PF_STATUS_RANGE); run with model.split_f16 = 0 or on_range_overflow = 'rerun'")
+            raise _lib.PfError('bg forward: status %d on the two-term fp16 operand path (PF_STATUS_RANGE = 1: an activation '
+                               'exceeded 65504; PF_STATUS_RANGE_LOW = 2: a tensor of tiny values, max below 2^-6); run with '
+                               "model.split_f16 = 0 or on_range_overflow = 'rerun'" % status)
         L, plan = _lib.load(), self._get_plan()
         self.range_reruns += 1
+        prior = self.plan_options.get('split_f16', 1)
         _lib.check(L.pf_hardnet_plan_set_option(plan, b'split_f16', 0), 'pf_hardnet_plan_set_option')
         try:
-            return self._run_once(inps, depths, depth_masks, want_logits, want_orig, hop_flags, seg_dtype)
+            self._run_once(*args, outs=outs)
         finally:
-            _lib.check(L.pf_hardnet_plan_set_option(plan, b'split_f16', 1), 'pf_hardnet_plan_set_option')
+            _lib.check(L.pf_hardnet_plan_set_option(plan, b'split_f16', prior), 'pf_hardnet_plan_set_option')
 
-    def _run_once(self, inps, depths, depth_masks, want_logits, want_orig, hop_flags, seg_dtype):
+    def _poll(self):
+        """Non-blocking: settle every enqueued forward whose status has arrived (predict i checks forward i - 1)."""
+        while self._pending and self._pending[0].event.query():
+            self._resolve(self._pending[0])
+
+    def _drain(self):
+        while self._pending:
+            self._resolve(self._pending[0])
+
+    def settle(self):
+        """Wait for and check every forward enqueued so far (what the first access of each LazyResult would do)."""
+        self._drain()
+
+    def run_async(self, inps, depths, depth_masks, want_logits=True, want_orig=True, hop_flags=0, seg_dtype=torch.int64):
+        """Enqueue ``pf_bg_forward`` / ``pf_hardnet_forward_dense`` -> ((seg, logits|None, orig|None), token).  ``token`` is
+        None when nothing has to be checked (policy 'ignore', fp32-only plan, stream capture); else pass it to
+        ``_resolve`` (or wrap the outputs in a LazyResult) before using them."""
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:                      # (events cannot be queried while a stream captures)
+            self._poll()
+        args = (inps, depths, depth_masks, want_logits, want_orig, hop_flags, seg_dtype)
+        outs = self._run_once(*args)
+        if not self._guarded() or capturing:
+            return outs, None
+        if self._pinned is None:
+            self._pinned = torch.zeros((self._RING, 2), dtype=torch.int32).pin_memory()
+        slot = self._ring_next
+        self._ring_next = (slot + 1) % self._RING
+        for t in list(self._pending):          # the ring wrapped onto a forward nobody has looked at yet
+            if t.slot == slot:
+                self._resolve(t)
+        self._pinned[slot].copy_(self._ws[:8].view(torch.int32), non_blocking=True)
+        token = _Pending()
+        token.slot, token.args, token.outs, token.done = slot, args, outs, False
+        token.event = torch.cuda.Event()
+        token.event.record()
+        self._pending.append(token)
+        return outs, token
+
+    def run(self, inps, depths, depth_masks, want_logits=True, want_orig=True, hop_flags=0, seg_dtype=torch.int64):
+        """``run_async`` + the range check of the fp16-pair path (``on_range_overflow``): (seg, logits|None, orig|None)."""
+        outs, token = self.run_async(inps, depths, depth_masks, want_logits, want_orig, hop_flags, seg_dtype)
+        if token is not None:
+            self._resolve(token)
+        return outs
+
+    def _run_once(self, inps, depths, depth_masks, want_logits, want_orig, hop_flags, seg_dtype, outs=None):
         L = _lib.load()
         plan = self._get_plan()
         fused = bool(self.convert2onehot and self.use_depth_inps and inps.dim() == 4)
@@ -212,14 +363,17 @@ class BGModel(BaseModel):
         dev = inps.device
         oh, ow = self.final_size if self.final_size is not None else (h, w)
         ws = self._workspace(b, h, w, dev)
-        seg = torch.empty((b, oh, ow), dtype=seg_dtype, device=dev)
-        logits = torch.empty((b, self.num_classes, oh, ow), dtype=torch.float32, device=dev) if want_logits else None
-        orig = None
-        if want_orig:
-            vo, vc, vh, vw = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-            _lib.check(L.pf_hardnet_tensor_view(plan, b'finalConv', b, h, w, ctypes.byref(vo), ctypes.byref(vc),
-                                                ctypes.byref(vh), ctypes.byref(vw)), 'pf_hardnet_tensor_view')
-            orig = torch.empty((b, vc.value, vh.value, vw.value), dtype=torch.float32, device=dev)
+        if outs is not None:
+            seg, logits, orig = outs
+        else:
+            seg = torch.empty((b, oh, ow), dtype=seg_dtype, device=dev)
+            logits = torch.empty((b, self.num_classes, oh, ow), dtype=torch.float32, device=dev) if want_logits else None
+            orig = None
+            if want_orig:
+                vo, vc, vh, vw = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+                _lib.check(L.pf_hardnet_tensor_view(plan, b'finalConv', b, h, w, ctypes.byref(vo), ctypes.byref(vc),
+                                                    ctypes.byref(vh), ctypes.byref(vw)), 'pf_hardnet_tensor_view')
+                orig = torch.empty((b, vc.value, vh.value, vw.value), dtype=torch.float32, device=dev)
         ptr = lambda t_: t_.data_ptr() if t_ is not None else None
         i64 = int(seg_dtype == torch.int64)
         if fused:
@@ -316,9 +470,9 @@ class BGModel(BaseModel):
 
     @torch.no_grad()
     def predict(self, inputs, labels=None):
-        seg, logits, orig = self.run(inputs['seg'], inputs.get('depth'), inputs.get('depth_mask'),
-                                     want_logits=self.return_logits, want_orig=True)
+        (seg, logits, orig), token = self.run_async(inputs['seg'], inputs.get('depth'), inputs.get('depth_mask'),
+                                                    want_logits=self.return_logits, want_orig=True)
         out = {'seg': seg, 'orig_size_logits': orig}
         if logits is not None:
             out['logits'] = logits
-        return out
+        return LazyResult(out, self, token)

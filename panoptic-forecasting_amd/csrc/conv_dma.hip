@@ -310,6 +310,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
     }
 
     DPROBE(3);
+    float vmax = 0.f;
     if (EPI == 0) {
         // ---- plain epilogue: bias + ReLU, NCHW float4 stores
 #pragma unroll
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
                     v[r] += biasv[n];
                     if (a.relu) v[r] = fmaxf(v[r], 0.f);
                 }
-                epi_store(a, b, co, oy, ox, v);
+                epi_store(a, b, co, oy, ox, v, vmax);
             }
         }
         if (RV > 0 && do_rem) {   // remainder channels: lane = pixel, stores coalesced along the row
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
                     if (co >= a.Cout) break;
                     float v = accv[r] + a.bias[co];
                     if (a.relu) v = fmaxf(v, 0.f);
-                    range_commit(a.status, fabsf(v));
+                    vmax = range_acc(vmax, v, 0.f, 0.f, 0.f);
                     a.dst[((size_t)b * a.dst_ctotal + a.dst_choff + co) * ((size_t)a.Hout * a.Wout) + (size_t)oy * a.Wout + ox] = v;
                 }
             }
@@ -371,13 +372,14 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
                 if (epi_skip(a, co)) continue;
                 const lds_float *chan = res_lds + (n * 16 + (lane_e & 15)) * rw.cs;
                 const f32x4 top = epi_finish(a, b, co, oy, ox, acc[m][n], biasv[n], has_res, chan, &t0);
-                if (!a.pool) epi_store(a, b, co, oy, ox, top);
-                else epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, acc[(m + C::TWT) % C::MP][n], biasv[n], has_res, chan, &t1));
+                if (!a.pool) epi_store(a, b, co, oy, ox, top, vmax);
+                else epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, acc[(m + C::TWT) % C::MP][n], biasv[n], has_res, chan, &t1), vmax);
                 __builtin_amdgcn_sched_barrier(0);   // one fragment at a time: interleaving them costs ~100 VGPRs (occupancy)
             }
             DPROBE(5 + m);
         }
     }
+    range_commit(a.status, a.range_slot, vmax);
     DPROBE(4);
 #endif
 }

@@ -189,8 +189,10 @@ __device__ __forceinline__ void s4_store_unit(const ConvArgs &a, int b, int chb,
     }
 }
 
-__device__ __forceinline__ void epi_store(const ConvArgs &a, int b, int co, int oy, int ox, epi_f32x4 v) {
-    range_commit(a.status, range_acc(0.f, v[0], v[1], v[2], v[3]));   // |v| > 65504 is flagged, never silently clamped (conv_mfma.h)
+// vmax: the caller's running max |v| of what it stores (range guard of the operand split, conv_mfma.h: the caller commits it
+// once, range_commit, at the end of its epilogue)
+__device__ __forceinline__ void epi_store(const ConvArgs &a, int b, int co, int oy, int ox, epi_f32x4 v, float &vmax) {
+    vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
     if (a.dst_fmt) {
         if (co >= a.Cout) v = epi_f32x4{0.f, 0.f, 0.f, 0.f};
         const epi_f32x4 c = quad_transpose(v);
@@ -211,11 +213,11 @@ __device__ __forceinline__ void epi_store(const ConvArgs &a, int b, int co, int 
 }
 
 // rows oy (even) and oy+1 of the conv output -> row oy/2 of the pooled tensor [.., Hout/2, Wout/2]
-__device__ __forceinline__ void epi_store_pooled(const ConvArgs &a, int b, int co, int oy, int ox, epi_f32x4 top, epi_f32x4 bot) {
+__device__ __forceinline__ void epi_store_pooled(const ConvArgs &a, int b, int co, int oy, int ox, epi_f32x4 top, epi_f32x4 bot, float &vmax) {
     const int Hp = a.Hout >> 1, Wp = a.Wout >> 1, py = oy >> 1, px = ox >> 1;
     const float p0 = (((top[0] + top[1]) + bot[0]) + bot[1]) * 0.25f;   // summation order of avgpool2_kernel
     const float p1 = (((top[2] + top[3]) + bot[2]) + bot[3]) * 0.25f;
-    range_commit(a.status, range_acc(0.f, p0, p1, 0.f, 0.f));
+    vmax = range_acc(vmax, p0, p1, 0.f, 0.f);
     if (a.dst_fmt) {
         const bool live = co < a.Cout;
         const epi_f32x4 c = quad_transpose(epi_f32x4{live ? p0 : 0.f, live ? p1 : 0.f, 0.f, 0.f});

@@ -25,6 +25,8 @@
 // weights from L2 or LDS): correct, 1.00 / 1.19 ms per 16 frames against 0.46 + 0.36 ms for conv_split + conv_dma - every tile
 // one dependent chain at 2.5 waves per SIMD (tools/probe_front.py: 22 000 clocks per tile, the matrix pipe busy for 7 000).
 // This form: 0.42 ms.
+#include <algorithm>
+
 #include "conv_epilogue.h"
 #include "pf_prof.h"
 #include <type_traits>
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
     // pass believes pending would be protected by s_waitcnt vmcnt(n) in front of its first use in EVERY step - a wait that, in
     // the loop, falls on the window block just requested
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    float vmax = 0.f;
+    float vmax = 0.f, vmax_mid = 0.f;       // range guard (conv_mfma.h): what is stored / what the second conv reads from LDS
     int cur = 0, prev = 2, next = 1;        // ring slots of the window blocks of this step, the one before, the one after
     // step -1 = the masked first step (intermediate row 2 oyA - 1 only); step s >= 0 = output rows oyA + 2 s, + 1
     auto run_step = [&](auto first_c, const int step) {
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(__builtin_fmaf(v[r], a.scale1, b1v[n][r]), lom, him);
             if (n * 4 + gq >= 6 || !live) return;
-            vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
+            vmax_mid = range_acc(vmax_mid, v[0], v[1], v[2], v[3]);
             fm_h4 hi, mid;
             split_terms4(v, hi, mid);
             *reinterpret_cast<fm_h4 *>(row + n * 4 * C::YPLANE) = hi;
@@ -431,13 +433,23 @@ __global__ __launch_bounds__(256, 2) void conv_front_kernel(FrontArgs a) {
     run_step(std::true_type{}, -1);
     for (int step = 0; step < nsteps; ++step) run_step(std::false_type{}, step);
     store_pending(rc_pack, g, 0, 2);
-    range_commit(a.status, vmax);
+    if (a.status) {
+        range_commit(a.status, a.range_slot_mid, vmax_mid);
+        range_commit(a.status, a.range_slot, vmax);
+    }
 #endif
 }
 
-// shapes this kernel is built for: 16 -> 24 -> (16, 32] channels, 3x3 stride 1 then 3x3 stride 2, width % 4 == 0 (16-B pieces), 32-bit offsets
-bool conv_front_supports(int c0, int c1, int c2, int h1, int w1) {
-    return c0 == 16 && c1 == 24 && c2 <= 32 && c2 > 16 && (w1 & 3) == 0 && h1 >= 2 && (long long)h1 * w1 < (1ll << 24);
+// shapes this kernel is built for: 16 -> 24 -> (16, 32] channels, 3x3 stride 1 then 3x3 stride 2, width % 4 == 0 (16-B pieces), 32-bit
+// offsets: the input pieces (h1 * w1 < 2^24) and the stores, whose buffer offsets - (dst_choff + co) * H2 * W2 * 4 in fp32 NCHW,
+// 2 * dst_c4 * H2 * W2 * 8 with the second term's plane offset in the packed layout - must stay below the 2^31 records of the
+// buffer descriptor for EVERY channel of the destination tensor (a wide concatenation at a large resolution would not)
+bool conv_front_supports(int c0, int c1, int c2, int h1, int w1, int dst_ctotal) {
+    const long long h2 = (h1 - 1) / 2 + 1, w2 = (w1 - 1) / 2 + 1;
+    const long long dst_c4 = (dst_ctotal + 3) / 4;
+    const long long max_off = std::max((long long)dst_ctotal * h2 * w2 * 4, 2 * dst_c4 * h2 * w2 * 8);
+    return c0 == 16 && c1 == 24 && c2 <= 32 && c2 > 16 && (w1 & 3) == 0 && h1 >= 2 && (long long)h1 * w1 < (1ll << 24) &&
+           max_off < 0x7FFFFFFFll;
 }
 
 // strips of 31 output columns x segments of `seg_steps` steps (2 output rows each) x frames.  The segment count is the one that

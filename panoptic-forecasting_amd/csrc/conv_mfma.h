@@ -44,6 +44,7 @@ struct ConvArgs {
     long long *probe;        // PF_PROBE builds only: in-kernel timestamps of workgroup 0 / wave 0 (else nullptr)
     unsigned *status;        // range guard of the two-term operand split (below): word 0 of the forward's workspace, or
                              // nullptr (fp32-only plans, training): epilogues OR PF_STATUS_RANGE into it when they store |v| > 65504
+    unsigned *range_slot;    // ... and keep max |v| of what this launch stored here (low side of the guard, below); nullable
     int accum;               // fp32 NCHW stores of conv_mfma.hip and of epi_store (conv_dma / conv_wave): dst += result (gradient
                              // accumulation of the training path); not combined with rem / pool / S4 destinations
     float acc_scale;         // split kernels (conv_split.hip, conv_s4.hip) only: their weights are packed as fp16 terms of
@@ -114,9 +115,49 @@ __device__ __forceinline__ float range_acc(float m, float a, float b, float c, f
 #endif
     return m;
 }
-__device__ __forceinline__ void range_commit(unsigned *status, float m) {
+// Low side of the same guard.  Below |x| = 2^-2 the pair keeps an ABSOLUTE 2^-25 (mid is an fp16 subnormal), so a tensor
+// whose values are all tiny loses relative precision where the reference's fp32 Conv2d (hardnet.py:16-25) does not.  Two
+// measures (hardnet_plan.hip): every tensor channel is stored multiplied by a power of two chosen at plan creation so that
+// its expected magnitude is kRangeTarget (exact re-parameterisation of the folded weights: producers' rows * s, consumers'
+// columns / s), and every launch that produces a split operand reports the maximum |v| of what it stored to its own word of
+// the forward's status block (ConvArgs::range_slot); range_finalize_kernel raises PF_STATUS_RANGE_LOW when a launch's
+// reported maximum is below kRangeLowMax: the unflagged operand bound is then |x - hi - mid| <= 2^-23 |x| + 2^-25, with
+// 2^-25 <= 2^-19 max|tensor| - and the caller re-runs a flagged forward on the fp32 matrix instructions as for overflow.
+// Only a SAMPLE of a launch's workgroups reports (range_sampled: 8-15 of them, picked by a hash of the workgroup id):
+// agent-scope atomics on one address execute memory-side at ~10 ns each (measured: every wave of a 16 384-workgroup launch
+// reporting tripled the kernel's time, and a cached pre-check of the word does not help - the XCD L2s keep serving the value
+// from before the atomics).  Sampling is conservative for this test: a tensor whose values are ALL below the threshold is
+// below it on every sample, so it is always flagged; a tensor with larger values escapes the flag as soon as one sampled
+// workgroup stored one (8 x 32 pixels x all its output channels each).  A reporting wave ORs 1 into the bit pattern, so a word
+// of 0 means "no report" (an op without a slot), and a launch whose sampled values are all exactly zero counts as low.
+constexpr float kRangeTarget = 8.0f;          // expected magnitude of a stored channel after the plan's scaling
+constexpr float kRangeLowMax = 0.015625f;     // 2^-6: a launch whose reported max |v| is below it raises PF_STATUS_RANGE_LOW
+__device__ __forceinline__ bool range_sampled() {   // uniform per workgroup
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (status != nullptr && !(m <= kSplitMaxAbs)) atomicOr(status, 1u);   // PF_STATUS_RANGE
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned mask = total >= 16u ? (1u << (28 - __builtin_clz(total))) - 1u : 0u;   // keeps one workgroup in 2^floor(log2(total)) / 8
+    return (((id * 0x9E3779B1u) >> 9) & mask) == 0u;
+#else
+    return false;
+#endif
+}
+// m = max |v| over what the lane stored (>= 0; v_max3 drops NaN); lanes that have exited are simply not counted
+__device__ __forceinline__ void range_commit(unsigned *status, unsigned *slot, float m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (status == nullptr) return;
+    if (!(m <= kSplitMaxAbs)) atomicOr(status, 1u);   // PF_STATUS_RANGE
+    if (slot == nullptr || !range_sampled()) return;
+    // wave maximum by a scalar walk over the lanes that exceed the running value (~5 steps for unordered data)
+    const unsigned mb = __builtin_bit_cast(unsigned, m);
+    unsigned wm = 0;
+    unsigned long long above = __builtin_amdgcn_ballot_w64(mb > wm);
+    while (above != 0) {
+        wm = (unsigned)__builtin_amdgcn_readlane((int)mb, (int)__builtin_ctzll(above));
+        above = __builtin_amdgcn_ballot_w64(mb > wm);
+    }
+    const unsigned lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (lane_id == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicMax(slot, wm | 1u);   // first active lane
 #endif
 }
 template <typename V4>   // any 4-float vector type
@@ -232,8 +273,12 @@ int launch_conv_s4(const ConvArgs &a, int ks, int nt, int wide, int B, hipStream
 // layout conversion (tests, tensor taps): fp32 NCHW <-> S4
 // status (nullable, device): PF_STATUS_RANGE is raised when an element exceeds what the pair represents (|x| > 65504)
 int launch_s4_pack(const float *src, void *dst, int B, int C, int H, int W, unsigned *status, hipStream_t stream);
-// raises PF_STATUS_RANGE in *status if any of the n floats at x is not |x| <= 65504 (NaN included)
-int launch_range_check(const float *x, size_t n, unsigned *status, hipStream_t stream);
+// raises PF_STATUS_RANGE in *status if any of the n floats at x is not |x| <= 65504 (NaN included); max |x| -> *slot (nullable)
+int launch_range_check(const float *x, size_t n, unsigned *status, unsigned *slot, hipStream_t stream);
+// status block of a forward's workspace (hardnet_plan.hip): word 0 = published PF_STATUS_* bits of the last forward, word
+// sticky_word = OR over all forwards since the host cleared it, word live_word = what the running forward's kernels OR into,
+// words first_slot .. + n_slots - 1 = reported max |v| per launch (bit patterns), the next n_slots words = those of the last forward
+int launch_range_finalize(unsigned *st, int live_word, int first_slot, int n_slots, int sticky_word, hipStream_t stream);
 int launch_s4_unpack(const void *src, float *dst, int B, int C, int H, int W, hipStream_t stream);
 
 // Fused front end (conv_front.hip): 3x3 stride-1 conv (16 -> 24 channels) + 3x3 stride-2 conv (24 -> <= 32) in one kernel; the
@@ -249,10 +294,11 @@ struct FrontArgs {
     int tilesX, tilesY;     // strips x vertical segments (set by the launcher)
     int seg_steps;          // steps (2 output rows each) per segment (set by the launcher)
     unsigned *status;
+    unsigned *range_slot_mid, *range_slot;   // max |v| of the tensor between the two convs / of the output (low side of the range guard); nullable
     long long *probe;       // PF_PROBE builds only (tools/probe_front.py), else nullptr
 };
 
-bool conv_front_supports(int c0, int c1, int c2, int h1, int w1);
+bool conv_front_supports(int c0, int c1, int c2, int h1, int w1, int dst_ctotal);
 int launch_conv_front(const FrontArgs &a, int B, hipStream_t s);
 
 // Kernel/shape choice for one stride-1 conv (conv_select.cpp): kind 1 = conv_dma (p0 = WM, p1 = NT),

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 
     // ---- epilogue: D[row = pixel (lane>>4)*4 + r][col = cout lane&15]; bias + ReLU; NCHW store
     const size_t out_plane = (size_t)a.Hout * a.Wout;
+    float vmax = 0.f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int co = (cb * NT + n) * 16 + (lane & 15);
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 v[r] += bias;
                 if (a.relu) v[r] = fmaxf(v[r], 0.f);
             }
-            range_commit(a.status, range_acc(0.f, v[0], v[1], v[2], v[3]));   // conv_mfma.h: range guard of the operand split
+            vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
             float *p = dplane + (size_t)oy * a.Wout + ox;
             if (ox + 3 < a.Wout && (a.Wout & 3) == 0) {
                 if (a.accum) v += *reinterpret_cast<const f32x4 *>(p);
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             }
         }
     }
+    range_commit(a.status, a.range_slot, vmax);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -43,13 +43,8 @@
 #define S4_PROBE(i) do { } while (0)
 #endif
 
-#ifndef S4_PAIRED      // 1: M-tile pairs = even / odd pixels of a 32-pixel segment, 16-B epilogue stores; 0: 16 consecutive pixels, 8-B stores (A/B)
-#define S4_PAIRED 0
-#endif
-#ifndef S4_ISSUE_FIRST
-#define S4_ISSUE_FIRST 1
-#define S4_ISSUE_STEP 2
-#endif
+// the DMA parts of the next stage go out after MFMA groups 1, 3, .. of a round (every placement measured within 1 %)
+[[maybe_unused]] constexpr int kS4IssueFirst = 1, kS4IssueStep = 2;
 
 namespace pf {
 
@@ -85,10 +80,15 @@ __device__ __forceinline__ bool s4_entry(const ConvArgs &a, int e, int b, size_t
     return e - e0 < gn;
 }
 
-template <int NT, int TW_, int TH_ = 8>
+// KS_ = 2 / 4 (the small levels, 64x128 and below at B = 16: a few hundred workgroups of 20-50 dependent rounds on 256 CUs):
+// KS_ wave groups per workgroup on the same pixel tile, each with its own stage ring; group k runs the k-th part of the rounds
+// (parts of a multiple of 4 rounds: the collected tap spans groups of 4); groups 1.. hand their sums over through LDS and
+// group 0 runs the epilogue.  KS_ times the waves per tile and 1 / KS_ of the dependent chain per wave.
+template <int NT, int TW_, int TH_ = 8, int KS_ = 1>
 struct S4Cfg {
     static constexpr int TW = TW_, TH = TH_, MTR = TW / 16, MP = 2 * MTR;   // TH / 2 waves x MP M-tiles = TH rows x TW pixels
-    static constexpr int NW = TH / 2, NTHR = 64 * NW;                       // TH = 16: 8 waves share the stage (half the weight bytes per MAC, halo 1.27 instead of 1.41)
+    static constexpr int KS = KS_;
+    static constexpr int NW = TH / 2, NTHR = 64 * NW;                       // per wave group.  TH = 16: 8 waves share the stage (half the weight bytes per MAC, halo 1.27 instead of 1.41)
     static constexpr int IW = TW + 4, IH = TH + 2;                        // halo tile, 2-pixel apron left/right (16-B pieces)
     static constexpr int ROWP = IW / 2, PIECES = IH * ROWP;               // 16-B pieces per (term, entry) plane
     static constexpr int NDMA_ALL = (PIECES + 63) / 64;                   // DMA instructions per plane ...
@@ -109,20 +109,25 @@ struct S4Cfg {
     static constexpr int WBUF = NT * BPT * WBLK;                          // [nt][block][term][lane]
     static constexpr int WPIECES = WBUF / 16, NITW = (WPIECES + NTHR - 1) / NTHR;
     static constexpr size_t STAGES_BYTES = 2 * (size_t)ABUF + 2 * (size_t)WBUF;
-    static constexpr size_t LDS_BYTES = STAGES_BYTES + NT * 16 * sizeof(float);   // + the bias values of the workgroup's couts
+    static constexpr size_t LDS_BYTES = KS * STAGES_BYTES + NT * 16 * sizeof(float);   // + the bias values of the workgroup's couts
+    static_assert(KS == 1 || (size_t)MP * NT * NW * 64 * 16 <= STAGES_BYTES, "the K-split hand-over uses group 1's stage ring");
 };
 
 // weight blocks in front of round r (2 per round + one collected-tap block per started group of 4 rounds before it)
 __host__ __device__ inline int s4_blocks_before(int r) { return 2 * r + r / 4; }
 __host__ __device__ inline int s4_blocks_total(int rounds) { return 2 * rounds + (rounds + 3) / 4; }
 
-template <int NT, int TW_, int TH_>
-__global__ __launch_bounds__(32 * TH_, TH_ == 16 ? 2 : (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT == 3) ? 3 : 2) void conv_s4_kernel(ConvArgs a) {
+template <int NT, int TW_, int TH_, int KS_>
+__global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ == 2) ? 2 : (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT == 3) ? 3 : 2) void conv_s4_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using C = S4Cfg<NT, TW_, TH_>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    using C = S4Cfg<NT, TW_, TH_, KS_>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int kgrp = C::KS > 1 ? wave_all / C::NW : 0;            // wave group of the K split (uniform)
+    const int wave = C::KS > 1 ? wave_all % C::NW : wave_all;      // wave inside its group
+    const int tid = C::KS > 1 ? (int)threadIdx.x & (C::NTHR - 1) : (int)threadIdx.x;   // thread inside its group
+    unsigned char *const smem_raw = smem_all + kgrp * C::STAGES_BYTES;   // this group's stage ring
     int tid_lin, cgroup;   // XCD-aware order of tiles and cout groups (conv_mfma.h)
     xcd_tile_order(a.tilesX * a.tilesY, tid_lin, cgroup);
     const int tileY = tid_lin / a.tilesX, tileX = tid_lin - tileY * a.tilesX;
@@ -168,13 +173,11 @@ __global__ __launch_bounds__(32 * TH_, TH_ == 16 ? 2 : (TW_ == 32 && NT <= 2) ? 
     {
         const int ky[2] = {g >> 1, g < 2 ? 2 : g - 2};
         const int kx[2] = {g & 1, g < 2 ? g : 2};
-        // M-tiles come in PAIRS over a 32-pixel row segment: tile 2j = its even pixels, tile 2j+1 = its odd pixels (lane i of
-        // the pair = pixels 2i, 2i+1), so that a lane's two D fragments are two ADJACENT pixels = one 16-B store per term in
-        // the epilogue instead of two 8-B ones (the epilogue is store-issue-bound: 16 % of a workgroup's life).  Bank-wise
-        // the lane stride of 16 B keeps the two lane groups of a ds_read_b64 pass apart exactly as the stride of 8 B did
+        // (M-tile = 16 consecutive pixels of a row.  Pairing even / odd pixels for 16-B epilogue stores was built and measured
+        //  +12 % on the fragment reads: profiles/r03_experiments.md)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) aoff[s] = ((wave * 2 + ky[s]) * C::IW + (S4_PAIRED ? 2 : 1) * (lane & 15) + kx[s] + 1) * 8;
-        aoff_col = ((wave * 2 + 2) * C::IW + (S4_PAIRED ? 2 : 1) * (lane & 15) + 2 + 1) * 8;
+        for (int s = 0; s < 2; ++s) aoff[s] = ((wave * 2 + ky[s]) * C::IW + (lane & 15) + kx[s] + 1) * 8;
+        aoff_col = ((wave * 2 + 2) * C::IW + (lane & 15) + 2 + 1) * 8;
     }
 
     // operand roles are swapped with respect to conv_split.hip (weights = A, pixels = B): the D fragment of lane (g, i) is
@@ -182,14 +185,19 @@ __global__ __launch_bounds__(32 * TH_, TH_ == 16 ? 2 : (TW_ == 32 && NT <= 2) ? 
     // The bias values of the workgroup's couts go to LDS by DMA now (4 B per lane, zero for couts past the layer) and are
     // read back in the epilogue: kept in registers across the main loop they cost NT * 4 registers (spilled at NT = 2, 3),
     // and either way the epilogue had to wait for them with vmcnt - which on gfx950 also waits for the epilogue's own stores
-    float *bias_lds = reinterpret_cast<float *>(smem_raw + C::STAGES_BYTES);
-    if (wave == 0 && lane < NT * 16) {
+    float *bias_lds = reinterpret_cast<float *>(smem_all + C::KS * C::STAGES_BYTES);
+    if (wave_all == 0 && lane < NT * 16) {
         const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias, 0, 0x7FFFFFFF, 0x00020000);
         const int co = tile0 * 16 + lane;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (s4_lds_ptr_t)bias_lds, 4, co < a.ntiles * 16 ? (unsigned)co * 4u : kS4Oob, 0, 0, 0);
     }
 
     const int nrounds = a.nchunks;   // 3x3 launches always run the whole K range (the collected tap spans 4 rounds)
+    // K split: group k runs rounds [k * chunk, (k + 1) * chunk); chunk is a multiple of 4, so every group but the last ends on a
+    // flush round and all see whole groups of four collected-tap rounds.  All groups execute the same number of barriers
+    const int chunk = C::KS > 1 ? (((nrounds + C::KS - 1) / C::KS + 3) / 4) * 4 : nrounds;
+    const int r_begin = min(nrounds, kgrp * chunk), r_end = min(nrounds, r_begin + chunk);
+    const int n_iter = chunk;
     // The DMA instructions of the next stage go out between the matrix groups of the current one (a part = one activation
     // piece + its share of the weight pieces): issued in one block they cost the wave ~1000 clocks per round in which it
     // feeds no MFMA (tools/probe_s4.py).
@@ -218,14 +226,14 @@ __global__ __launch_bounds__(32 * TH_, TH_ == 16 ? 2 : (TW_ == 32 && NT <= 2) ? 
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (s4_lds_ptr_t)(wdst + (it * C::NTHR + wave * 64) * 16), 16, woff[it],
                                                          (unsigned)s4_blocks_before(r) * C::WBLK, 0, 0);
     };
-    // part j of the next stage goes out after MFMA group S4_ISSUE_FIRST + j * S4_ISSUE_STEP of the round (6 HALVES groups)
+    // part j of the next stage goes out after MFMA group kS4IssueFirst + j * kS4IssueStep of the round (6 HALVES groups)
     auto issue_slot = [&](int round, bool more, int slot) {
         if (!more) return;
 #pragma unroll
         for (int j = 0; j < C::NDMA; ++j)
-            if (slot == S4_ISSUE_FIRST + j * S4_ISSUE_STEP) issue_part(round + 1, (round + 1) & 1, j);
+            if (slot == kS4IssueFirst + j * kS4IssueStep) issue_part(round + 1, (round + 1) & 1, j);
     };
-    static_assert(S4_ISSUE_FIRST + (C::NDMA - 1) * S4_ISSUE_STEP < 6 * HALVES, "every DMA part needs a slot inside the two full instructions");
+    static_assert(kS4IssueFirst + (C::NDMA - 1) * kS4IssueStep < 6 * HALVES, "every DMA part needs a slot inside the two full instructions");
 
     // collected tap: K-slice g of these fragments = entries of round 4q + g
     s4_h8 col_h[C::MP], col_m[C::MP];
@@ -233,17 +241,19 @@ __global__ __launch_bounds__(32 * TH_, TH_ == 16 ? 2 : (TW_ == 32 && NT <= 2) ? 
 #pragma unroll
     for (int m = 0; m < C::MP; ++m) col_h[m] = col_m[m] = zero8;
 
-    if (nrounds > 0) {
-        prepare_round(0);
+    if (r_begin < r_end) {
+        prepare_round(r_begin);
 #pragma unroll
-        for (int j = 0; j < C::NDMA; ++j) issue_part(0, 0, j);
+        for (int j = 0; j < C::NDMA; ++j) issue_part(r_begin, r_begin & 1, j);
     }
-    for (int round = 0; round < nrounds; ++round) {
+    for (int it_ = 0; it_ < n_iter; ++it_) {
+        const int round = r_begin + it_;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
         S4_PROBE(round * 4 + 0);
         __syncthreads();                                    // everyone's have, and everyone is done reading the other stage
         S4_PROBE(round * 4 + 1);
-        const bool more = round + 1 < nrounds;
+        if (C::KS > 1 && round >= r_end) continue;          // a shorter part of a K split idles through the others' last rounds
+        const bool more = round + 1 < r_end;
         if (more) prepare_round(round + 1);
         S4_PROBE(round * 4 + 2);
         const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(32 * TH_, TH_ == 16 ? 2 : (TW_ == 32 && NT <= 2) ? 
             md = s4_join(*reinterpret_cast<const s4_h4 *>(p + 2 * C::PLANE), *reinterpret_cast<const s4_h4 *>(p + 3 * C::PLANE));
         };
         auto mtile_off = [&](int mm) {
-            return S4_PAIRED ? ((mm / C::MTR) * C::IW + ((mm % C::MTR) >> 1) * 32 + (mm & 1)) * 8 : ((mm / C::MTR) * C::IW + (mm % C::MTR) * 16) * 8;
+            return ((mm / C::MTR) * C::IW + (mm % C::MTR) * 16) * 8;
         };
         // the three products of one block of weights with 4 M-tiles; `slot0` numbers the MFMA groups for the DMA parts
         auto mfmas = [&](const s4_h8 (&wh)[NT], const s4_h8 (&wm)[NT], int m0, const s4_h8 (&fh)[4], const s4_h8 (&fm)[4], int slot0, bool dma) {
@@ -333,6 +343,27 @@ __global__ __launch_bounds__(32 * TH_, TH_ == 16 ? 2 : (TW_ == 32 && NT <= 2) ? 
         S4_PROBE(round * 4 + 3);
     }
     S4_PROBE(58);
+    if (C::KS > 1) {
+        // hand-over of the K split: groups 1.. park their sums in their own stage rings (conflict-free 16-B units), group 0 adds them
+        __syncthreads();                                    // every wave is done reading its ring
+        if (kgrp > 0) {
+            s4_f32x4 *red = reinterpret_cast<s4_f32x4 *>(smem_raw);
+#pragma unroll
+            for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) red[((m * NT + n) * C::NW + wave) * 64 + lane] = acc[m][n];
+        }
+        __syncthreads();
+        if (kgrp > 0) return;
+#pragma unroll
+        for (int k = 1; k < C::KS; ++k) {
+            const s4_f32x4 *red = reinterpret_cast<const s4_f32x4 *>(smem_all + k * C::STAGES_BYTES);
+#pragma unroll
+            for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] += red[((m * NT + n) * C::NW + wave) * 64 + lane];
+        }
+    }
 
     // ---- epilogue: bias + ReLU; lane (g, i) holds couts 4g..4g+3 of the pixel pair (2i, 2i+1) of every M-tile pair: one
     //      16-B unit [2 px][4 ch] per term, or fp32 NCHW pairs
@@ -376,7 +407,6 @@ __global__ __launch_bounds__(32 * TH_, TH_ == 16 ? 2 : (TW_ == 32 && NT <= 2) ? 
                 }
             }
         };
-#if !S4_PAIRED
 #pragma unroll
         for (int m = 0; m < C::MP; ++m) {
             const int mt = wave * C::MP + m;
@@ -402,71 +432,30 @@ __global__ __launch_bounds__(32 * TH_, TH_ == 16 ? 2 : (TW_ == 32 && NT <= 2) ? 
                 }
             }
         }
-#else
-#pragma unroll
-        for (int m = 0; m < C::MP; m += 2) {
-            const int mt = wave * C::MP + m;
-            const int oy = tileY * C::TH + mt / C::MTR;
-            const int ox = tileX * C::TW + ((mt % C::MTR) >> 1) * 32 + 2 * px;     // even; ox + 1 < Wout (Wout % 4 == 0)
-            if (oy >= a.Hout || ox >= a.Wout) continue;
-            const size_t pix = (size_t)oy * a.Wout + ox;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int co = (tile0 + n) * 16 + 4 * g;
-                if (co >= a.Cout + 2) continue;                      // nothing of this unit is stored (limit <= Cout + 2)
-                s4_f32x4 v0 = acc[m][n], v1 = acc[m + 1][n];
-                const s4_f32x4 b4 = *reinterpret_cast<const s4_f32x4 *>(bias_lds + n * 16 + 4 * g);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v0[r] = fmaxf(v0[r] * a.acc_scale + b4[r], relu_lo);   // acc_scale = 2^-k of the weight scaling: exact
-                    v1[r] = fmaxf(v1[r] * a.acc_scale + b4[r], relu_lo);
-                }
-                vmax = range_acc(range_acc(vmax, v0[0], v0[1], v0[2], v0[3]), v1[0], v1[1], v1[2], v1[3]);
-                const int chb = a.dst_choff + co;
-                if (a.dst_fmt && !mis && chb + 2 < a.dst_limit) {
-                    s4_h4 h0, m0, h1, m1;
-                    split_terms4(v0, h0, m0);
-                    split_terms4(v1, h1, m1);
-                    char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
-                    *reinterpret_cast<s4_h8 *>(p) = s4_join(h0, h1);
-                    *reinterpret_cast<s4_h8 *>(p + term) = s4_join(m0, m1);
-                } else if (a.dst_fmt) {
-                    store_px(co, pix, v0);
-                    store_px(co, pix + 1, v1);
-                } else {
-                    typedef float f2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (co + r < a.Cout)
-                            *reinterpret_cast<f2 *>(a.dst + ((size_t)b * a.dst_ctotal + a.dst_choff + co + r) * hw + pix) = f2{v0[r], v1[r]};
-                }
-            }
-        }
-#endif
-        range_commit(a.status, vmax);
+        range_commit(a.status, a.range_slot, vmax);
     }
     S4_PROBE(59);
 #endif
 }
 
-template <int NT, int TW_, int TH_ = 8>
+template <int NT, int TW_, int TH_ = 8, int KS_ = 1>
 static int launch_s4_cfg(const ConvArgs &a0, int B, hipStream_t s) {
-    using C = S4Cfg<NT, TW_, TH_>;
+    using C = S4Cfg<NT, TW_, TH_, KS_>;
     ConvArgs a = a0;
     a.tilesX = (a.Wout + C::TW - 1) / C::TW;
     a.tilesY = (a.Hout + C::TH - 1) / C::TH;
     static bool attr_set = false;
     if (!attr_set) {
-        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s4_kernel<NT, TW_, TH_>),
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s4_kernel<NT, TW_, TH_, KS_>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_set = true;
     }
     char label[96];
-    snprintf(label, sizeof(label), "void pf::conv_s4_kernel<%d, %d, %d>(pf::ConvArgs)", NT, TW_, TH_);   // = the symbol rocprofv3 reports (bench.py looks its PMC bytes up by it)
+    snprintf(label, sizeof(label), "void pf::conv_s4_kernel<%d, %d, %d, %d>(pf::ConvArgs)", NT, TW_, TH_, KS_);   // = the symbol rocprofv3 reports (bench.py looks its PMC bytes up by it)
     const double px = (double)B * a.Hout * a.Wout;
     ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * 9,
                  4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * 9));
-    hipLaunchKernelGGL((conv_s4_kernel<NT, TW_, TH_>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(C::NTHR), C::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_s4_kernel<NT, TW_, TH_, KS_>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(C::NTHR * C::KS), C::LDS_BYTES, s, a);
     PF_LAUNCH_CHECK("conv_s4_kernel");
     return PF_OK;
 }
@@ -782,7 +771,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : (NT == 3 ? 3 : 2)) void conv_s4_
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        range_commit(a.status, vmax);
+        range_commit(a.status, a.range_slot, vmax);
     }
 #endif
 }
@@ -838,6 +827,15 @@ int launch_conv_s4(const ConvArgs &a, int ks, int nt, int wide, int B, hipStream
             if (nt == 1) return launch_s4_cfg<1, 32, 16>(a, B, s);
             return launch_s4_cfg<2, 32, 16>(a, B, s);
         }
+        if (wide == 4 && a.nchunks >= 16) {   // 8x32-pixel tiles, FOUR wave groups split the rounds (16 waves on one tile)
+            if (nt == 1) return launch_s4_cfg<1, 32, 8, 4>(a, B, s);
+            return launch_s4_cfg<2, 32, 8, 4>(a, B, s);
+        }
+        if (wide >= 3 && a.nchunks >= 8) {   // 8x32-pixel tiles, two wave groups split the rounds (small images, long K)
+            if (nt == 1) return launch_s4_cfg<1, 32, 8, 2>(a, B, s);
+            return launch_s4_cfg<2, 32, 8, 2>(a, B, s);
+        }
+        if (wide >= 3) wide = 0;
         if (wide) {
             if (nt == 1) return launch_s4_cfg<1, 64>(a, B, s);
             if (nt == 2) return launch_s4_cfg<2, 64>(a, B, s);
@@ -951,24 +949,60 @@ __global__ void s4_pack_kernel(const float *src, unsigned short *dst, int B, int
     }
     if (bad && status) atomicOr(status, 1u);   // PF_STATUS_RANGE
 }
-// the range guard for tensors no kernel of this library produced (dense network inputs)
-__global__ void range_check_kernel(const float *x, size_t n, unsigned *status) {
+// the range guard for tensors no kernel of this library produced (dense network inputs): overflow / NaN -> PF_STATUS_RANGE,
+// max |x| -> the launch's slot (low side, conv_mfma.h)
+__global__ void range_check_kernel(const float *x, size_t n, unsigned *status, unsigned *slot) {
     bool bad = false;
+    float m = 0.f;
     const size_t n4 = n / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const s4_f32x4 v = reinterpret_cast<const s4_f32x4 *>(x)[i];
         bad = bad || !(fabsf(v[0]) <= kSplitMaxAbs) || !(fabsf(v[1]) <= kSplitMaxAbs) || !(fabsf(v[2]) <= kSplitMaxAbs) ||
               !(fabsf(v[3]) <= kSplitMaxAbs);
+        m = range_acc(m, v[0], v[1], v[2], v[3]);
     }
-    if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) bad = bad || !(fabsf(x[n4 * 4 + threadIdx.x]) <= kSplitMaxAbs);
+    if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) {
+        const float t = x[n4 * 4 + threadIdx.x];
+        bad = bad || !(fabsf(t) <= kSplitMaxAbs);
+        m = range_acc(m, t, 0.f, 0.f, 0.f);
+    }
     if (bad) atomicOr(status, 1u);   // PF_STATUS_RANGE
+    range_commit(status, slot, m);
 }
-int launch_range_check(const float *x, size_t n, unsigned *status, hipStream_t s) {
+int launch_range_check(const float *x, size_t n, unsigned *status, unsigned *slot, hipStream_t s) {
     if (!status || n == 0) return PF_OK;
     if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(PF_EINVAL, "range check: input is not 16-B aligned");
     const size_t blocks = (n / 4 + 255) / 256;
-    hipLaunchKernelGGL(range_check_kernel, dim3((unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048)), dim3(256), 0, s, x, n, status);
+    hipLaunchKernelGGL(range_check_kernel, dim3((unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048)), dim3(256), 0, s, x, n, status, slot);
     PF_LAUNCH_CHECK("range_check_kernel");
+    return PF_OK;
+}
+// end of a forward: a launch whose reported maximum is below kRangeLowMax raises PF_STATUS_RANGE_LOW; the forward's status
+// (the live word the kernels ORed into) is published in word 0 and ORed into the sticky word (only the host clears that one);
+// the reported maxima move to the "last forward" half of the slot area, and the live word and slots are left cleared for the
+// next forward (hardnet_plan.hip: no memset at the start of a forward)
+__global__ void range_finalize_kernel(unsigned *st, int live_word, int first_slot, int n_slots, unsigned low_bits, int sticky_word) {
+    __shared__ unsigned low;
+    if (threadIdx.x == 0) low = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
+        const unsigned v = st[first_slot + i];
+        if (v != 0 && v < low_bits) low = 1;
+        st[first_slot + n_slots + i] = v;
+        st[first_slot + i] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned w = st[live_word] | (low ? 2u : 0u);   // PF_STATUS_RANGE_LOW
+        st[0] = w;
+        st[sticky_word] |= w;
+        st[live_word] = 0;
+    }
+}
+int launch_range_finalize(unsigned *st, int live_word, int first_slot, int n_slots, int sticky_word, hipStream_t s) {
+    hipLaunchKernelGGL(range_finalize_kernel, dim3(1), dim3(256), 0, s, st, live_word, first_slot, n_slots,
+                       __builtin_bit_cast(unsigned, kRangeLowMax), sticky_word);
+    PF_LAUNCH_CHECK("range_finalize_kernel");
     return PF_OK;
 }
 __global__ void s4_unpack_kernel(const unsigned short *src, float *dst, int B, int C, int H, int W) {

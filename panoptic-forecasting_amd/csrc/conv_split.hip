@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: bias + ReLU, NCHW float4 stores (same D fragment as the fp32 kernels)
+    float vmax = 0.f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int co = (tile0 + n) * 16 + (lane & 15);
@@ -245,9 +246,10 @@ __global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
                 v[r] = v[r] * a.acc_scale + biasv[n];   // acc_scale = 2^-k of the weight scaling: exact
                 if (a.relu) v[r] = fmaxf(v[r], 0.f);
             }
-            epi_store(a, b, co, oy, ox, v);
+            epi_store(a, b, co, oy, ox, v, vmax);
         }
     }
+    range_commit(a.status, a.range_slot, vmax);
 #endif
 }
 
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(256) void conv_split1_kernel(ConvArgs a) {
         __syncthreads();
     }
 
+    float vmax = 0.f;
     if (EPI == 0) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256) void conv_split1_kernel(ConvArgs a) {
                     v[r] = v[r] * a.acc_scale + biasv[n];   // acc_scale = 2^-k of the weight scaling: exact
                     if (a.relu) v[r] = fmaxf(v[r], 0.f);
                 }
-                epi_store(a, b, co, oy, ox, v);
+                epi_store(a, b, co, oy, ox, v, vmax);
             }
         }
     } else {
@@ -497,12 +500,13 @@ __global__ __launch_bounds__(256) void conv_split1_kernel(ConvArgs a) {
                 if (epi_skip(a, co)) continue;
                 const lds_float *chan = res_lds + (n * 16 + (lane_e & 15)) * rw.cs;
                 const sp_f32x4 top = epi_finish(a, b, co, oy, ox, acc[m][n] * a.acc_scale, biasv[n], has_res, chan, &t0);
-                if (!a.pool) epi_store(a, b, co, oy, ox, top);
-                else epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, acc[(m + C::MTR) % C::MP][n] * a.acc_scale, biasv[n], has_res, chan, &t1));
+                if (!a.pool) epi_store(a, b, co, oy, ox, top, vmax);
+                else epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, acc[(m + C::MTR) % C::MP][n] * a.acc_scale, biasv[n], has_res, chan, &t1), vmax);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
+    range_commit(a.status, a.range_slot, vmax);
 #endif
 }
 

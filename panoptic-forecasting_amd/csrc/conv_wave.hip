@@ -260,6 +260,8 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
     asm volatile("" : "+v"(lane_e));
     // unit = one output fragment (or, when pooling, the fragments of rows m, m+1): summed and finished by one wave
     const int rows = (EPI == 1 && a.pool) ? 2 : 1;
+    float vmax = 0.f;
+
 #pragma unroll
     for (int u = 0; u < MH * NT; ++u) {
         if (u % WK != wk || u >= (MH / rows) * NT) continue;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
                 v[r] += biasv[n];
                 if (a.relu) v[r] = fmaxf(v[r], 0.f);
             }
-            epi_store(a, b, co, oy, ox, v);
+            epi_store(a, b, co, oy, ox, v, vmax);
         } else {
             const lds_float *chan = res_lds + (n * 16 + (lane_e & 15)) * rw.cs;
             ResTaps t0, t1;
@@ -292,13 +294,14 @@ __global__ __launch_bounds__(64 * WK) void conv_wave_kernel(ConvArgs a) {
             const f32x4 top = epi_finish(a, b, co, oy, ox, total(m), biasv[n], has_res, chan, &t0);
             if (a.pool) {
                 if (MH > 1 && oy + 1 < a.Hout)
-                    epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, total(MH > 1 ? m + 1 : m), biasv[n], has_res, chan, &t1));
+                    epi_store_pooled(a, b, co, oy, ox, top, epi_finish(a, b, co, oy + 1, ox, total(MH > 1 ? m + 1 : m), biasv[n], has_res, chan, &t1), vmax);
             } else {
-                epi_store(a, b, co, oy, ox, top);
+                epi_store(a, b, co, oy, ox, top, vmax);
             }
             __builtin_amdgcn_sched_barrier(0);   // one fragment at a time (register pressure)
         }
     }
+    range_commit(a.status, a.range_slot, vmax);
 #endif
 }
 

@@ -3,6 +3,7 @@
 // Replaces the module walk of reference hardnet.py:353-387 (hardnet.forward) and the glue of
 // bg_model.py:61-71,91-102.  The op table comes from the blob (packing.py / hardnet_arch.py); nothing
 // about FC-HarDNet-70 is hard-coded here, so single-op test networks use the same code.
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -57,13 +58,22 @@ struct pf_plan {
     int opt_range_guard = 1;   // kernels raise PF_STATUS_RANGE in the workspace's status word when they store |v| > 65504 while
                                // two-term fp16 operands are in use (conv_mfma.h); 0 = no checks (the clamp-free fp32 path needs none)
     int opt_packed_acts = 1;   // tensors whose producers and consumers all support it live in the S4 layout (conv_s4.hip)
-    // formats of the last forward (pf_hardnet_tensor_read): 1 = S4
+    // formats of the last forward (pf_hardnet_tensor_read): 1 = S4, 0xFF = elided (never stored: conv_front.hip)
     mutable std::vector<uint8_t> last_fmt;
+    // range normalisation (conv_mfma.h): tensor t, channel c is stored multiplied by chan_scale[t][c] (a power of two; 1 for
+    // the network input, the head's input and every tensor no convolution reads); inv_scale_off[t] = offset in dev_weights
+    // of the reciprocals (pf_hardnet_tensor_read), or 0 when all are 1
+    std::vector<std::vector<float>> chan_scale;
+    std::vector<size_t> inv_scale_off;
+    std::vector<uint8_t> feeds_conv;   // per tensor: a convolution reads it (directly or through pool / upsample ops)
+    int opt_normalize = 1;
+    int opt_tag_ops = 0;       // pf_profile_* records carry one label per op of the table (tools/)
 };
 
 namespace pf {
 int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_split = 1, g_opt_packed_acts = 1, g_opt_tag_ops = 0;
 int g_opt_range_guard = 1, g_opt_fuse_front = 1;   // fuse_front: conv_front.hip (0: stem -> conv_split -> conv_dma stride 2, three kernels)
+int g_opt_normalize = 1;   // normalize_ranges: per-channel power-of-two scaling of the stored activations, fixed at plan creation
 extern int g_opt_use_tuned;
 }
 
@@ -77,6 +87,7 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "packed_acts")) g_opt_packed_acts = value;
     else if (!strcmp(name, "range_guard")) g_opt_range_guard = value;
     else if (!strcmp(name, "fuse_front")) g_opt_fuse_front = value;
+    else if (!strcmp(name, "normalize_ranges")) g_opt_normalize = value;
     else if (!strcmp(name, "profile_tag_ops")) g_opt_tag_ops = value;
     else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);
     return PF_OK;
@@ -93,6 +104,7 @@ extern "C" int pf_hardnet_plan_set_option(pf_plan *p, const char *name, int valu
     else if (!strcmp(name, "range_guard")) p->opt_range_guard = value;
     else if (!strcmp(name, "fuse_front")) p->opt_fuse_front = value;
     else if (!strcmp(name, "table_batch")) p->opt_table_batch = value < 0 ? 0 : value;
+    else if (!strcmp(name, "profile_tag_ops")) p->opt_tag_ops = value;
     else return fail(PF_EINVAL, "pf_hardnet_plan_set_option: unknown option '%s'", name);
     return PF_OK;
 }
@@ -142,9 +154,15 @@ int propagate_dims(const pf_plan *p, int H, int W, std::vector<Dims> &d) {
     return PF_OK;
 }
 
-// workspace: 256 B of status words (word 0 = PF_STATUS_* bits of the last forward, pfhip.h), then every tensor except the
-// network input in its own 256-B aligned region
-constexpr size_t kStatusBytes = 256;
+// workspace: PF_WS_STATUS_BYTES of status words - word 0 = PF_STATUS_* bits of the last forward (written once, by the
+// range_finalize launch that ends a forward), word 1 = the same bits ORed over every forward since the host cleared it
+// (sticky), word 2 = the word the kernels of the running forward OR their flags into, words kSlot0 + i = max |v| that op i
+// of the table reported so far (bit pattern; low side of the range guard, conv_mfma.h), words kSlot0 + kMaxSlots + i = the
+// same for the last finished forward (pf_hardnet_range_maxima).  The finalizer leaves word 2 and the live slots cleared for
+// the next forward: the host zeroes the block once (pf_hardnet_status_reset) and no forward starts with a memset.  Then
+// every tensor except the network input in its own 256-B aligned region
+constexpr size_t kStatusBytes = PF_WS_STATUS_BYTES;
+constexpr int kStickyWord = PF_WS_STICKY_OFFSET / 4, kLiveWord = 2, kSlot0 = 16, kMaxSlots = ((int)(kStatusBytes / 4) - kSlot0) / 2;
 int layout(const pf_plan *p, int B, const std::vector<Dims> &d, std::vector<size_t> &off, size_t &total) {
     off.assign(p->tensors.size(), (size_t)-1);
     size_t cur = kStatusBytes;
@@ -174,12 +192,19 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         return t == input ? const_cast<float *>(dense_x) : reinterpret_cast<float *>((char *)ws + off[t]);
     };
 
-    const bool tag_ops = g_opt_tag_ops != 0;      // pf_set_option("profile_tag_ops", 1): per-op labels in pf_profile_* records (tools/)
+    const bool tag_ops = p->opt_tag_ops != 0;     // option "profile_tag_ops": per-op labels in pf_profile_* records (tools/)
     const bool fuse = p->opt_fuse_pool != 0;      // option "fuse_pool"
-    // range guard of the two-term operand split (conv_mfma.h): the status word is cleared by every forward; producers of
-    // tensors a split kernel may read raise PF_STATUS_RANGE in it.  fp32-only plans clamp nothing and check nothing
-    PF_HIP_CHECK(hipMemsetAsync(ws, 0, kStatusBytes, s));
-    unsigned *status = (p->opt_split && p->opt_range_guard) ? reinterpret_cast<unsigned *>(ws) : nullptr;
+    // range guard of the two-term operand split (conv_mfma.h): producers of tensors a split kernel may read raise
+    // PF_STATUS_RANGE in the live status word and report their max |v| to their op's slot; the forward ends with range_finalize
+    // (PF_STATUS_RANGE_LOW, published status word, sticky word, everything live cleared for the next forward).  fp32-only plans
+    // clamp nothing and check nothing
+    unsigned *const st_words = reinterpret_cast<unsigned *>(ws);
+    unsigned *const status_all = (p->opt_split && p->opt_range_guard) ? st_words + kLiveWord : nullptr;
+    // the guard of a launch: only if what it stores can become an operand of a split kernel (the logits cannot)
+    auto status_of = [&](uint32_t dst_t) -> unsigned * { return p->feeds_conv[dst_t] ? status_all : nullptr; };
+    auto slot_of = [&](size_t op_i, uint32_t dst_t) -> unsigned * {
+        return (status_all && p->feeds_conv[dst_t]) ? st_words + kSlot0 + op_i : nullptr;
+    };
 
     // ---- tensor formats.  The op loop below runs twice: a dry pass records every launch (which tensors it reads and
     // writes, whether its kernel can read / write the S4 layout of conv_s4.hip), the formats are then decided - a tensor is
@@ -231,7 +256,8 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         a.src_begin = 0;
         a.src_end = a.n_src;
         a.acc_scale = 1.0f;
-        a.status = status;
+        a.status = status_of(o.dst);
+        a.range_slot = slot_of(i, o.dst);
         static const bool probe_on = ab_env("PF_PROBE") != nullptr;
         a.probe = probe_on ? probe_buffer() : nullptr;
     };
@@ -416,7 +442,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                     p->readers[o.dst] == 1 && p->readers[n1.dst] == 1 && n1.relu && p->conv[i + 1].has_s4 && p->conv[i + 1].s4_rounds == 2 &&
                     n2.kind == OP_CONV && n2.k == 3 && n2.stride == 2 && n2.n_src == 1 && n2.src[0].tensor == n1.dst && n2.src[0].choff == 0 &&
                     n2.src[0].ch == n1.cout && p->conv[i + 2].has_front && (n2.dst_choff & 3) == 0 &&
-                    conv_front_supports((int)o.cout, (int)n1.cout, (int)n2.cout, out.h, out.w) && stem_writes_s4(probe) && g_conv_force.kind == 0;
+                    conv_front_supports((int)o.cout, (int)n1.cout, (int)n2.cout, out.h, out.w, (int)p->tensors[n2.dst].channels) && stem_writes_s4(probe) && g_conv_force.kind == 0;
         }
         if (front) {
             const BlobOp &n1 = p->ops[i + 1], &n2 = p->ops[i + 2];
@@ -443,7 +469,8 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.wdep = p->dev_weights + p->conv[i].dep_off;
             a.woh = p->conv[i].has_oh ? p->dev_weights + p->conv[i].oh_off : nullptr;
             a.bias = p->dev_weights + p->conv[i].bias_off;
-            a.status = status;
+            a.status = status_of(o.dst);
+            a.range_slot = slot_of(i, o.dst);
             a.lut = p->dev_lut;
             a.dst = tptr(o.dst);
             a.dst_fmt = 1;
@@ -466,7 +493,9 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             f.dst_limit = rec.dst_limit;
             f.H1 = out.h; f.W1 = out.w; f.H2 = o2.h; f.W2 = o2.w;
             f.C1 = (int)n1.cout; f.C2 = (int)n2.cout; f.relu1 = (int)n1.relu; f.relu2 = (int)n2.relu;
-            f.status = status;
+            f.status = status_all;
+            f.range_slot_mid = slot_of(i + 1, n1.dst);
+            f.range_slot = slot_of(i + 2, n2.dst);
             static const bool front_probe = ab_env("PF_PROBE") != nullptr;
             f.probe = front_probe ? probe_buffer() : nullptr;
             if (tag_ops && prof_enabled()) {
@@ -478,6 +507,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             if ((rc = launch_conv_front(f, B, s))) return rc;
             fmt[o.dst] = 1;            // pf_hardnet_tensor_read unpacks the stem output
             p->last_fmt = fmt;
+            p->last_fmt[n1.dst] = 0xFF;   // ... and refuses the tensor between the two convs: it is never stored
             i += 2;
             continue;
         }
@@ -492,7 +522,8 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.probe = stem_probe ? probe_buffer() : nullptr;
             a.dbg_plane_pad = stem_plane_pad;
             a.bias = p->dev_weights + p->conv[i].bias_off;
-            a.status = status;
+            a.status = status_of(o.dst);
+            a.range_slot = slot_of(i, o.dst);
             a.lut = p->dev_lut;
             a.dst = tptr(o.dst);
             a.Hout = out.h;
@@ -506,8 +537,9 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             if (o.src[0].tensor == input && !dense_x)
                 return fail(PF_EINVAL, "network input is consumed by a generic conv: use pf_hardnet_forward_dense");
             // a caller-provided dense input has no producer kernel that could have checked its range
-            if (o.src[0].tensor == input && !dry && status &&
-                (rc = launch_range_check(dense_x, (size_t)B * p->tensors[input].channels * in.h * in.w, status, s)))
+            // (its maximum goes to the last slot of the block: the input has no op of its own)
+            if (o.src[0].tensor == input && !dry && status_all &&
+                (rc = launch_range_check(dense_x, (size_t)B * p->tensors[input].channels * in.h * in.w, status_all, st_words + kSlot0 + kMaxSlots - 1, s)))
                 return rc;
             // conv + AvgPool2d(2,2): pool in the conv epilogue, the full-resolution tensor is never written
             const BlobOp *pool = nullptr;
@@ -523,12 +555,14 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                 a.dst = tptr(pool->dst);
                 mt.dst_t = pool->dst;
                 a.dst_ctotal = (int)p->tensors[pool->dst].channels;
+                a.status = status_of(pool->dst);
+                a.range_slot = slot_of(i, pool->dst);
             }
             if ((rc = launch_conv_op(o, i, a, mt, pool ? 2 : 0))) return rc;
             if (pool) ++i;   // the pool op is done
         } else if (o.kind == OP_POOL) {
             if (dry) { pin_fp32(o); continue; }
-            if ((rc = launch_avgpool2(tptr(o.src[0].tensor), tptr(o.dst), B * (int)o.cin, in.h, in.w, s))) return rc;
+            if ((rc = launch_avgpool2(tptr(o.src[0].tensor), tptr(o.dst), B * (int)o.cin, in.h, in.w, status_of(o.dst), slot_of(i, o.dst), s))) return rc;
         } else if (o.kind == OP_UPSAMPLE && can_commute_upsample(i, in, out)) {
             // TransitionUp + 1x1 conv over cat([up(x), skip])  ==  W_skip*skip + up(W_x*x)   (conv_epilogue.h)
             const BlobOp &n = p->ops[i + 1];
@@ -547,6 +581,8 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             lo.dst_choff = 0;
             lo.relu = 0;
             lo.no_bias = 1;
+            lo.status = nullptr;                               // an fp32 residual of the other half, never a split operand
+            lo.range_slot = nullptr;
             lo.Cin = (int)n.src[0].ch;
             lo.src_begin = 0;
             lo.src_end = 1;
@@ -578,7 +614,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             ++i;   // the 1x1 conv is done
         } else if (o.kind == OP_UPSAMPLE) {
             if (dry) { pin_fp32(o); continue; }
-            if ((rc = launch_upsample(tptr(o.src[0].tensor), tptr(o.dst), B * (int)o.cin, in.h, in.w, out.h, out.w, s)))
+            if ((rc = launch_upsample(tptr(o.src[0].tensor), tptr(o.dst), B * (int)o.cin, in.h, in.w, out.h, out.w, status_of(o.dst), slot_of(i, o.dst), s)))
                 return rc;
         } else if (o.kind == OP_HEAD) {
             if (dry) { pin_fp32(o); continue; }
@@ -616,10 +652,107 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
     }
     }
     if (tag_ops) prof_set_tag(nullptr);
-    return PF_OK;
+    // the dense input's slot is the last word of the block: the finalizer scans all of it (unused slots stay 0)
+    return launch_range_finalize(st_words, kLiveWord, kSlot0, kMaxSlots, kStickyWord, s);
 }
 
 }  // namespace
+
+// Range normalisation (conv_mfma.h, "low side"): a static range propagation over the op table.  est[t][c] = expected magnitude
+// (rms-like) of channel c of tensor t in the ORIGINAL units: 1 for dense inputs (sqrt(1/n_cls) for the one-hot channels of the
+// fused stem), sqrt(sum_k |w_ok|^2 est_k^2 + b_o^2) behind a conv (uncorrelated-inputs model), / sqrt(2) behind a ReLU, copied
+// through pool / upsample.  Channel c is then STORED multiplied by s = 2^round(log2(kRangeTarget / est)): the producer's
+// weight row and bias are multiplied by s, every consumer's weight column divided by it - powers of two, so the network
+// computes bit-identical fp32 products; only where the fp16 pair's subnormal floor (2^-25 absolute) and its ceiling (65504)
+// fall relative to the data changes.  A checkpoint re-parameterised across a BatchNorm (gamma * alpha, next weights / alpha)
+// gets s / alpha and stores the same values.  Channels of tensors no convolution reads (network outputs, the head's input)
+// keep s = 1.  The guarantee itself is the run-time guard (PF_STATUS_RANGE / PF_STATUS_RANGE_LOW); this only decides how
+// often it fires.
+static void normalize_ranges(pf_plan *p, std::vector<float> &w) {
+    const size_t nT = p->tensors.size();
+    p->chan_scale.assign(nT, std::vector<float>());
+    std::vector<std::vector<double>> est(nT);
+    for (size_t t = 0; t < nT; ++t) {
+        p->chan_scale[t].assign(p->tensors[t].channels, 1.0f);
+        est[t].assign(p->tensors[t].channels, 1.0);
+    }
+    // feeds_conv: backwards over the table (ops are in topological order)
+    p->feeds_conv.assign(nT, 0);
+    for (size_t i = p->ops.size(); i-- > 0;) {
+        const BlobOp &o = p->ops[i];
+        if (o.kind == OP_STEM || o.kind == OP_CONV)
+            for (uint32_t j = 0; j < o.n_src; ++j) p->feeds_conv[o.src[j].tensor] = 1;
+        else if ((o.kind == OP_POOL || o.kind == OP_UPSAMPLE) && p->feeds_conv[o.dst])
+            p->feeds_conv[o.src[0].tensor] = 1;
+    }
+    // pinned to s = 1: read by the head, by nobody (outputs tapped by the caller), or the network input
+    std::vector<uint8_t> pinned(nT, 0), read(nT, 0);
+    for (const BlobOp &o : p->ops) {
+        for (uint32_t j = 0; j < (o.kind == OP_UPSAMPLE ? 1u : o.n_src); ++j) read[o.src[j].tensor] = 1;
+        if (o.kind == OP_HEAD) pinned[o.src[0].tensor] = 1;
+    }
+    for (size_t t = 0; t < nT; ++t) pinned[t] = pinned[t] || !read[t] || !p->feeds_conv[t];
+    if (p->ops.empty()) return;
+    const uint32_t input = p->ops[0].src[0].tensor;
+    pinned[input] = 1;
+    if (p->ops[0].kind == OP_STEM && p->hdr.n_cls > 0) {   // fused stem: T * n_cls one-hot channels, then T depth channels
+        const uint32_t C = p->tensors[input].channels, T = C / (p->hdr.n_cls + 1);
+        if (T * (p->hdr.n_cls + 1) == C)
+            for (uint32_t c = 0; c < T * p->hdr.n_cls; ++c) est[input][c] = std::sqrt(1.0 / p->hdr.n_cls);
+    }
+    // pool / upsample outputs inherit their source's scale: they are pinned iff ... their source is; a pinned destination of
+    // such an op pins the source channel too (the scale must be the same on both sides), so walk backwards first
+    for (size_t i = p->ops.size(); i-- > 0;) {
+        const BlobOp &o = p->ops[i];
+        if ((o.kind == OP_POOL || o.kind == OP_UPSAMPLE) && pinned[o.dst]) pinned[o.src[0].tensor] = 1;
+    }
+    for (const BlobOp &o : p->ops) {
+        if (o.kind == OP_POOL || o.kind == OP_UPSAMPLE) {
+            for (uint32_t c = 0; c < o.src[0].ch; ++c) {
+                p->chan_scale[o.dst][o.dst_choff + c] = p->chan_scale[o.src[0].tensor][o.src[0].choff + c];
+                est[o.dst][o.dst_choff + c] = est[o.src[0].tensor][o.src[0].choff + c];
+            }
+            continue;
+        }
+        if (o.kind != OP_STEM && o.kind != OP_CONV) continue;
+        const size_t kk = (size_t)o.k * o.k;
+        // input channel k of the conv -> (estimate, stored scale)
+        std::vector<double> e_in(o.cin);
+        std::vector<float> s_in(o.cin);
+        uint32_t k0 = 0;
+        for (uint32_t j = 0; j < o.n_src; ++j)
+            for (uint32_t c = 0; c < o.src[j].ch; ++c, ++k0) {
+                e_in[k0] = est[o.src[j].tensor][o.src[j].choff + c];
+                s_in[k0] = p->chan_scale[o.src[j].tensor][o.src[j].choff + c];
+            }
+        for (uint32_t co = 0; co < o.cout; ++co) {
+            float *wr = w.data() + o.w_off + (size_t)co * o.cin * kk;
+            float &b = w[o.b_off + co];
+            double var = (double)b * b;
+            for (uint32_t k = 0; k < o.cin; ++k) {
+                double ss = 0;
+                for (size_t q = 0; q < kk; ++q) ss += (double)wr[k * kk + q] * wr[k * kk + q];
+                var += ss * e_in[k] * e_in[k];
+            }
+            double e = std::sqrt(var);
+            if (o.relu) e *= 0.70710678118654752;
+            float s_out = 1.0f;
+            if (p->opt_normalize && !pinned[o.dst] && e > 0 && std::isfinite(e)) {
+                int ex = (int)std::lround(std::log2((double)kRangeTarget / e));
+                ex = ex < -60 ? -60 : (ex > 60 ? 60 : ex);
+                s_out = std::ldexp(1.0f, ex);
+            }
+            for (uint32_t k = 0; k < o.cin; ++k) {
+                const float f = s_out / s_in[k];   // a power of two
+                if (f != 1.0f)
+                    for (size_t q = 0; q < kk; ++q) wr[k * kk + q] *= f;
+            }
+            b *= s_out;
+            p->chan_scale[o.dst][o.dst_choff + co] = s_out;
+            est[o.dst][o.dst_choff + co] = e;
+        }
+    }
+}
 
 extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch, int n_cls, pf_plan **out) {
     if (!blob || !out) return fail(PF_EINVAL, "pf_hardnet_plan_create: null argument");
@@ -639,17 +772,20 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
     p->opt_split = g_opt_split; p->opt_use_tuned = g_opt_use_tuned; p->opt_packed_acts = g_opt_packed_acts;
     p->opt_range_guard = g_opt_range_guard;
     p->opt_fuse_front = g_opt_fuse_front;
+    p->opt_normalize = g_opt_normalize;
+    p->opt_tag_ops = g_opt_tag_ops;
     p->hdr = h;
     p->tensors.resize(h.n_tensors);
     p->ops.resize(h.n_ops);
     memcpy(p->tensors.data(), (const char *)blob + h.tensor_off, h.n_tensors * sizeof(BlobTensor));
     memcpy(p->ops.data(), (const char *)blob + h.op_off, h.n_ops * sizeof(BlobOp));
-    const float *wts = reinterpret_cast<const float *>((const char *)blob + h.weights_off);
     const size_t n_w = (bytes - h.weights_off) / sizeof(float);
+    if ((int)p->ops.size() >= kMaxSlots - 1) {
+        delete p;
+        return fail(PF_EUNSUPPORTED, "op table of %zu ops: the status block has %d per-op words", p->ops.size(), kMaxSlots - 1);
+    }
 
-    // validate + tile the weights on the host
-    std::vector<float> host(64, 0.f);   // zero page
-    p->conv.resize(p->ops.size());
+    // validate the op table
     for (size_t i = 0; i < p->ops.size(); ++i) {
         const BlobOp &o = p->ops[i];
         bool ok = o.n_src >= 1 && o.n_src <= (uint32_t)kMaxSrc && o.dst < h.n_tensors;
@@ -663,10 +799,23 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
             ok = cin == o.cin && o.dst_choff + o.cout <= p->tensors[o.dst].channels && (o.k == 1 || o.k == 3) &&
                  (o.stride == 1 || o.stride == 2) && o.w_off + (uint64_t)o.cout * o.cin * o.k * o.k <= n_w &&
                  o.b_off + o.cout <= n_w;
+        if (ok && (o.kind == OP_POOL || o.kind == OP_UPSAMPLE)) ok = o.src[0].ch <= p->tensors[o.dst].channels;
         if (!ok) {
             delete p;
             return fail(PF_EBLOB, "op %zu is inconsistent with the tensor table", i);
         }
+    }
+    // the folded weights, re-parameterised so that every stored channel has an expected magnitude of kRangeTarget
+    std::vector<float> wnorm(reinterpret_cast<const float *>((const char *)blob + h.weights_off),
+                             reinterpret_cast<const float *>((const char *)blob + h.weights_off) + n_w);
+    normalize_ranges(p, wnorm);
+    const float *wts = wnorm.data();
+
+    // tile the weights on the host
+    std::vector<float> host(64, 0.f);   // zero page
+    p->conv.resize(p->ops.size());
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const BlobOp &o = p->ops[i];
         if (o.kind != OP_STEM && o.kind != OP_CONV) continue;
         if (o.k == 1 && o.stride != 1) {
             delete p;
@@ -790,6 +939,15 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
     p->readers.assign(p->tensors.size(), 0);
     for (const BlobOp &o : p->ops)
         for (uint32_t j = 0; j < o.n_src; ++j) p->readers[o.src[j].tensor]++;
+    p->inv_scale_off.assign(p->tensors.size(), 0);
+    for (size_t t = 0; t < p->tensors.size(); ++t) {
+        bool any = false;
+        for (float v : p->chan_scale[t]) any = any || v != 1.0f;
+        if (!any) continue;
+        p->inv_scale_off[t] = host.size();
+        for (float v : p->chan_scale[t]) host.push_back(1.0f / v);   // exact: powers of two
+        host.resize(align_up(host.size(), 64), 0.f);
+    }
     p->dev_floats = host.size();
     uint8_t lut[256];
     fill_lut(lut);
@@ -862,6 +1020,30 @@ extern "C" int pf_hardnet_status(const void *ws, unsigned *status, void *stream)
     return PF_OK;
 }
 
+extern "C" int pf_hardnet_status_sticky(void *ws, unsigned *status, int clear, void *stream) {
+    if (!ws || !status) return fail(PF_EINVAL, "pf_hardnet_status_sticky: null argument");
+    char *w = (char *)ws + PF_WS_STICKY_OFFSET;
+    PF_HIP_CHECK(hipMemcpyAsync(status, w, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (clear) PF_HIP_CHECK(hipMemsetAsync(w, 0, sizeof(unsigned), (hipStream_t)stream));
+    PF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return PF_OK;
+}
+
+extern "C" int pf_hardnet_status_reset(void *ws, void *stream) {
+    if (!ws) return fail(PF_EINVAL, "pf_hardnet_status_reset: null argument");
+    PF_HIP_CHECK(hipMemsetAsync(ws, 0, PF_WS_STATUS_BYTES, (hipStream_t)stream));
+    return PF_OK;
+}
+
+extern "C" int pf_hardnet_range_maxima(const pf_plan *p, const void *ws, float *maxima, int cap, int *n_ops, void *stream) {
+    if (!p || !ws || !maxima || !n_ops) return fail(PF_EINVAL, "pf_hardnet_range_maxima: null argument");
+    *n_ops = (int)p->ops.size();
+    if (cap < *n_ops) return fail(PF_EINVAL, "pf_hardnet_range_maxima: room for %d values, the plan has %d ops", cap, *n_ops);
+    PF_HIP_CHECK(hipMemcpyAsync(maxima, (const char *)ws + (kSlot0 + kMaxSlots) * 4, p->ops.size() * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    PF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return PF_OK;
+}
+
 extern "C" int pf_hardnet_tensor_view(const pf_plan *p, const char *name, int B, int H, int W, size_t *ws_offset,
                                       int *channels, int *h, int *w) {
     if (!p || !name || !ws_offset || !channels || !h || !w) return fail(PF_EINVAL, "pf_hardnet_tensor_view: null");
@@ -884,6 +1066,11 @@ extern "C" int pf_hardnet_tensor_view(const pf_plan *p, const char *name, int B,
     return fail(PF_EINVAL, "no tensor named '%s'", name);
 }
 
+__global__ void unscale_channels_kernel(float *x, const float *inv_scale, int C, size_t hw, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        x[i] *= inv_scale[(i / hw) % C];
+}
+
 extern "C" int pf_hardnet_tensor_read(const pf_plan *p, const char *name, int B, int H, int W, const void *ws, float *dst,
                                       void *stream) {
     if (!p || !name || !ws || !dst) return fail(PF_EINVAL, "pf_hardnet_tensor_read: null");
@@ -894,8 +1081,20 @@ extern "C" int pf_hardnet_tensor_read(const pf_plan *p, const char *name, int B,
     size_t t = 0;
     while (strncmp(p->tensors[t].name, name, sizeof(p->tensors[t].name)) != 0) ++t;
     const char *src = (const char *)ws + off;
-    if (t < p->last_fmt.size() && p->last_fmt[t]) return launch_s4_unpack(src, dst, B, c, h, w, (hipStream_t)stream);
-    PF_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)B * c * h * w * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (t < p->last_fmt.size() && p->last_fmt[t] == 0xFF)
+        return fail(PF_EUNSUPPORTED, "tensor '%s' was elided by the fused front end (never stored); set plan option fuse_front = 0 to tap it", name);
+    if (t < p->last_fmt.size() && p->last_fmt[t]) {
+        if ((rc = launch_s4_unpack(src, dst, B, c, h, w, (hipStream_t)stream))) return rc;
+    } else {
+        PF_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)B * c * h * w * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    // tensors are stored multiplied by the plan's per-channel powers of two (normalize_ranges): undo it for the caller
+    if (p->inv_scale_off[t]) {
+        const size_t n = (size_t)B * c * h * w;
+        hipLaunchKernelGGL(unscale_channels_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream,
+                           dst, p->dev_weights + p->inv_scale_off[t], c, (size_t)h * w, n);
+        PF_LAUNCH_CHECK("unscale_channels_kernel");
+    }
     return PF_OK;
 }
 

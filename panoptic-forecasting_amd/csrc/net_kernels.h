@@ -20,6 +20,7 @@ struct StemArgs {
     float depth_mean, depth_std, min_depth, max_depth;
     int seg_is_i64, hop, B, T, n_cls, H, W, Hout, Wout;
     unsigned *status;      // range guard of the operand split (conv_mfma.h): |output| > 65504 raises PF_STATUS_RANGE; nullable
+    unsigned *range_slot;  // ... and max |output| goes to this word of the status block (low side of the guard); nullable
     long long *probe;      // PF_PROBE builds only
     int dbg_plane_pad;     // timing experiment only (PF_DBG_PLANE_PAD): extra floats between output planes
 };
@@ -33,8 +34,9 @@ struct HeadArgs {
 
 int launch_stem(const StemArgs &a, hipStream_t s);
 bool stem_writes_s4(const StemArgs &a);   // the kernel launch_stem() picks for these arguments can write dst_fmt = 1
-int launch_avgpool2(const float *src, float *dst, int planes, int Hin, int Win, hipStream_t s);
-int launch_upsample(const float *src, float *dst, int planes, int Hin, int Win, int Hout, int Wout, hipStream_t s);
+// status / slot (nullable): max |output| of the launch for the low side of the range guard (conv_mfma.h)
+int launch_avgpool2(const float *src, float *dst, int planes, int Hin, int Win, unsigned *status, unsigned *slot, hipStream_t s);
+int launch_upsample(const float *src, float *dst, int planes, int Hin, int Win, int Hout, int Wout, unsigned *status, unsigned *slot, hipStream_t s);
 int launch_head(const HeadArgs &a, hipStream_t s);
 
 }  // namespace pf

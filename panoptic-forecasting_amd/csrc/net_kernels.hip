@@ -89,12 +89,14 @@ __global__ __launch_bounds__(256) void stem_onehot_kernel(StemArgs a) {
     const size_t op = (size_t)a.Hout * a.Wout;
     float *o = a.dst + (size_t)b * 16 * op + (size_t)oy * a.Wout + ox;
     float vmax = 0.f;   // the output is >= 0 after the ReLU: range guard of the operand split (conv_mfma.h)
+    bool nan = false;   // a NaN input propagates like in the reference's fp32 conv, but max() would drop it: flag it
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         o[i * op] = fmaxf(acc[i], 0.f);
         vmax = fmaxf(vmax, acc[i]);
+        nan = nan || acc[i] != acc[i];
     }
-    range_commit(a.status, vmax);
+    range_commit(a.status, a.range_slot, nan ? __builtin_inff() : vmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -182,12 +184,14 @@ __global__ __launch_bounds__(256) void stem_onehot_batched_kernel(StemArgs a) {
     const size_t op = (size_t)a.Hout * a.Wout;
     float *o = a.dst + (size_t)b * 16 * op + (size_t)oy * a.Wout + ox;
     float vmax = 0.f;   // the output is >= 0 after the ReLU: range guard of the operand split (conv_mfma.h)
+    bool nan = false;   // a NaN input propagates like in the reference's fp32 conv, but max() would drop it: flag it
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         o[i * op] = fmaxf(acc[i], 0.f);
         vmax = fmaxf(vmax, acc[i]);
+        nan = nan || acc[i] != acc[i];
     }
-    range_commit(a.status, vmax);
+    range_commit(a.status, a.range_slot, nan ? __builtin_inff() : vmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -296,13 +300,15 @@ __global__ __launch_bounds__(256) void stem_onehot_v3_kernel(StemArgs a) {
     const size_t op = (size_t)a.Hout * a.Wout;
     float *o = a.dst + (size_t)b * 16 * op + (size_t)oy * a.Wout + ox;
     float vmax = 0.f;   // range guard of the operand split (conv_mfma.h)
+    bool nan = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         o[(2 * i) * op] = fmaxf(acc[i].x, 0.f);
         o[(2 * i + 1) * op] = fmaxf(acc[i].y, 0.f);
         vmax = fmaxf(vmax, fmaxf(acc[i].x, acc[i].y));
+        nan = nan || acc[i].x != acc[i].x || acc[i].y != acc[i].y;
     }
-    range_commit(a.status, vmax);
+    range_commit(a.status, a.range_slot, nan ? __builtin_inff() : vmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -432,6 +438,17 @@ __global__ __launch_bounds__(256) void stem_onehot_v4_kernel(StemArgs a, float i
     }
     const size_t op = (size_t)a.Hout * a.Wout;
     float vmax = 0.f;   // range guard of the operand split (conv_mfma.h): base.1 reads this tensor through conv_split
+    if (!HOP_D) {
+        // a NaN depth (the hop chain cannot produce one: its clamp absorbs it) propagates through the reference's fp32 conv; here
+        // the ReLU's max would turn it into 0: the sum of all accumulators is NaN iff one of them is (or two infinities cancel)
+        f32x2v sum = f32x2v{0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += acc[o >> 1][o & 1][i];
+        const float s1 = sum.x + sum.y;
+        if (s1 != s1) vmax = __builtin_inff();
+    }
     if (a.dst_fmt) {
         // packed pairs for the fused front kernel (conv_front.hip): per term and channel group one 16-B unit [2 px][4 ch]
         char *base = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * 4 * op * 8;
@@ -455,7 +472,7 @@ __global__ __launch_bounds__(256) void stem_onehot_v4_kernel(StemArgs a, float i
                 *reinterpret_cast<split_x8 *>(p + (size_t)4 * op * 8) = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         }
-        range_commit(a.status, vmax);
+        range_commit(a.status, a.range_slot, vmax);
         return;
     }
 #pragma unroll
@@ -468,12 +485,13 @@ __global__ __launch_bounds__(256) void stem_onehot_v4_kernel(StemArgs a, float i
             vmax = range_acc(vmax, acc[dy][0][i].x, acc[dy][1][i].x, acc[dy][0][i].y, acc[dy][1][i].y);
         }
     }
-    range_commit(a.status, vmax);
+    range_commit(a.status, a.range_slot, vmax);
 }
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void avgpool2_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                       int planes, int Hin, int Win, int Hout, int Wout) {
+                                                       int planes, int Hin, int Win, int Hout, int Wout, unsigned *status, unsigned *slot) {
+    float vmax = 0.f;
     const size_t total = (size_t)planes * Hout * Wout;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int x = (int)(i % Wout);
@@ -481,12 +499,16 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const float *__restrict__
         const int y = (int)(r % Hout);
         const size_t p = r / Hout;
         const float *s = src + (p * Hin + 2 * y) * (size_t)Win + 2 * x;
-        dst[i] = (((s[0] + s[1]) + s[Win]) + s[Win + 1]) * 0.25f;
+        const float v = (((s[0] + s[1]) + s[Win]) + s[Win + 1]) * 0.25f;
+        dst[i] = v;
+        vmax = fmaxf(vmax, fabsf(v));
     }
+    range_commit(status, slot, vmax);
 }
 
 __global__ __launch_bounds__(256) void upsample_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                       int planes, int Hin, int Win, int Hout, int Wout) {
+                                                       int planes, int Hin, int Win, int Hout, int Wout, unsigned *status, unsigned *slot) {
+    float vmax = 0.f;
     const float sh = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
     const float sw = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
     const size_t total = (size_t)planes * Hout * Wout;
@@ -502,8 +524,11 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float *__restrict__
         const float *s = src + p * (size_t)Hin * Win;
         const float t0 = lx0 * s[(size_t)y0 * Win + x0] + lx1 * s[(size_t)y0 * Win + x1];
         const float t1 = lx0 * s[(size_t)y1 * Win + x0] + lx1 * s[(size_t)y1 * Win + x1];
-        dst[i] = hy0 * t0 + hy1 * t1;
+        const float v = hy0 * t0 + hy1 * t1;
+        dst[i] = v;
+        vmax = fmaxf(vmax, fabsf(v));
     }
+    range_commit(status, slot, vmax);
 }
 
 // final upsample + argmax; logits [B,C,Hin,Win] -> seg [B,Hout,Wout] (+ optional full logits)
@@ -884,19 +909,20 @@ int launch_stem(const StemArgs &a, hipStream_t s) {
     return PF_OK;
 }
 
-int launch_avgpool2(const float *src, float *dst, int planes, int Hin, int Win, hipStream_t s) {
+int launch_avgpool2(const float *src, float *dst, int planes, int Hin, int Win, unsigned *status, unsigned *slot, hipStream_t s) {
     const int Ho = Hin / 2, Wo = Win / 2;
     ProfScope ps(s, "pf::avgpool2_kernel", 0, 4.0 * planes * ((double)Hin * Win + (double)Ho * Wo));
     hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for((size_t)planes * Ho * Wo)), dim3(256), 0, s, src, dst, planes,
-                       Hin, Win, Ho, Wo);
+                       Hin, Win, Ho, Wo, status, slot);
     PF_LAUNCH_CHECK("avgpool2_kernel");
     return PF_OK;
 }
 
-int launch_upsample(const float *src, float *dst, int planes, int Hin, int Win, int Hout, int Wout, hipStream_t s) {
+int launch_upsample(const float *src, float *dst, int planes, int Hin, int Win, int Hout, int Wout, unsigned *status, unsigned *slot,
+                    hipStream_t s) {
     ProfScope ps(s, "pf::upsample_kernel", 0, 4.0 * planes * ((double)Hin * Win + (double)Hout * Wout));
     hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((size_t)planes * Hout * Wout)), dim3(256), 0, s, src, dst,
-                       planes, Hin, Win, Hout, Wout);
+                       planes, Hin, Win, Hout, Wout, status, slot);
     PF_LAUNCH_CHECK("upsample_kernel");
     return PF_OK;
 }

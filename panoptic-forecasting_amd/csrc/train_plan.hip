@@ -380,9 +380,9 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
                 if ((rc = run_conv(a, (int)o.k, (int)o.stride, theta + p->w_off[i], (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, 0, 0, 0))) return rc;
             }
         } else if (o.kind == OP_POOL) {
-            if ((rc = launch_avgpool2(act(o.src[0].tensor), act(o.dst), B * (int)o.cin, in.h, in.w, s))) return rc;
+            if ((rc = launch_avgpool2(act(o.src[0].tensor), act(o.dst), B * (int)o.cin, in.h, in.w, nullptr, nullptr, s))) return rc;
         } else if (o.kind == OP_UPSAMPLE) {
-            if ((rc = launch_upsample(act(o.src[0].tensor), act(o.dst), B * (int)o.cin, in.h, in.w, out.h, out.w, s))) return rc;
+            if ((rc = launch_upsample(act(o.src[0].tensor), act(o.dst), B * (int)o.cin, in.h, in.w, out.h, out.w, nullptr, nullptr, s))) return rc;
         } else if (o.kind == OP_HEAD) {
             if ((rc = launch_ce_fwd_bwd(act(o.src[0].tensor), B, (int)o.cin, in.h, in.w, labels, labels_i64, out_h, out_w, ignore_index, dfull,
                                         cepart, loss3, s)))

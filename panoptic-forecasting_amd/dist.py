@@ -78,6 +78,22 @@ def device_identity(local):
     return 'pci:%s:%s:%s' % (getattr(p, 'pci_domain_id', '?'), getattr(p, 'pci_bus_id', '?'), getattr(p, 'pci_device_id', local))
 
 
+def backend_description():
+    """What carries the collectives of this run: ``'single process'``, or the torch.distributed backend string with the
+    RCCL version when it is "nccl" (which is RCCL on ROCm)."""
+    if not is_dist():
+        return 'single process'
+    b = str(dist.get_backend())
+    if b == 'nccl':
+        try:
+            v = torch.cuda.nccl.version()
+            v = '.'.join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        except Exception as e:   # pragma: no cover - version probe only
+            v = 'unknown (%s)' % type(e).__name__
+        return 'nccl = RCCL %s, world %d' % (v, dist.get_world_size())
+    return '%s, world %d' % (b, dist.get_world_size())
+
+
 def max_over_ranks(x, device):
     if not is_dist():
         return float(x)

@@ -28,6 +28,9 @@ SIGNATURES = {
                                     _c.POINTER(_i), _c.POINTER(_i)]),
     'pf_hardnet_tensor_read': (_i, [_vp, _c.c_char_p, _i, _i, _i, _vp, _vp, _vp]),
     'pf_hardnet_status': (_i, [_vp, _c.POINTER(_c.c_uint), _vp]),
+    'pf_hardnet_status_sticky': (_i, [_vp, _c.POINTER(_c.c_uint), _i, _vp]),
+    'pf_hardnet_status_reset': (_i, [_vp, _vp]),
+    'pf_hardnet_range_maxima': (_i, [_vp, _vp, _vp, _i, _c.POINTER(_i), _vp]),
     'pf_s4_pack': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'pf_s4_unpack': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'pf_hardnet_flops': (_i, [_vp, _i, _i, _c.POINTER(_c.c_double)]),

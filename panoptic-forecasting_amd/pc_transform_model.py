@@ -25,21 +25,24 @@ class InverseCache:
     costs a device->host copy = a stream sync; cameras are per-sequence constants, so ``predict`` pays it once per
     (tensor storage, version) and afterwards enqueues without touching the host (include/pfhip.h: calls only enqueue).
     Entries keep the source tensor alive, so a data_ptr can not be recycled for another matrix while it is a key; an
-    in-place edit bumps ``_version`` and misses.  Writes that bypass the version counter (``K.data.copy_``, a custom kernel
-    or the C library writing into a staging tensor, numpy-aliased memory) are caught by content: an entry also keeps a
-    device clone of the matrix it inverted, and a hit is honoured only if the tensor still equals it - one tiny device
-    comparison whose result is read on the host, still far cheaper than the copy + LAPACK call it replaces.  Under stream
-    capture nothing may synchronise: the content check is skipped there (a captured graph bakes in the inverse of the
-    matrices it was captured with anyway)."""
+    in-place edit bumps ``_version`` and misses: a hit on (storage, version, shape, dtype, device) enqueues nothing and
+    waits for nothing.  Writes that bypass the version counter (``K.data.copy_``, a custom kernel or the C library writing
+    into a staging tensor, numpy-aliased memory) are NOT seen by that key; ``verify = True`` (``PF_VERIFY_CAMERA_CACHE=1``
+    in the environment, or ``pc_transform_model._inverse_cache.verify = True``) adds a content check for such callers: an
+    entry keeps a device clone of the matrix it inverted and a hit is honoured only if the tensor still equals it - a
+    device comparison read on the host, i.e. one stream synchronisation per camera tensor per predict (skipped under
+    stream capture, where nothing may synchronise)."""
 
-    def __init__(self, capacity=16):
+    def __init__(self, capacity=16, verify=None):
+        import os
         self.capacity, self._d = capacity, {}
+        self.verify = bool(int(os.environ.get('PF_VERIFY_CAMERA_CACHE', '0'))) if verify is None else bool(verify)
 
     def __call__(self, m):
         key = (m.data_ptr(), m._version, tuple(m.shape), m.dtype, str(m.device))
         hit = self._d.get(key)
         capturing = m.is_cuda and torch.cuda.is_current_stream_capturing()
-        if hit is not None and not capturing and not torch.equal(m, hit[2]):
+        if hit is not None and self.verify and not capturing and not torch.equal(m, hit[2]):
             hit = None               # same storage, same version, other numbers
         if hit is None:
             self._d.pop(key, None)

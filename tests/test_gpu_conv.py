@@ -401,7 +401,7 @@ def test_packed_activation_block(h, w, b, nt, wide, force_conv):
     labels = [r['label'] for r in pflib.profile_results()]
     pflib.profile(False)
     assert sum('conv_s4_kernel' in l for l in labels) >= 1, labels
-    assert any('32, 16>' in l for l in labels) == (wide == 2), labels
+    assert any('32, 16, 1>' in l for l in labels) == (wide == 2), labels
     for tag in ('+pool', '+res', 'lowres-half'):
         assert any('conv_s4_1x1_kernel' in l and tag in l for l in labels), (tag, labels)
     ref = _block_ref(x, P, h, w)
@@ -434,13 +434,54 @@ def test_s4_four_cout_tiles(h, w, b, force_conv):
     net = MiniNet(spec, P).run(x.cuda())
     labels = [r['label'] for r in pflib.profile_results()]
     pflib.profile(False)
-    assert any('conv_s4_kernel<4, 32, 8>' in l for l in labels), labels
+    assert any('conv_s4_kernel<4, 32, 8, 1>' in l for l in labels), labels
     D = {k: (v[0].double(), v[1].double()) for k, v in P.items()}
     t0r = F.relu(F.conv2d(x.double(), *D['t0'], padding=1))
     c1r = F.relu(F.conv2d(t0r, *D['c1'], padding=1))
     c2r = F.relu(F.conv2d(torch.cat([c1r, t0r], 1), *D['c2'], padding=1))
     c3r = F.conv2d(c2r, *D['c3'], padding=1)
     for name, r, scale in [('c1', c1r, 1), ('c2', c2r, 2), ('c3', c3r, 3)]:
+        r = r.float()
+        err = (net.tensor(name).cpu() - r).abs().max().item()
+        assert err <= scale * _tol_split(r), (name, err, _tol_split(r))
+    net.close()
+
+
+@pytest.mark.parametrize('nt,ks', [(1, 2), (2, 2), (1, 4), (2, 4)])
+@pytest.mark.parametrize('h,w,b', [(16, 64, 2), (24, 40, 1), (32, 64, 3)])
+def test_s4_k_split(h, w, b, nt, ks, force_conv):
+    """conv_s4_kernel<NT, 32, 8, KS> (the shapes of the small levels: KS = 2 / 4 wave groups of a workgroup split the rounds of
+    one pixel tile and hand their sums over through LDS): layers of 9, 16 and 9 rounds - uneven parts, parts that end early, two
+    input ranges - against float64 torch at the split tolerance; a layer with fewer than 16 (8) rounds falls back to KS = 2 (1)."""
+    from helpers import MiniNet, MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    from panoptic_forecasting_amd import lib as pflib
+    S = arch.Src
+    g = torch.Generator().manual_seed(h + w + nt)
+    x = torch.randn(b, 12, h, w, generator=g) * torch.exp(torch.randn(b, 12, 1, 1, generator=g))
+    spec = MiniSpec(12)
+    t0 = spec.conv('t0', [S(0, 0, 12)], 72, 3)
+    c1 = spec.conv('c1', [S(t0, 0, 72)], 52, 3)
+    c2 = spec.conv('c2', [S(c1, 0, 52), S(t0, 0, 72)], 70, 3)
+    c3 = spec.conv('c3', [S(c2, 0, 70)], 24, 3)
+    spec.conv('c4', [S(c3, 0, 24)], 11, 3, relu=False)
+    shapes = [('t0', 12, 72), ('c1', 72, 52), ('c2', 124, 70), ('c3', 70, 24), ('c4', 24, 11)]
+    P = {n: (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5, torch.randn(co, generator=g)) for n, ci, co in shapes}
+    force_conv(5, nt, 3 if ks == 2 else 4, 0)
+    pflib.profile(True)
+    net = MiniNet(spec, P).run(x.cuda())
+    labels = [r['label'] for r in pflib.profile_results()]
+    pflib.profile(False)
+    assert any('conv_s4_kernel<%d, 32, 8, 2>' % nt in l for l in labels), labels            # c1, c3 (9 rounds); c2 too when KS = 2
+    assert any('conv_s4_kernel<%d, 32, 8, 4>' % nt in l for l in labels) == (ks == 4), labels    # c2: 16 rounds
+    assert any('conv_s4_kernel<1, 32, 8, 1>' in l for l in labels), labels                  # c4: 3 rounds, one cout tile
+    D = {k: (v[0].double(), v[1].double()) for k, v in P.items()}
+    t0r = F.relu(F.conv2d(x.double(), *D['t0'], padding=1))
+    c1r = F.relu(F.conv2d(t0r, *D['c1'], padding=1))
+    c2r = F.relu(F.conv2d(torch.cat([c1r, t0r], 1), *D['c2'], padding=1))
+    c3r = F.relu(F.conv2d(c2r, *D['c3'], padding=1))
+    c4r = F.conv2d(c3r, *D['c4'], padding=1)
+    for name, r, scale in [('c1', c1r, 1), ('c2', c2r, 2), ('c3', c3r, 3), ('c4', c4r, 3)]:
         r = r.float()
         err = (net.tensor(name).cpu() - r).abs().max().item()
         assert err <= scale * _tol_split(r), (name, err, _tol_split(r))

@@ -1,7 +1,8 @@
 """Adversarial cases for the two-term fp16 operand path (conv_split / conv_s4; conv_mfma.h) against float64 torch and the
-oracle: activations far outside O(1) must come out right or be FLAGGED (PF_STATUS_RANGE) - never silently clamped - and a
-cancellation-heavy convolution must stay inside the stated operand bound.  The reference is plain fp32 Conv2d
-(hardnet.py:16-25).  Measured errors are written to gpurun_out/r03_precision.json (copied to profiles/)."""
+oracle: activations far outside O(1) IN EITHER DIRECTION must come out right - to a tolerance relative to the tensor's own
+magnitude - or be FLAGGED (PF_STATUS_RANGE above 65504, PF_STATUS_RANGE_LOW for tensors of tiny values) - never silently
+clamped or flushed - and a cancellation-heavy convolution must stay inside the stated operand bound.  The reference is plain
+fp32 Conv2d (hardnet.py:16-25).  Measured errors are written to gpurun_out/r04_precision.json (copied to profiles/)."""
 import json
 import os
 
@@ -12,7 +13,8 @@ import torch.nn.functional as F
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
-REPORT = os.path.join(ROOT, 'gpurun_out', 'r03_precision.json')
+REPORT = os.path.join(ROOT, 'gpurun_out', 'r04_precision.json')
+RANGE, RANGE_LOW = 1, 2          # include/pfhip.h: PF_STATUS_RANGE, PF_STATUS_RANGE_LOW
 
 
 def _report(key, value):
@@ -27,6 +29,15 @@ def _report(key, value):
 
 
 @pytest.fixture
+def normalize_ranges():
+    """pf_set_option('normalize_ranges', v): read when a plan is created; restored to the default (1) afterwards"""
+    from panoptic_forecasting_amd import lib as pflib
+    L = pflib.load()
+    yield lambda v: pflib.check(L.pf_set_option(b'normalize_ranges', int(v)), 'pf_set_option')
+    L.pf_set_option(b'normalize_ranges', 1)
+
+
+@pytest.fixture
 def force_conv():
     from panoptic_forecasting_amd import lib as pflib
     L = pflib.load()
@@ -34,55 +45,110 @@ def force_conv():
     L.pf_debug_force_conv(0, 0, 0, 0)
 
 
+def _scaled_block(g, scale):
+    """The HarDBlock-shaped net of test_gpu_conv.py with its input AND every bias multiplied by ``scale``: a ReLU network is
+    positively homogeneous, so every activation of the reference is exactly ``scale`` times the unscaled one."""
+    from test_gpu_conv import _block_net
+    spec, P = _block_net(g, 12)
+    return spec, {k: (w, b * scale) for k, (w, b) in P.items()}
+
+
+def _check_block(net, ref, tag, unit=1e-5):
+    """every tapped tensor within k * unit * max|ref| of float64 torch - relative to the TENSOR's magnitude, no '1 +'"""
+    worst = 0.0
+    for name, k in [('t0', 1), ('L2', 1), ('out', 2), ('p', 2), ('c6', 3), ('c7', 3), ('c8', 3)]:
+        r = ref[name].float()
+        mag = r.abs().max().item()
+        err = (net.tensor(name).cpu() - r).abs().max().item()
+        assert err <= k * unit * mag, (tag, name, err, k * unit * mag)
+        worst = max(worst, err / mag)
+    return worst
+
+
 @pytest.mark.parametrize('force', [(5, 2, 0, 0), (4, 2, 0, 0), None], ids=['conv_s4', 'conv_split', 'table'])
-@pytest.mark.parametrize('scale', [1.0, 1e3, 1e5, 3e7])
+@pytest.mark.parametrize('scale', [1e-7, 1e-5, 1e-3, 1.0, 1e3, 1e5, 3e7])
 def test_scaled_activations_through_a_hardblock_are_right_or_flagged(scale, force, force_conv):
-    """The HarDBlock-shaped net of test_gpu_conv.py with its input scaled by 1, 1e3, 1e5, 3e7: activations reach ~5e0 ..
-    ~1e8.  Either every tensor agrees with float64 torch to the split tolerance RELATIVE to its magnitude and the status
-    word is clear, or the status word carries PF_STATUS_RANGE; then the same plan with split_f16 = 0 (fp32 matrix
-    instructions, what BGModel re-runs) must be right and unflagged.  A silently clamped result fails both branches."""
+    """Activations of ~5e-7 .. ~1e8.  Either every tensor agrees with float64 torch to the split tolerance RELATIVE to its
+    own magnitude and the status word is clear, or the status word carries PF_STATUS_RANGE (values beyond 65504) or
+    PF_STATUS_RANGE_LOW (a tensor whose largest value is below 2^-6, where the pair's absolute 2^-25 floor would cost relative
+    precision that fp32 keeps); then the same plan with split_f16 = 0 (fp32 matrix instructions, what BGModel re-runs) must
+    be right and unflagged.  A silently clamped or flushed result fails both branches."""
     from helpers import MiniNet
-    from test_gpu_conv import _block_net, _block_ref
+    from test_gpu_conv import _block_ref
     g = torch.Generator().manual_seed(11)
     b, h, w = 1, 24, 40
     x = torch.randn(b, 12, h, w, generator=g) * scale
-    spec, P = _block_net(g, 12)
+    spec, P = _scaled_block(g, scale)
     if force:
         force_conv(*force)
     ref = _block_ref(x, P, h, w)
     peak = max(r.abs().max().item() for r in ref.values())
     net = MiniNet(spec, P).run(x.cuda())
-    flagged = bool(net.status() & 1)
-
-    def check(tag):
-        worst = 0.0
-        for name, k in [('t0', 1), ('L2', 1), ('out', 2), ('p', 2), ('c6', 3), ('c7', 3), ('c8', 3)]:
-            r = ref[name].float()
-            err = (net.tensor(name).cpu() - r).abs().max().item()
-            tol = k * 2e-5 * (1.0 + r.abs().max().item())
-            assert err <= tol, (tag, name, err, tol)
-            worst = max(worst, err / (1.0 + r.abs().max().item()))
-        return worst
+    status = net.status()
+    flagged = bool(status & (RANGE | RANGE_LOW))
     # (the first conv reads the caller's fp32 input: the dense-input pre-pass has looked at it too)
     if max(peak, x.abs().max().item()) > 65504.0:
-        assert flagged, 'activations up to %g were not flagged' % peak
+        assert status & RANGE, 'activations up to %g were not flagged' % peak
+    if x.abs().max().item() < 2.0 ** -6:
+        assert status & RANGE_LOW, 'an input of at most %g was not flagged' % x.abs().max().item()
     if scale == 1.0:
         assert not flagged
     rel = None
     if not flagged:
-        rel = check('split')
+        rel = _check_block(net, ref, 'split')
     net.set_option('split_f16', 0).run(x.cuda())
-    assert net.status() == 0, 'the fp32-only plan must never raise PF_STATUS_RANGE'
-    rel32 = check('fp32')
+    assert net.status() == 0, 'the fp32-only plan must never raise a range flag'
+    rel32 = _check_block(net, ref, 'fp32')
     _report('hardblock_scale_%g_%s' % (scale, 'table' if not force else 'kind%d' % force[0]),
-            {'peak_activation': peak, 'flagged': flagged, 'max_rel_err_split': rel, 'max_rel_err_fp32_rerun': rel32})
+            {'peak_activation': peak, 'status': status, 'max_rel_err_split': rel, 'max_rel_err_fp32_rerun': rel32})
     net.close()
 
 
-def test_range_flag_catches_a_single_outlier_channel(force_conv):
-    """One output channel with a huge bias pushes ONE value per pixel past 65504 in the middle of the block: flagged."""
+@pytest.mark.parametrize('alpha', [1e-5, 1e-3, 1e3])
+def test_reparameterised_block_runs_on_the_pair_path(alpha, force_conv, normalize_ranges):
+    """The same function with other numbers: the first conv's weights and bias times alpha, every consumer's columns of that
+    tensor divided by alpha.  The reference (fp32) does not care.  With the plan's range normalisation (the stored channel
+    = value * 2^k chosen from the folded weights) the pair path stores what it stores for alpha = 1: unflagged and right
+    relative to each tensor's magnitude, the tiny tensor t0 included.  Without it (normalize_ranges = 0) alpha = 1e-5 is a
+    tensor of ~1e-5 values: it must be FLAGGED (PF_STATUS_RANGE_LOW), never silently short of bits."""
     from helpers import MiniNet
-    from test_gpu_conv import _block_net
+    from test_gpu_conv import _block_net, _block_ref
+    g = torch.Generator().manual_seed(13)
+    b, h, w = 1, 24, 40
+    x = torch.randn(b, 12, h, w, generator=g)
+    spec, P = _block_net(g, 12)
+    P = dict(P)
+    P['t0'] = (P['t0'][0] * alpha, P['t0'][1] * alpha)
+    for name, lo in (('L1', 0), ('L2', 10), ('L4', 28)):       # input columns that read t0 (test_gpu_conv._block_net)
+        wt = P[name][0].clone()
+        wt[:, lo:lo + 20] /= alpha
+        P[name] = (wt, P[name][1])
+    ref = _block_ref(x, P, h, w)
+    force_conv(5, 2, 0, 0)
+    net = MiniNet(spec, P).run(x.cuda())
+    assert net.status() == 0, net.status()
+    rel = _check_block(net, ref, 'normalised')
+    net.close()
+    normalize_ranges(0)
+    raw = MiniNet(spec, P).run(x.cuda())
+    st = raw.status()
+    t0_max = ref['t0'].abs().max().item()
+    if t0_max < 2.0 ** -6:
+        assert st & RANGE_LOW, (st, t0_max)
+    if t0_max > 65504.0:
+        assert st & RANGE, (st, t0_max)
+    rel_raw = _check_block(raw, ref, 'raw') if st == 0 else None
+    raw.close()
+    _report('reparameterised_block_alpha_%g' % alpha, {'t0_max': t0_max, 'max_rel_err_normalised': rel, 'status_without_normalisation': st,
+                                                       'max_rel_err_without_normalisation': rel_raw})
+
+
+def test_range_flag_catches_a_single_outlier_channel(force_conv, normalize_ranges):
+    """One output channel with a huge bias pushes ONE value per pixel past 65504 in the middle of the block.  With the values
+    stored raw (normalize_ranges = 0) that is flagged; with the plan's range normalisation that channel alone is stored times
+    2^-13 or so (its bias is in the plan's estimate of its magnitude): unflagged, and every tensor right relative to its size."""
+    from helpers import MiniNet
+    from test_gpu_conv import _block_net, _block_ref
     g = torch.Generator().manual_seed(12)
     x = torch.randn(1, 12, 16, 64, generator=g)
     spec, P = _block_net(g, 12)
@@ -95,7 +161,12 @@ def test_range_flag_catches_a_single_outlier_channel(force_conv):
     bias[7] = 7e4
     P['L2'] = (w, bias)
     net = MiniNet(spec, P).run(x.cuda())
-    assert net.status() & 1
+    assert net.status() == 0
+    _check_block(net, _block_ref(x, P, 16, 64), 'outlier channel, normalised')
+    net.close()
+    normalize_ranges(0)
+    net = MiniNet(spec, P).run(x.cuda())
+    assert net.status() & RANGE
     net.close()
 
 
@@ -170,7 +241,7 @@ def test_whole_network_out_of_range_checkpoint_reruns_in_fp32_or_raises():
     cuda_inp = {k: v.cuda() for k, v in inp.items()}
     ok = build_model(_bg_params(h, w, 15.0))
     ok.load_state_dict(sd)
-    ok.predict(cuda_inp, None)
+    ok.predict(cuda_inp, None)['seg']        # (first access of a result = the range check of its forward)
     assert ok.bg.range_reruns == 0 and ok.bg.range_status() == 0
 
     sd_bad = dict(sd)
@@ -178,6 +249,8 @@ def test_whole_network_out_of_range_checkpoint_reruns_in_fp32_or_raises():
     m = build_model(_bg_params(h, w, 2e-4))
     m.load_state_dict(sd_bad)
     out = m.predict(cuda_inp, None)
+    assert m.bg.range_reruns == 0            # predict() only enqueued: nothing has been waited for
+    out['seg']
     assert m.bg.range_reruns == 1
     ref, _, _ = t.oracle_pipeline(sd_bad, inp, h, w)
     scale = ref['orig_size_logits'].abs().max().item()
@@ -189,18 +262,21 @@ def test_whole_network_out_of_range_checkpoint_reruns_in_fp32_or_raises():
     r = build_model(_bg_params(h, w, 2e-4, on_range_overflow='raise'))
     r.load_state_dict(sd_bad)
     with pytest.raises(pflib.PfError, match='65504'):
-        r.predict(cuda_inp, None)
+        r.predict(cuda_inp, None)['seg']
     i = build_model(_bg_params(h, w, 2e-4, on_range_overflow='ignore'))
     i.load_state_dict(sd_bad)
-    i.predict(cuda_inp, None)
-    assert i.bg.range_status() & 1 and i.bg.range_reruns == 0
+    i.predict(cuda_inp, None)['seg']
+    assert i.bg.range_status() & RANGE and i.bg.range_reruns == 0
+    assert i.bg.range_status_sticky(clear=True) & RANGE and i.bg.range_status_sticky() == 0
 
 
-def test_overflow_inside_the_fused_front_end_is_flagged():
+def test_overflow_inside_the_fused_front_end_is_flagged(normalize_ranges):
     """base.1's output never leaves LDS in conv_front.hip - it is still a tensor a split kernel reads (base.2, inside the same
     kernel), so its producer must guard it: with base.1's BatchNorm affine scaled by 1e5 the stem output stays in range and the
-    overflow arises INSIDE the fused kernel.  Default policy: one re-run on the fp32 matrix instructions, result = oracle;
-    'ignore': the status word carries the flag and the fused kernel is what ran."""
+    overflow arises INSIDE the fused kernel.  Without the plan's range normalisation: default policy = one re-run on the fp32
+    matrix instructions, result = oracle; 'ignore': the status word carries the flag and the fused kernel is what ran.  With
+    the normalisation (the default) the 1e5 is absorbed into the stored channels' powers of two: no flag, no re-run, and the
+    pair path itself returns the oracle's logits."""
     import test_gpu_bg_forecast as t
     from panoptic_forecasting_amd import lib as pflib
     from panoptic_forecasting_amd import synth
@@ -212,20 +288,117 @@ def test_overflow_inside_the_fused_front_end_is_flagged():
         sd[k] = sd[k] * 1e5
     inp = synth.make_inputs(b=1, h=h, w=w, seed=6, gap_len=3)
     cuda_inp = {k: v.cuda() for k, v in inp.items()}
+    ref, _, _ = t.oracle_pipeline(sd, inp, h, w)
+    scale = ref['orig_size_logits'].abs().max().item()
+
+    n = build_model(_bg_params(h, w, 15.0))
+    n.load_state_dict(sd)
+    out = n.predict(cuda_inp, None)
+    err_n = (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max().item()
+    assert n.bg.range_reruns == 0 and n.bg.range_status() == 0
+    assert err_n <= 1e-4 * scale, (err_n, scale)
+
+    normalize_ranges(0)
     i = build_model(_bg_params(h, w, 15.0, on_range_overflow='ignore'))
     i.load_state_dict(sd)
     pflib.profile(True)
-    i.predict(cuda_inp, None)
+    i.predict(cuda_inp, None)['seg']
     labels = [r['label'] for r in pflib.profile_results()]
     pflib.profile(False)
     assert any('conv_front' in l for l in labels), labels
-    assert i.bg.range_status() & 1 and i.bg.range_reruns == 0
+    assert i.bg.range_status() & RANGE and i.bg.range_reruns == 0
     m = build_model(_bg_params(h, w, 15.0))
     m.load_state_dict(sd)
     out = m.predict(cuda_inp, None)
-    assert m.bg.range_reruns == 1
-    ref, _, _ = t.oracle_pipeline(sd, inp, h, w)
-    scale = ref['orig_size_logits'].abs().max().item()
     err = (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max().item()
-    assert err <= 1e-4 * (1.0 + scale), (err, scale)
-    _report('overflow_inside_conv_front', {'max_abs_logit': scale, 'err_after_fp32_rerun': err, 'reruns': m.bg.range_reruns})
+    assert m.bg.range_reruns == 1
+    assert err <= 1e-4 * scale, (err, scale)
+    _report('overflow_inside_conv_front', {'max_abs_logit': scale, 'err_after_fp32_rerun': err, 'reruns': m.bg.range_reruns,
+                                           'err_normalised_pair_path': err_n})
+
+
+def _reparameterise(sd, producer, alpha):
+    """(gamma, beta) of ``producer``'s BatchNorm times alpha, the input columns of every conv that reads its output divided by
+    alpha: the same function for the reference (hardnet.py:16-25, ReLU commutes with a positive factor)."""
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    sd = dict(sd)
+    for k in ('model.%s.norm.weight' % producer, 'model.%s.norm.bias' % producer):
+        sd[k] = sd[k] * alpha
+    spec = arch.Spec(36, 11)
+    src_t = next(op.dst for op in spec.ops if op.name == producer)
+    hit = []
+    for op in spec.conv_ops():
+        off = 0
+        for s_ in op.srcs:
+            if s_.tensor == src_t:
+                key = 'model.%s.conv.weight' % op.name
+                wt = sd[key].clone()
+                wt[:, off:off + s_.ch] /= alpha
+                sd[key] = wt
+                hit.append(op.name)
+            off += s_.ch
+    assert hit, producer
+    return sd, hit
+
+
+@pytest.mark.parametrize('alpha', [1e-5, 1e5])
+def test_reparameterised_checkpoint_gives_the_oracles_logits(alpha, normalize_ranges):
+    """model.base.3's BatchNorm times alpha and its consumers' weights divided by alpha: the same function, so the logits must
+    equal the oracle's (torch fp32 on the CPU, run on the SAME re-parameterised checkpoint) to 1e-4 - on the fp16-pair path
+    itself with the plan's range normalisation (no flag, no re-run), and through a flagged fp32 re-run without it."""
+    import test_gpu_bg_forecast as t
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.registry import build_model
+    h, w = 128, 256
+    sd, hit = _reparameterise(t._sd(), 'base.3', alpha)
+    inp = synth.make_inputs(b=1, h=h, w=w, seed=7, gap_len=3)
+    cuda_inp = {k: v.cuda() for k, v in inp.items()}
+    ref, _, _ = t.oracle_pipeline(sd, inp, h, w)
+    plain, _, _ = t.oracle_pipeline(dict(t._sd()), inp, h, w)
+    assert (ref['orig_size_logits'] - plain['orig_size_logits']).abs().max().item() < 1e-3      # the same function indeed
+    m = build_model(_bg_params(h, w, 15.0))
+    m.load_state_dict(sd)
+    out = m.predict(cuda_inp, None)
+    err = (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max().item()
+    assert m.bg.range_reruns == 0 and m.bg.range_status() == 0
+    assert err <= 1e-4, err
+    assert (out['seg'].cpu().long() == ref['seg']).float().mean().item() >= 0.999
+    normalize_ranges(0)
+    r = build_model(_bg_params(h, w, 15.0))
+    r.load_state_dict(sd)
+    out_r = r.predict(cuda_inp, None)
+    err_r = (out_r['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max().item()
+    st = r.bg.range_status_sticky()
+    assert st & (RANGE_LOW if alpha < 1 else RANGE), st
+    assert r.bg.range_reruns == 1
+    assert err_r <= 1e-4, err_r
+    _report('reparameterised_base3_alpha_%g' % alpha, {'consumers': hit, 'err_pair_path_normalised': err, 'status_without_normalisation': st,
+                                                      'err_after_fp32_rerun_without_normalisation': err_r})
+
+
+def test_predict_is_asynchronous_and_a_late_check_still_reruns():
+    """predict() only enqueues: two forwards are issued back to back, the first one (an out-of-range checkpoint) is found
+    flagged when ITS result is first touched - after the second forward was already enqueued behind it - and is re-run into
+    the same output tensors."""
+    import test_gpu_bg_forecast as t
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.registry import build_model
+    h, w = 128, 256
+    sd_bad = dict(t._sd())
+    sd_bad['depth_std'] = torch.tensor([2e-4])
+    m = build_model(_bg_params(h, w, 2e-4))
+    m.load_state_dict(sd_bad)
+    inp = [synth.make_inputs(b=1, h=h, w=w, seed=s_, gap_len=3) for s_ in (5, 8)]
+    cuda = [{k: v.cuda() for k, v in i.items()} for i in inp]
+    m.predict(cuda[0], None)['seg']              # warm-up: plan, workspace
+    n0 = m.bg.range_reruns
+    a = m.predict(cuda[0], None)
+    b = m.predict(cuda[1], None)
+    assert list(a.keys()) and m.bg.range_reruns <= n0 + 1     # (the second predict may already have settled the first)
+    ra, _, _ = t.oracle_pipeline(sd_bad, inp[0], h, w)
+    rb, _, _ = t.oracle_pipeline(sd_bad, inp[1], h, w)
+    for out, ref in ((a, ra), (b, rb)):
+        scale = ref['orig_size_logits'].abs().max().item()
+        err = (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max().item()
+        assert err <= 1e-4 * scale, (err, scale)
+    assert m.bg.range_reruns == n0 + 2

@@ -22,31 +22,37 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--size', type=int, default=800)
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--no-graph', action='store_true', help='enqueue every step kernel by kernel (training.use_hip_graph = False)')
     ap.add_argument('--out', default='', help='also write the JSON line here')
     a = ap.parse_args()
     params = {'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])]},
               'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True},
-              'training': {'lr': 2e-3, 'mom': 0.9, 'wd': 1e-4, 'clip_grad_norm': 5.0}}
+              'training': {'lr': 2e-3, 'mom': 0.9, 'wd': 1e-4, 'clip_grad_norm': 5.0, 'use_hip_graph': not a.no_graph}}
     tr = BGTrainer(params)
     tr.load_state_dict(synth.make_state_dict(seed=1234))
     inp = {k: v.cuda() for k, v in synth.make_bg_inputs(b=a.batch, h=a.size, w=a.size, seed=1).items()}
     inp['seg'] = inp['seg'].to(torch.uint8)
     lab = {'seg': torch.randint(0, 11, (a.batch, a.size, a.size), dtype=torch.uint8, device='cuda')}
-    tr.train_step(inp, lab)
+    for _ in range(3):          # the first step of a configuration runs eagerly, the second captures the hipGraph
+        tr.train_step(inp, lab)
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(a.steps):
         out = tr.train_step(inp, lab)
     torch.cuda.synchronize()
     ms = (time.time() - t0) / a.steps * 1e3
+    graph = tr.use_graph
+    tr.use_graph = False        # the per-kernel records need eager launches (hipEvents around every kernel)
     pflib.profile(True)
     tr.train_step(inp, lab)
     torch.cuda.synchronize()
     recs = pflib.profile_results()
     pflib.profile(False)
+    tr.use_graph = graph
     top = sorted(recs, key=lambda r: -r['ms'])
     line = {'ms_per_step': ms, 'samples_per_s': a.batch / ms * 1e3, 'batch': a.batch, 'size': a.size, 'loss': float(out['loss']),
+            'launch': 'hipGraph replay of forward + loss + backward, eager SGD step' if graph else 'eager', 'steps': a.steps,
             'workspace_GB': tr._ws.numel() / 1e9, 'kernel_ms_sum': sum(r['ms'] for r in recs),
             'profiled_kernels': {r['label'][:70]: {'ms': round(r['ms'], 3), 'launches': r['launches'],
                                                    'TFLOPs': round(r['flops'] / max(r['ms'], 1e-9) / 1e9, 1),

@@ -25,7 +25,7 @@ pflib.check(L.pf_set_option(b'profile_tag_ops', 1), 'pf_set_option')   # per-op 
 model = build_model(bench.model_params())
 model.load_state_dict(bench.calibrated_state_dict())
 batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
-CONFIGS = [(0, 0, 0, 0)] + [(5, nt, wd, 0) for nt in (1, 2, 3, 4) for wd in (0, 1)] + [(5, 1, 2, 0), (5, 2, 2, 0)]   # wd 2: 16x32 tiles, 8 waves
+CONFIGS = [(0, 0, 0, 0)] + [(5, nt, wd, 0) for nt in (1, 2, 3, 4) for wd in (0, 1)] + [(5, 1, 2, 0), (5, 2, 2, 0), (5, 1, 3, 0), (5, 2, 3, 0), (5, 1, 4, 0), (5, 2, 4, 0)]   # wd 2: 16x32 tiles, 8 waves; wd 3 / 4: 8x32 tiles, K split over two / four wave groups
 
 
 def run(cfg):
@@ -85,7 +85,7 @@ if args.emit:
             if key in seen:
                 continue
             seen.add(key)
-            nt, wide = nums[0], (2 if ks == 3 and len(nums) > 2 and nums[2] == 16 else 1 if ks == 3 and nums[1] == 64 else 0)
+            nt, wide = nums[0], (4 if ks == 3 and len(nums) > 3 and nums[3] == 4 else 3 if ks == 3 and len(nums) > 3 and nums[3] == 2 else 2 if ks == 3 and len(nums) > 2 and nums[2] == 16 else 1 if ks == 3 and nums[1] == 64 else 0)
             # keep = 0: the non-S4 kernel the table picks was faster in situ (mixed formats are decided by the plan's fixpoint)
             keep = 1 if ('conv_s4' in auto[1] or us < 0.98 * auto[0]) else 0
             f.write('    {%d, %d, %d, %d, %d, %d, {%d, %d, %d, 0}},   // %s: auto %.1f (%s) -> %.1f us\n'
