@@ -192,7 +192,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
         return t == input ? const_cast<float *>(dense_x) : reinterpret_cast<float *>((char *)ws + off[t]);
     };
 
-    const bool tag_ops = p->opt_tag_ops != 0;     // option "profile_tag_ops": per-op labels in pf_profile_* records (tools/)
+    const bool tag_ops = p->opt_tag_ops != 0 || g_opt_tag_ops != 0;   // option "profile_tag_ops" (per plan, or process-wide for tools that switch it on late): per-op labels in pf_profile_* records
     const bool fuse = p->opt_fuse_pool != 0;      // option "fuse_pool"
     // range guard of the two-term operand split (conv_mfma.h): producers of tensors a split kernel may read raise
     // PF_STATUS_RANGE in the live status word and report their max |v| to their op's slot; the forward ends with range_finalize

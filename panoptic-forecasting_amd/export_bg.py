@@ -48,6 +48,9 @@ EXTRA_FLAGS = (
     # not reference flags:
     ('--synthetic', dict(type=int, default=0, help='export N synthetic samples instead of a dataset')),
     ('--dataset', dict(default='reference', choices=['reference'])),
+    ('--dry_run', dict(action='store_true', help='with --synthetic: no model and no GPU - every rank writes a constant placeholder map '
+                                                 'per sample of its shard (gloo rendezvous), then the barrier and the fill of missing frames '
+                                                 'run as in a real export: a check of the driver\'s sharding, never a prediction')),
 )
 
 
@@ -64,7 +67,8 @@ class SyntheticDataset(torch.utils.data.Dataset):
     """N samples shaped like the reference datasets' items ({'inputs','labels','meta'}) for the task at hand."""
 
     def __init__(self, params, n, split='val'):
-        self.n, self.split, self.task = n, split, params['task']
+        self.n, self.split, self.task = n, split, params.get('task')
+        self.dry = bool(params.get('dry_run'))
         mp = params.get('model', {})
         self.h, self.w = mp.get('final_h') or 1024, mp.get('final_w') or 2048
         gaps = params.get('data', {}).get('gap_len', 3)
@@ -74,12 +78,18 @@ class SyntheticDataset(torch.utils.data.Dataset):
         return self.n
 
     def __getitem__(self, i):
+        meta = {'city': 'synth', 'seq': '%06d' % i, 'frame': 19, 'target_frame': 19}
+        if self.dry:
+            # a dry run carries no tensors; rank r takes r x 0.2 s per sample, so that ranks finish their shards at different
+            # times and a fill of missing frames that did not wait for the barrier would count the slower rank's frames
+            import time
+            time.sleep(0.2 * pfdist.env_rank()[0])
+            return {'inputs': {}, 'labels': {}, 'meta': meta}
         if self.task == 'bg':
             inp = synth.make_bg_inputs(b=1, h=self.h, w=self.w, seed=i)
         else:
             inp = synth.make_inputs(b=1, h=self.h, w=self.w, seed=i, gap_len=self.gap, predicted=self.gap > 3)
         inp = {k: v[0] for k, v in inp.items()}
-        meta = {'city': 'synth', 'seq': '%06d' % i, 'frame': 19, 'target_frame': 19}
         return {'inputs': inp, 'labels': {}, 'meta': meta}
 
 
@@ -102,6 +112,18 @@ def build_datasets(params):
     return data, params.get('collate_fn')
 
 
+def dry_write(meta, base):
+    """--dry_run: a constant 8x16 placeholder map under the name a real export would give the sample's prediction."""
+    import numpy as np
+    written = []
+    for city, seq, target in zip(meta['city'], meta['seq'], meta['target_frame']):
+        os.makedirs(os.path.join(base, city), exist_ok=True)
+        path = os.path.join(base, city, hop_io.LABEL_PNG % (city, seq, int(target)))
+        hop_io.write_png(path, np.full((8, 16), int(seq) % 19, np.uint8))
+        written.append(path)
+    return written
+
+
 def export_split(model, dataset, split, params, collate_fn):
     if params.get('viz') or params.get('save_disp_as_png'):
         raise SystemExit('export_bg: --viz / --save_disp_as_png are visualisation branches of the reference; not built here')
@@ -117,6 +139,9 @@ def export_split(model, dataset, split, params, collate_fn):
                                          num_workers=tr.get('num_data_workers', 0), pin_memory=False)
     written = []
     for batch in loader:
+        if params.get('dry_run'):
+            written += dry_write(batch['meta'], base)
+            continue
         inputs = batch['inputs'] if params.get('no_gpu') else to_device(batch['inputs'])
         with torch.no_grad():
             preds = model.predict(inputs, batch.get('labels'))
@@ -131,7 +156,7 @@ def export_split(model, dataset, split, params, collate_fn):
     if params.get('is_img'):
         return written
     cs_dir = params.get('data', {}).get('cityscapes_dir')
-    if cs_dir is None or params.get('synthetic'):
+    if cs_dir is None or (params.get('synthetic') and not params.get('dry_run')):
         print('DID NOT RECEIVE CITYSCAPES DIR. SKIPPING.')
         return written
     if rank == 0:
@@ -146,12 +171,17 @@ def export_split(model, dataset, split, params, collate_fn):
 def main(argv=None):
     params = pfconfig.load_config(EXTRA_FLAGS, argv)
     torch.manual_seed(params['seed'])
-    rank, world, local = pfdist.init_distributed_mode()
-    if not params.get('no_gpu'):
+    dry = bool(params.get('dry_run'))
+    if dry and not params.get('synthetic'):
+        raise SystemExit('export_bg: --dry_run writes placeholders, it needs --synthetic N')
+    rank, world, local = pfdist.init_distributed_mode(backend='gloo' if dry else None)
+    if not params.get('no_gpu') and not dry:
         torch.cuda.set_device(local)
     data, collate_fn = build_datasets(params)
-    model = build_model(params)
-    model.eval()
+    model = None
+    if not dry:
+        model = build_model(params)
+        model.eval()
     written = []
     for split, dataset in data.items():
         written += export_split(model, dataset, split, params, collate_fn)

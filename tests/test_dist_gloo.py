@@ -94,3 +94,35 @@ def test_bench_refuses_more_ranks_than_gpus():
     r, line = _run_bench('--gpus', '2')
     assert r.returncode != 0 and line is None
     assert 'GPU(s)' in r.stderr
+
+
+def test_export_driver_two_ranks_shard_then_barrier_then_fill(tmp_path):
+    """`export_bg.py --synthetic 5 --dry_run` under two gloo ranks (torch.distributed.run, as scripts/bg/run_export_bg_val.sh would
+    be started on a node): the samples are sharded round-robin, every rank writes its own frames, ALL ranks take the barrier
+    and only then does rank 0 fill the ground-truth frames nobody predicted (export_cityscapes_segmentation_results.py:129-165).
+    Rank 1 is slower by construction: without the barrier rank 0 would count its frames as missing."""
+    import glob
+    import subprocess
+    import numpy as np
+    from panoptic_forecasting_amd import hop_io
+    gt = tmp_path / 'cs' / 'gtFine' / 'val' / 'synth'
+    gt.mkdir(parents=True)
+    for i in range(7):                      # 7 ground-truth frames, 5 of them predicted
+        hop_io.write_png(str(gt / (hop_io.LABEL_PNG % ('synth', '%06d' % i, 19))), np.zeros((8, 16), np.uint8))
+    wd = tmp_path / 'work'
+    wd.mkdir()
+    e = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'panoptic-forecasting_amd', 'export_bg.py'),
+           '--working_dir', str(wd), '--synthetic', '5', '--dry_run', '--no_convert', '--no_gpu',
+           '--extra_args', 'data.cityscapes_dir', str(tmp_path / 'cs'), '--extra_args', 'data.data_splits', '[val]',
+           '--extra_args', 'task', 'bg_forecast', '--extra_args', 'training.batch_size', '1']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert 'NUM MISSING:  2' in r.stdout, r.stdout[-2000:]
+    files = sorted(glob.glob(str(wd / 'exported_predictions' / 'val' / 'synth' / '*.png')))
+    assert len(files) == 7, files
+    vals = [int(hop_io.read_png(f).max()) for f in files]
+    assert vals == [0, 1, 2, 3, 4, 255, 255], vals      # both ranks' placeholders are intact, the two unpredicted frames got the fill value

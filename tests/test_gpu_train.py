@@ -114,7 +114,15 @@ def test_forward_backward_vs_oracle(size):
     got = tr.named_grads()
     dist = {k: _rel(got[k].cpu(), g) for k, g in g64.items()}
     _record_grad_distances('%dx%d' % size, dist, {k: _rel(ref['grads'][k], g) for k, g in g64.items()})
+    aten = {k: _rel(ref['grads'][k], g) for k, g in g64.items()}
+    aten_med = sorted(aten.values())[len(aten) // 2]
     for k, g in g64.items():
+        # two criteria.  The correctness criterion is INDEPENDENT of this implementation: the HIP gradient may be at most twice as
+        # far from float64 as the reference's own fp32 (ATen) gradient of that tensor is - or as ATen's median tensor, for the
+        # few tensors where ATen happens to land within 1e-5 (measured: HIP / max(ATen, median) <= 0.95 at both sizes,
+        # profiles/r03_train_grad_dist.json).  The per-tensor bars measured on this implementation (train_grad_bars.json)
+        # stay as a regression tripwire
+        assert dist[k] <= max(2.0 * max(aten[k], aten_med), 1e-4), (k, dist[k], aten[k], aten_med)
         assert dist[k] <= bars[k], (k, dist[k], bars[k])
     # the last block is well conditioned at the level of the head: tight bar there
     for k in ('model.finalConv.weight', 'model.finalConv.bias', 'model.denseBlocksUp.3.layers.3.norm.weight'):

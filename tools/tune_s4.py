@@ -17,7 +17,8 @@ from panoptic_forecasting_amd.registry import build_model  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=16)
-ap.add_argument('--steps', type=int, default=3)
+ap.add_argument('--steps', type=int, default=5)
+ap.add_argument('--margin', type=float, default=0.03, help='a challenger shape replaces the shape the current table runs only if it is this much faster (run-to-run noise is 1-3 %%)')
 ap.add_argument('--emit', default=None, help='append the conv_s4 winners as C table rows to this .inc file')
 args = ap.parse_args()
 L = pflib.load()
@@ -63,6 +64,10 @@ for tag in sorted(table):
             nums = [int(x) for x in re.findall(r'-?\d+', kern.split('<', 1)[1].split('>')[0])]
             s4.setdefault(kern.split('>')[0] + '>', []).append(us)     # the shape that actually ran
     best = min(s4.items(), key=lambda kv: min(kv[1])) if s4 else ('-', [auto[0]])
+    # hysteresis: the shape the current table already runs stays unless a challenger beats it by the margin
+    inc = auto[1].split('>')[0] + '>' if 'conv_s4' in auto[1] else None
+    if s4 and inc in s4 and min(best[1]) > (1.0 - args.margin) * min(min(s4[inc]), auto[0]):
+        best = (inc, [min(min(s4[inc]), auto[0])])
     tot_auto += auto[0]
     tot_best += min(min(best[1]), auto[0])
     if s4:
