@@ -37,9 +37,6 @@
 #ifndef PF_PROBE
 #define PF_PROBE 0
 #endif
-#ifndef S4_EXP   // timing experiments (profiles/r04_experiments.md): 1 / 2 = fewer pixel-fragment reads, 3 = one product of three; never shipped
-#define S4_EXP 0
-#endif
 #if PF_PROBE   // shader-clock stamps of one workgroup in the middle of the grid (tools/probe_s4.py)
 #define S4_PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2 && a.probe && (i) < 60) a.probe[i] = clock64(); } while (0)
 #else
@@ -269,21 +266,17 @@ __global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ ==
         };
         // the three products of one block of weights with 4 M-tiles; `slot0` numbers the MFMA groups for the DMA parts
         auto mfmas = [&](const s4_h8 (&wh)[NT], const s4_h8 (&wm)[NT], int m0, const s4_h8 (&fh)[4], const s4_h8 (&fm)[4], int slot0, bool dma) {
-#if S4_EXP != 3
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc[m0 + m][n] = PF_MFMA_SPLIT(wh[n], fm[m], acc[m0 + m][n]);
-#endif
             if (dma) issue_slot(round, more, slot0 + 0);
-#if S4_EXP != 3
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc[m0 + m][n] = PF_MFMA_SPLIT(wm[n], fh[m], acc[m0 + m][n]);
-#endif
             if (dma) issue_slot(round, more, slot0 + 1);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -301,21 +294,11 @@ __global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ ==
             }
             mfmas(wh, wm, m0, fh, fm, slot0, dma);
         };
-#if S4_EXP == 1 || S4_EXP == 2     // timing-only builds (wrong results): fragment reads of the second instruction / of every round but the first skipped
-        s4_h8 fh[4], fm[4];
-#endif
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int hf = 0; hf < HALVES; ++hf) {
-#if !(S4_EXP == 1 || S4_EXP == 2)
                 s4_h8 fh[4], fm[4];
-#endif
-#if S4_EXP == 1
-                if (s == 0)
-#elif S4_EXP == 2
-                if (s == 0 && round == r_begin)
-#endif
 #pragma unroll
                 for (int m = 0; m < 4; ++m) frag(ab + aoff[s] + mtile_off(hf * 4 + m), fh[m], fm[m]);
                 products(s, hf * 4, fh, fm, 3 * (s * HALVES + hf), true);
