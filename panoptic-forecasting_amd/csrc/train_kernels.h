@@ -15,6 +15,21 @@ int launch_pack_weights(const float *w, int cin_f, int cout_f, const ConvTiling 
 size_t tiled_packed_floats(const int *src_ch, int n_src, int cout, int ks, int stride);
 int launch_pack_weights_tiled(const float *w, int cin_f, int cout_f, int ks, int stride, const int *src_ch, int n_src, int transpose_flip,
                               int c0, int ch, float *out, hipStream_t s);
+// the same packings for a whole training step in ceil(n / kPackBatch) launches: jobs as kernel arguments
+constexpr int kPackBatch = 24;
+struct PackJob {
+    long long w_off, out_off, total;   // floats: weights inside theta, packing inside the arena, packed size
+    int cin_f, cout_f, ks2, kc, tflip, c0, ch, n_src, block0;
+    int cstart[kConvMaxSrc + 1], chunk0[kConvMaxSrc + 1];
+};
+struct PackBatch {
+    int n;
+    PackJob job[kPackBatch];
+};
+static_assert(sizeof(PackBatch) <= 3584, "PackBatch travels as kernel arguments");
+void pack_job_fill(PackJob &q, size_t w_off, int cin_f, int cout_f, int ks, int stride, const int *src_ch, int n_src, int transpose_flip, int c0,
+                   int ch, size_t out_off);
+int launch_pack_weights_batch(const float *theta, float *arena, const PackJob *jobs, int n, hipStream_t s);
 size_t bn_partial_doubles(int C);
 int launch_bn_forward(const float *y, int B, int C, int H, int W, float eps, float momentum, const float *gamma, const float *beta,
                       float *running_mean, float *running_var, float *mean, float *invstd, double *partial, float *dst, int dst_ctotal,

@@ -71,6 +71,12 @@ struct TLayout {
     size_t dy = 0, wpk = 0, wpart = 0, dfull = 0, cepart = 0, bnpart = 0, sums = 0, out3 = 0, total = 0;
     size_t pad_in = 0, pad_out = 0;    // odd-width convs: gathered input / result with the row pitch rounded up to 4
     size_t grad_begin = 0, grad_end = 0;
+    // every tiled weight packing of the step (forward convs in op order, then the backward-data convs of every op and input
+    // range in op order): packed by ONE batch of launches at the start of the step into wpk_arena
+    std::vector<PackJob> jobs;
+    std::vector<int> fwd_job;                  // per op: its forward job, or -1
+    std::vector<std::vector<int>> bwd_job;     // per op, per input range: its backward-data job, or -1 (the network input needs none)
+    size_t wpk_arena = 0;
 };
 
 TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_h, int out_w) {
@@ -131,6 +137,42 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
         const size_t wp = wgrad_partial_floats((int)o.cout, (int)o.cin, (int)o.k, B, out.h, wpi, wpo);
         max_wpart = wp > max_wpart ? wp : max_wpart;
         max_c = o.cout > max_c ? o.cout : max_c;
+    }
+    // the step's packing jobs (the padded copies of odd-width levels read ONE gathered range)
+    {
+        const uint32_t input_t = p->ops[0].src[0].tensor;
+        L.fwd_job.assign(p->ops.size(), -1);
+        L.bwd_job.assign(p->ops.size(), std::vector<int>());
+        size_t arena = 0;
+        auto add = [&](size_t w_off, int cin_f, int cout_f, int ks, int stride, const int *chs, int ns, int tflip, int c0, int ch) {
+            PackJob q;
+            pack_job_fill(q, w_off, cin_f, cout_f, ks, stride, chs, ns, tflip, c0, ch, arena);
+            arena += align_up((size_t)q.total, 64);
+            L.jobs.push_back(q);
+            return (int)L.jobs.size() - 1;
+        };
+        for (size_t i = 0; i < p->ops.size(); ++i) {
+            const BlobOp &o = p->ops[i];
+            if (o.kind != OP_STEM && o.kind != OP_CONV) continue;
+            const TDims in = d[o.src[0].tensor];
+            int src_ch[kMaxSrc];
+            for (uint32_t j = 0; j < o.n_src; ++j) src_ch[j] = (int)o.src[j].ch;
+            const int one = (int)o.cin;
+            const bool aligned = (in.w & 3) == 0;
+            L.fwd_job[i] = add(p->w_off[i], (int)o.cin, (int)o.cout, (int)o.k, (int)o.stride, aligned ? src_ch : &one, aligned ? (int)o.n_src : 1, 0, 0, 0);
+        }
+        for (size_t i = 0; i < p->ops.size(); ++i) {
+            const BlobOp &o = p->ops[i];
+            if (o.kind != OP_STEM && o.kind != OP_CONV) continue;
+            L.bwd_job[i].assign(o.n_src, -1);
+            int c0 = 0;
+            const int dy_ch = (int)o.cout;
+            for (uint32_t j = 0; j < o.n_src; ++j) {
+                if (o.src[j].tensor != input_t) L.bwd_job[i][j] = add(p->w_off[i], (int)o.cin, (int)o.cout, (int)o.k, 1, &dy_ch, 1, 1, c0, (int)o.src[j].ch);
+                c0 += (int)o.src[j].ch;
+            }
+        }
+        L.wpk_arena = take(arena * sizeof(float) + 256);
     }
     L.dy = take(max_dy + 256);
     L.wpk = take(max_wpk * sizeof(float));
@@ -285,6 +327,8 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
         if (T * (n_cls + 1) != in_ch) return fail(PF_EINVAL, "T=%d frames x (%d classes + depth) != %d input channels", T, n_cls, in_ch);
         if ((rc = launch_onehot_dense(seg, seg_is_i64, depth, depth_mask, depth_mean, depth_std, B, T, n_cls, H, W, act(input), s))) return rc;
     }
+    float *wpk_arena = reinterpret_cast<float *>(wsb + L.wpk_arena);
+    if ((rc = launch_pack_weights_batch(theta, wpk_arena, L.jobs.data(), (int)L.jobs.size(), s))) return rc;   // theta does not move inside this call
     PF_HIP_CHECK(hipMemsetAsync(wsb + L.grad_begin, 0, L.grad_end - L.grad_begin, s));
     if (!accumulate_grads) PF_HIP_CHECK(hipMemsetAsync(grad, 0, p->n_params * sizeof(float), s));
 
@@ -310,14 +354,19 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
 
     // one convolution: a = sources / destination / shapes filled, weights = OIHW in theta.  fwd: the op's own conv (input
     // ranges src_ch); else the backward-data conv of forward input range [c0, c0 + ch) (one range: the cout_f channels of dy)
+    // job: the conv's entry in L.jobs (its tiled packing is already in the arena), or -1
     auto run_conv = [&](ConvArgs &a, int ks, int stride, const float *w, int cin_f, int cout_f, const int *src_ch, int n_src, int tflip, int c0,
-                        int ch) -> int {
+                        int ch, int job) -> int {
         int rc2 = PF_EUNSUPPORTED;
         auto fast = [&](ConvArgs &c, const int *chs, int ns) -> int {
-            int r2 = launch_pack_weights_tiled(w, cin_f, cout_f, ks, stride, chs, ns, tflip, c0, ch, wpk, s);
-            if (r2) return r2;
+            if (job >= 0 && L.jobs[job].n_src == ns) {
+                c.wpk = wpk_arena + L.jobs[job].out_off;
+            } else {
+                int r2 = launch_pack_weights_tiled(w, cin_f, cout_f, ks, stride, chs, ns, tflip, c0, ch, wpk, s);
+                if (r2) return r2;
+                c.wpk = wpk;
+            }
             const int kc = dma_kc(ks, stride);
-            c.wpk = wpk;
             c.src_chunk0[0] = 0;
             for (int j = 0; j < kConvMaxSrc; ++j) c.src_chunk0[j + 1] = c.src_chunk0[j] + (j < ns ? (chs[j] + kc - 1) / kc : 0);
             c.nchunks = c.src_chunk0[ns];
@@ -366,7 +415,7 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
             if (p->bn[i]) {
                 float *y = reinterpret_cast<float *>(wsb + L.ypre[i]);
                 a.dst = y; a.dst_ctotal = (int)o.cout; a.dst_choff = 0; a.relu = 0;
-                if ((rc = run_conv(a, (int)o.k, (int)o.stride, theta + p->w_off[i], (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, 0, 0, 0))) return rc;
+                if ((rc = run_conv(a, (int)o.k, (int)o.stride, theta + p->w_off[i], (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, 0, 0, 0, L.fwd_job[i]))) return rc;
                 float *aux = theta + p->aux_off[i];
                 float *stat = reinterpret_cast<float *>(wsb + L.stat[i]);
                 if ((rc = launch_bn_forward(y, B, (int)o.cout, out.h, out.w, bn_eps, bn_momentum, aux, aux + o.cout,
@@ -377,7 +426,7 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
             } else {
                 a.bias = theta + p->aux_off[i];
                 a.dst = act(o.dst); a.dst_ctotal = (int)p->tensors[o.dst].channels; a.dst_choff = (int)o.dst_choff; a.relu = (int)o.relu;
-                if ((rc = run_conv(a, (int)o.k, (int)o.stride, theta + p->w_off[i], (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, 0, 0, 0))) return rc;
+                if ((rc = run_conv(a, (int)o.k, (int)o.stride, theta + p->w_off[i], (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, 0, 0, 0, L.fwd_job[i]))) return rc;
             }
         } else if (o.kind == OP_POOL) {
             if ((rc = launch_avgpool2(act(o.src[0].tensor), act(o.dst), B * (int)o.cin, in.h, in.w, nullptr, nullptr, s))) return rc;
@@ -462,7 +511,7 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
                     b.Cin = (int)o.cout; b.Cout = ch; b.Hin = in.h; b.Win = in.w; b.Hout = in.h; b.Wout = in.w;
                     b.ntiles = (ch + 15) / 16; b.src_end = 1; b.accum = 1;
                     const int dy_ch = (int)o.cout;
-                    if ((rc = run_conv(b, (int)o.k, 1, theta + p->w_off[ii], (int)o.cin, (int)o.cout, &dy_ch, 1, 1, c0, ch))) return rc;
+                    if ((rc = run_conv(b, (int)o.k, 1, theta + p->w_off[ii], (int)o.cin, (int)o.cout, &dy_ch, 1, 1, c0, ch, L.bwd_job[ii][j]))) return rc;
                 }
                 c0 += ch;
             }
