@@ -147,3 +147,53 @@ def test_split_operand_bound():
     with np.errstate(over='ignore'):
         assert np.isinf(np.float32(65520.0).astype(np.float16))
     assert np.float32(65519.0).astype(np.float16) == np.float16(65504.0)
+
+
+def test_lazy_result_checks_once_on_first_value_access():
+    """bg_model.LazyResult (the dict predict() returns): listing keys waits for nothing; the first access of a VALUE settles the
+    forward behind it exactly once - through every accessor a caller of the reference's result dict may use."""
+    from panoptic_forecasting_amd.bg_model import LazyResult
+
+    class FakeModel:
+        def __init__(self):
+            self.resolved = []
+
+        def _resolve(self, token):
+            self.resolved.append(token)
+
+    for access in (lambda r: r['seg'], lambda r: r.get('seg'), lambda r: list(r.items()), lambda r: list(r.values()),
+                   lambda r: r.copy(), lambda r: r.pop('seg')):
+        m = FakeModel()
+        r = LazyResult({'seg': 1, 'orig_size_logits': 2}, m, 'token')
+        assert sorted(r.keys()) == ['orig_size_logits', 'seg'] and 'seg' in r and len(r) == 2
+        assert m.resolved == []                      # nothing waited for yet
+        access(r)
+        access(LazyResult({'seg': 1, 'orig_size_logits': 2}, m, None))   # a result without a token (stream capture, policy 'ignore') never resolves
+        r.get('orig_size_logits')
+        assert m.resolved == ['token'], m.resolved   # exactly once
+
+
+def test_inverse_cache_hits_without_touching_the_tensor_and_verifies_on_request():
+    """pc_transform_model.InverseCache: a hit on (storage, version) returns the cached host inverse without comparing contents
+    (no stream synchronisation per predict); an in-place edit bumps the version and misses; a write that bypasses the version
+    counter is caught only when `verify` is on."""
+    from panoptic_forecasting_amd.pc_transform_model import InverseCache
+    K = torch.tensor([[[2.0, 0.0, 1.0], [0.0, 4.0, 2.0], [0.0, 0.0, 1.0]]])
+    c = InverseCache(verify=False)
+    a = c(K)
+    assert torch.allclose(a @ K, torch.eye(3).expand(1, 3, 3)) and c(K) is a
+    K.mul_(2.0)                                       # in-place: _version changes
+    b = c(K)
+    assert b is not a and torch.allclose(b @ K, torch.eye(3).expand(1, 3, 3), atol=1e-6)
+    K.data.copy_(K.data * 0.5)                         # bypasses the version counter
+    assert c(K) is b                                   # not seen without verification (documented)
+    v = InverseCache(verify=True)
+    first = v(K)
+    K.data.copy_(K.data * 4.0)
+    again = v(K)
+    assert again is not first and torch.allclose(again @ K, torch.eye(3).expand(1, 3, 3), atol=1e-6)
+
+
+def test_backend_description_single_process():
+    from panoptic_forecasting_amd import dist as pfdist
+    assert pfdist.backend_description() == 'single process'
