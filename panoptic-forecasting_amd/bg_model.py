@@ -30,7 +30,7 @@ PF_WS_STATUS_BYTES = 2048
 
 class _Pending:
     """One enqueued forward whose status words are on their way to pinned host memory."""
-    __slots__ = ('slot', 'event', 'args', 'outs', 'done')
+    __slots__ = ('slot', 'event', 'stream', 'args', 'outs', 'done')
 
 
 class LazyResult(dict):
@@ -301,7 +301,13 @@ class BGModel(BaseModel):
         prior = self.plan_options.get('split_f16', 1)
         _lib.check(L.pf_hardnet_plan_set_option(plan, b'split_f16', 0), 'pf_hardnet_plan_set_option')
         try:
-            self._run_once(*args, outs=outs)
+            # on the stream the forward ran on (the workspace belongs to that stream's order: a later forward may be using it
+            # right now); whoever touches the result on another stream is made to wait for the re-run
+            here = torch.cuda.current_stream()
+            with torch.cuda.stream(token.stream):
+                self._run_once(*args, outs=outs)
+            if here != token.stream:
+                here.wait_stream(token.stream)
         finally:
             _lib.check(L.pf_hardnet_plan_set_option(plan, b'split_f16', prior), 'pf_hardnet_plan_set_option')
 
@@ -339,8 +345,9 @@ class BGModel(BaseModel):
         self._pinned[slot].copy_(self._ws[:8].view(torch.int32), non_blocking=True)
         token = _Pending()
         token.slot, token.args, token.outs, token.done = slot, args, outs, False
+        token.stream = torch.cuda.current_stream()
         token.event = torch.cuda.Event()
-        token.event.record()
+        token.event.record(token.stream)
         self._pending.append(token)
         return outs, token
 
