@@ -105,6 +105,13 @@ def test_fused_front_end_vs_oracle(h, w, b):
             got = view_tensor(m._get_plan(), m._ws, tap, b, h, w).cpu()
             err = (got - taps[tap]).abs().max().item()
             assert err <= 1e-4 * (1 + taps[tap].abs().max().item()), (fuse, tap, err)
+        # the tensor between the two fused convs is never stored: a tap of it must fail loudly, not return workspace bytes
+        if fuse:
+            with pytest.raises(pflib.PfError, match='elided'):
+                view_tensor(m._get_plan(), m._ws, 'base.1', b, h, w)
+        else:
+            got = view_tensor(m._get_plan(), m._ws, 'base.1', b, h, w).cpu()
+            assert (got - taps['base.1']).abs().max().item() <= 1e-4 * (1 + taps['base.1'].abs().max().item())
         assert m.range_status() == 0
         assert (outs[fuse]['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max() <= LOGIT_TOL
         assert (outs[fuse]['seg'].cpu() == ref['seg']).float().mean().item() >= AGREE
@@ -217,3 +224,24 @@ def test_validation_loss_matches_torch_cross_entropy(h, w, b):
     assert abs(got['accuracy'].item() - want_acc.item()) <= 1e-6
     got8 = m.loss(inp, {'seg': lab.to(torch.uint8).cuda()})    # u8 labels, same numbers, deterministic
     assert got8['loss'].item() == got['loss'].item() and got8['accuracy'].item() == got['accuracy'].item()
+
+
+@pytest.mark.parametrize('u8', [False, True], ids=['i64_labels', 'u8_labels'])
+def test_nan_depth_is_flagged_not_turned_into_zero(u8):
+    """A NaN depth propagates through the reference's fp32 conv (hardnet.py:16-25) even under a zero mask (NaN * 0 = NaN); the
+    stem's ReLU max would turn it into 0.  The stem raises PF_STATUS_RANGE instead, the forward is re-run on the fp32 path under
+    the default policy, and 'ignore' leaves the flag readable."""
+    from panoptic_forecasting_amd import synth
+    h, w = 64, 128
+    inp = synth.make_bg_inputs(b=1, h=h, w=w, seed=3)
+    inp['depth'] = inp['depth'].clone()
+    inp['depth'][0, 1, 20, 40] = float('nan')
+    cu = {k: v.cuda() for k, v in inp.items()}
+    if u8:
+        cu['seg'] = cu['seg'].to(torch.uint8)        # selects the 2 x 2-outputs-per-lane stem
+    m = _model(h, w, on_range_overflow='ignore')
+    m.predict(cu, None)['seg']
+    assert m.range_status() & 1
+    m2 = _model(h, w)
+    m2.predict(cu, None)['seg']
+    assert m2.range_reruns == 1
