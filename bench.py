@@ -54,6 +54,10 @@ PEAK_HBM_GBPS = 8000.0          # HBM3E spec (6.3 TB/s achievable)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 (2495 measured; tools/ubench/f16_split.hip: same rate)
 CPU_BUDGET_S = 20.0             # stop starting new baseline frames after this much CPU time
 SUB_BATCH = 16                  # frames per concurrent sub-batch of the headline workload
+# test hook (tests/test_gpu_pipeline.py): PF_BENCH_SHARE_GPU=1 lets the ranks of --gpus N share the GPUs that exist (gloo instead of
+# RCCL, which refuses two ranks per device) so that the N > 1 line - per-rank times, gather, backend - is exercised on a 1-GPU box.
+# Never a measurement: the line says so (config.backend = gloo, identical `devices`)
+SHARE_GPU = os.environ.get('PF_BENCH_SHARE_GPU') == '1'
 
 
 def build_model(params):
@@ -517,7 +521,7 @@ def parse_args(argv=None):
 
 def relaunch_under_torchrun(args):
     """python bench.py --gpus N (N > 1) from a plain shell: become the launcher of N ranks."""
-    if not args.dry_run and torch.cuda.device_count() < args.gpus:
+    if not args.dry_run and torch.cuda.device_count() < args.gpus and not SHARE_GPU:
         raise SystemExit('bench.py: --gpus %d but this node has %d GPU(s)' % (args.gpus, torch.cuda.device_count()))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -531,7 +535,9 @@ def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         relaunch_under_torchrun(args)
-    rank, world, local = pfdist.init_distributed_mode(backend='gloo' if args.dry_run else None)
+    rank, world, local = pfdist.init_distributed_mode(backend='gloo' if (args.dry_run or SHARE_GPU) else None)
+    if SHARE_GPU and not args.dry_run:
+        local = local % max(1, torch.cuda.device_count())
     joined = torch.distributed.get_world_size() if pfdist.is_dist() else 1
     if world != args.gpus or joined != args.gpus:
         raise SystemExit('bench.py: --gpus %d but %d rank(s) joined (WORLD_SIZE=%d)' % (args.gpus, joined, world))
@@ -583,7 +589,7 @@ def main():
     # every rank's own step time and device identity: a straggler, or two ranks on one device, shows in the N > 1 line
     ident = pfdist.device_identity(local)
     per_rank = pfdist.gather_objects({'rank': rank, 'ms_per_step': 1e3 * wl.local_s / args.steps, 'device': ident})
-    if len({r['device'] for r in per_rank}) != len(per_rank):
+    if len({r['device'] for r in per_rank}) != len(per_rank) and not SHARE_GPU:
         raise SystemExit('bench.py: %d ranks share devices: %s' % (len(per_rank), [r['device'] for r in per_rank]))
 
     # ---- sharded metric exchange: PQ accumulators of this rank's forecasts vs a synthetic ground truth

@@ -46,10 +46,17 @@ def shard_indices(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
+def _host_collectives():
+    """gloo carries the collectives of CPU runs and of several ranks sharing one GPU (tests): its tensors travel through host memory"""
+    return str(dist.get_backend()) == 'gloo'
+
+
 def gather_accumulators(acc):
     """acc [n_cls,4] float64 on this rank -> [world, n_cls, 4] on every rank (identity for 1 process)."""
     if not is_dist():
         return acc.unsqueeze(0)
+    if acc.is_cuda and _host_collectives():
+        return gather_accumulators(acc.cpu()).to(acc.device)
     world = dist.get_world_size()
     # concatenated along dim 0 (the layout every backend accepts), viewed back as [world, ...]
     out = torch.empty((world * acc.shape[0],) + tuple(acc.shape[1:]), dtype=acc.dtype, device=acc.device)
@@ -97,7 +104,7 @@ def backend_description():
 def max_over_ranks(x, device):
     if not is_dist():
         return float(x)
-    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(x)], dtype=torch.float64, device='cpu' if _host_collectives() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -107,6 +114,11 @@ def all_reduce_mean_(flat):
     for FC-HarDNet-70) and a division by the world size — what DistributedDataParallel does bucket by bucket in the
     reference (``training/train.py:96-103``).  In place; identity for a single process."""
     if is_dist():
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if flat.is_cuda and _host_collectives():
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(dist.get_world_size())
     return flat

@@ -71,3 +71,29 @@ def test_forecast_export_merge_encode_pq(tmp_path):
     worse = seg.clone()
     worse[:, : h // 2] = 255
     assert pq.pq_from_acc(pq.pq_accumulate_panoptic(worse, seg))['pq'] < 100.0
+
+
+def test_bench_two_ranks_on_one_gpu_prints_the_multi_rank_line():
+    """`bench.py --gpus 2` end to end on a 1-GPU box: PF_BENCH_SHARE_GPU=1 lets both ranks use the one device over gloo (RCCL refuses
+    two ranks per device), so the N > 1 code path really runs on the GPU - the launcher, the barrier-bracketed timed region with the
+    max over ranks, the sharded PQ gather, per-rank times and device identities - and prints ONE line with n_gpus = 2.  Not a
+    measurement (the line names gloo and two identical devices); the 8-GPU run is the driver's."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    e = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e['PF_BENCH_SHARE_GPU'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '16',
+                        '--profile-steps', '1'], capture_output=True, text=True, timeout=900, env=e)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+    assert len(d['per_rank_ms']) == 2 and len(d['devices']) == 2 and d['pq_gather_check']['ranks_gathered'] == 2
+    assert 'gloo' in d['config']['backend'] and d['config']['world'] == 2
+    assert d['cpu_baseline'] is None and d['by_batch'] is None          # rank 0 at N = 1 only
+    assert d['range_overflow'] is False
