@@ -558,29 +558,34 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(ConvArgs a, const fl
 // [16][KS][64 S + 8] are loaded with coalesced 16-B loads one segment AHEAD (registers), parked in LDS, and the 4 waves
 // multiply 16 pixels each for all k*k taps from there (pitches == 4 mod 32 floats: at most 2-way bank conflicts on
 // the one-float-per-lane fragment reads).  Partial sums per slab as before, same fixed-order reduction.
-template <int KS, int STRIDE>
+// R = output rows per work item (round 4).  With R = 1 every x row is staged three times by a 3x3 layer (once per tap row of the
+// three output rows it feeds); R = 2 stages KS + 1 rows for two output rows: 2 x rows per output row instead of 3, a fifth
+// fewer bytes per multiply-add (the kernel is bound by its L2 -> LDS bytes)
+template <int KS, int STRIDE, int R>
 struct WgCfg {
     static constexpr int KS2 = KS * KS, P = KS / 2, TW = 64;
+    static constexpr int XR = KS + (R - 1) * STRIDE;                // staged x rows
     static constexpr int XW = TW * STRIDE + 8;                      // staged x columns: [x0 S - 4, x0 S + 64 S + 4)
-    static constexpr int XCP = (KS * XW + 27) / 32 * 32 + 4;        // channel pitch == 4 (mod 32), >= KS * XW
+    static constexpr int XCP = (XR * XW + 27) / 32 * 32 + 4;        // channel pitch == 4 (mod 32), >= XR * XW
     static constexpr int DP = TW + 4;                               // dy row pitch: 68 == 4 (mod 32)
-    static constexpr int NDY = 32 * (TW / 4), NX = 16 * KS * (XW / 4);   // float4 loads per segment
+    static constexpr int NDY = R * 32 * (TW / 4), NX = 16 * XR * (XW / 4);   // float4 loads per item
     static constexpr int ITD = NDY / 256, ITX = (NX + 255) / 256;
-    static constexpr int LDS_FLOATS = 32 * DP + 16 * XCP;
-    static_assert(XCP >= KS * XW && XCP % 32 == 4 && NDY % 256 == 0, "wgrad tile geometry");
+    static constexpr int LDS_FLOATS = R * 32 * DP + 16 * XCP;
+    static_assert(XCP >= XR * XW && XCP % 32 == 4 && NDY % 256 == 0, "wgrad tile geometry");
 };
 
-template <int KS, int STRIDE>
+template <int KS, int STRIDE, int R>
 __global__ __launch_bounds__(256) void wgrad_tiled_kernel(ConvArgs a, const float *dy, int B, int slabs, float *partial) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using C = WgCfg<KS, STRIDE>;
+    using C = WgCfg<KS, STRIDE, R>;
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS > 3 * 4 * 256 ? C::LDS_FLOATS : 3 * 4 * 256];
-    float *dy_s = lds, *x_s = lds + 32 * C::DP;
+    float *dy_s = lds, *x_s = lds + R * 32 * C::DP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 16, slab = blockIdx.z;
     const long long in_plane = (long long)a.Hin * a.Win, out_plane = (long long)a.Hout * a.Wout;
     const int chunks = (a.Wout + C::TW - 1) / C::TW;
-    const long long items = (long long)B * a.Hout * chunks;
+    const int row_groups = (a.Hout + R - 1) / R;
+    const long long items = (long long)B * row_groups * chunks;
 
     // this thread's x loads: (channel, tap row, 16-B column) of the staged window -> plane base of the channel (batch 0)
     const float *xplane[C::ITX];
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(256) void wgrad_tiled_kernel(ConvArgs a, const floa
 #pragma unroll
     for (int it = 0; it < C::ITX; ++it) {
         const int idx = it * 256 + tid;
-        const int c = idx / (KS * (C::XW / 4)), r = idx - c * (KS * (C::XW / 4));
+        const int c = idx / (C::XR * (C::XW / 4)), r = idx - c * (C::XR * (C::XW / 4));
         const int row = r / (C::XW / 4), c4 = r - row * (C::XW / 4);
         const int ci = ci0 + c;
         xplane[it] = nullptr;
@@ -608,15 +613,15 @@ __global__ __launch_bounds__(256) void wgrad_tiled_kernel(ConvArgs a, const floa
     auto fetch = [&](long long item) {
         const int ch = (int)(item % chunks);
         const long long row = item / chunks;
-        const int b = (int)(row / a.Hout), oy = (int)(row - (long long)b * a.Hout);
+        const int b = (int)(row / row_groups), oy = (int)(row - (long long)b * row_groups) * R;
         const int x0 = ch * C::TW;
 #pragma unroll
         for (int it = 0; it < C::ITD; ++it) {
-            const int idx = it * 256 + tid, c = idx >> 4, c4 = idx & 15;
+            const int idx = it * 256 + tid, r2 = idx >> 9, c = (idx >> 4) & 31, c4 = idx & 15;
             const int co = co0 + c, ox = x0 + c4 * 4;
             rdy[it] = tr_f32x4{0.f, 0.f, 0.f, 0.f};
-            if (co < a.Cout && ox < a.Wout)   // Wout % 4 == 0: a 16-B piece is inside the row or outside it
-                rdy[it] = *reinterpret_cast<const tr_f32x4 *>(dy + ((long long)b * a.Cout + co) * out_plane + (long long)oy * a.Wout + ox);
+            if (co < a.Cout && ox < a.Wout && oy + r2 < a.Hout)   // Wout % 4 == 0: a 16-B piece is inside the row or outside it
+                rdy[it] = *reinterpret_cast<const tr_f32x4 *>(dy + ((long long)b * a.Cout + co) * out_plane + (long long)(oy + r2) * a.Wout + ox);
         }
 #pragma unroll
         for (int it = 0; it < C::ITX; ++it) {
@@ -629,7 +634,7 @@ __global__ __launch_bounds__(256) void wgrad_tiled_kernel(ConvArgs a, const floa
     auto park = [&]() {
 #pragma unroll
         for (int it = 0; it < C::ITD; ++it) {
-            const int idx = it * 256 + tid;
+            const int idx = it * 256 + tid;      // (row r2, cout c) = idx >> 4: rows of 32 couts follow each other
             *reinterpret_cast<tr_f32x4 *>(dy_s + (idx >> 4) * C::DP + (idx & 15) * 4) = rdy[it];
         }
 #pragma unroll
@@ -653,14 +658,16 @@ __global__ __launch_bounds__(256) void wgrad_tiled_kernel(ConvArgs a, const floa
         __syncthreads();
         if (item + slabs < items) fetch(item + slabs);   // in flight during the MFMAs
 #pragma unroll
+        for (int r2 = 0; r2 < R; ++r2)
+#pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             const int q = wave * 4 + qq;                 // 4-pixel group of the segment
-            const float a0 = dy_s[m * C::DP + q * 4 + kq];
-            const float a1 = two ? dy_s[(16 + m) * C::DP + q * 4 + kq] : 0.f;
+            const float a0 = dy_s[(r2 * 32 + m) * C::DP + q * 4 + kq];
+            const float a1 = two ? dy_s[(r2 * 32 + 16 + m) * C::DP + q * 4 + kq] : 0.f;
 #pragma unroll
             for (int t = 0; t < C::KS2; ++t) {
                 const int ky = t / KS, kx = t - ky * KS;
-                const float bv = x_s[m * C::XCP + ky * C::XW + (q * 4 + kq) * STRIDE + kx - C::P + 4];
+                const float bv = x_s[m * C::XCP + (r2 * STRIDE + ky) * C::XW + (q * 4 + kq) * STRIDE + kx - C::P + 4];
                 acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][t], 0, 0, 0);
                 if (two) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][t], 0, 0, 0);
             }
@@ -728,17 +735,22 @@ size_t wgrad_partial_floats(int cout, int cin, int ks, int B, int Hout, int Win,
 }
 
 int launch_wgrad(const ConvArgs &a, int ks, int stride, const float *dy, int B, float *partial, float *dw, hipStream_t s) {
-    const int slabs = wgrad_slabs(a.Cout, a.Cin, B, a.Hout, a.Win, a.Wout);
+    int slabs = wgrad_slabs(a.Cout, a.Cin, B, a.Hout, a.Win, a.Wout);
     const bool tiled = wgrad_tiled_ok(a.Win, a.Wout);
+    const bool two_rows = tiled && ks == 3 && stride == 1;      // R = 2: half as many work items (the partial buffer is sized for R = 1)
+    if (two_rows) {
+        const long long items2 = (long long)B * ((a.Hout + 1) / 2) * ((a.Wout + 63) / 64);
+        slabs = (int)(slabs > items2 ? items2 : slabs);
+    }
     const dim3 grid(tiled ? (a.Cout + 31) / 32 : (a.Cout + 15) / 16, (a.Cin + 15) / 16, slabs);
     const double flops = 2.0 * B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks;
     {
         ProfScope ps(s, tiled ? "wgrad_tiled_kernel" : "wgrad_partial_kernel", flops,
                      4.0 * B * ((double)a.Cout * a.Hout * a.Wout + (double)a.Cin * a.Hin * a.Win));
         if (tiled) {
-            if (ks == 3 && stride == 1) hipLaunchKernelGGL((wgrad_tiled_kernel<3, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
-            else if (ks == 3 && stride == 2) hipLaunchKernelGGL((wgrad_tiled_kernel<3, 2>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
-            else if (ks == 1 && stride == 1) hipLaunchKernelGGL((wgrad_tiled_kernel<1, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
+            if (ks == 3 && stride == 1) hipLaunchKernelGGL((wgrad_tiled_kernel<3, 1, 2>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
+            else if (ks == 3 && stride == 2) hipLaunchKernelGGL((wgrad_tiled_kernel<3, 2, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
+            else if (ks == 1 && stride == 1) hipLaunchKernelGGL((wgrad_tiled_kernel<1, 1, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
             else return fail(PF_EUNSUPPORTED, "wgrad: k=%d stride=%d", ks, stride);
         } else {
             if (ks == 3 && stride == 1) hipLaunchKernelGGL((wgrad_partial_kernel<3, 1>), grid, dim3(256), 0, s, a, dy, B, slabs, partial);
