@@ -61,11 +61,17 @@ class BGTrainer:
         self.clip_value = float(tr.get('clip_grad') or 0.)
         self.clip_norm = 0. if tr.get('clip_grad') is not None else float(tr.get('clip_grad_norm') or 0.)   # train.py:205-208
         self.accumulate_steps = int(tr.get('accumulate_steps', 1))
-        # forward + loss + backward of a batch configuration is ~1100 kernel launches; enqueued one by one from the host they
-        # leave the GPU idle a third of the step (14.2 ms of kernels in a 20.8 ms step at batch 8 of 800x800).  With
-        # ``training.use_hip_graph`` (default on) the call is captured into a hipGraph the second time a configuration (shapes,
-        # dtypes, accumulate / loss-scale / running-stat flags) is seen and replayed from then on, on static copies of the inputs
-        self.use_graph = bool(tr.get('use_hip_graph', True))
+        # Two launch forms (same bits, tests/test_gpu_train.py):
+        #  * default - eager launches with the weight gradients (leaves of the backward pass) on the training plan's own
+        #    lower-priority stream (``training.weight_gradient_stream``, library option "train_side_stream"): they fill the
+        #    GPU beside the small-grid kernels of the bn-backward -> input-gradient chain; 17.7 ms per step at batch 8 of
+        #    800x800 against 19.6 ms on one stream;
+        #  * ``training.use_hip_graph`` - the call is captured into a hipGraph the second time a configuration (shapes, dtypes,
+        #    accumulate / loss-scale / running-stat flags) is seen and replayed from then on, on static copies of the inputs:
+        #    no host launch cost (a busy host, many ranks per socket), 19.6 ms.  A captured step stays on one stream: every
+        #    cross-stream edge of a hipGraph costs a barrier packet on ROCm 7.2 (30.5 ms with the fork per layer).
+        self.use_graph = bool(tr.get('use_hip_graph', False))
+        self.side_stream = bool(tr.get('weight_gradient_stream', not self.use_graph))
         self._graphs = {}
         dn = params['data'].get('depth_norm_params')
         self.depth_mean, self.depth_std = (float(dn[0]), float(dn[1])) if dn is not None else (0., 0.)
@@ -79,7 +85,11 @@ class BGTrainer:
                                          for op in self.spec.conv_ops()})
         self._buf = ctypes.create_string_buffer(blob, len(blob))
         self._t = ctypes.c_void_p()
-        _lib.check(L.pf_train_create(self._buf, len(blob), self.in_ch, self.n_cls, ctypes.byref(self._t)), 'pf_train_create')
+        _lib.check(L.pf_set_option(b'train_side_stream', int(self.side_stream)), 'pf_set_option')   # read by pf_train_create
+        try:
+            _lib.check(L.pf_train_create(self._buf, len(blob), self.in_ch, self.n_cls, ctypes.byref(self._t)), 'pf_train_create')
+        finally:
+            L.pf_set_option(b'train_side_stream', 1)
         n = ctypes.c_size_t()
         _lib.check(L.pf_train_param_count(self._t, ctypes.byref(n)), 'pf_train_param_count')
         if n.value != self.n:

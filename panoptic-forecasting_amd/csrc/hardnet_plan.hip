@@ -75,6 +75,7 @@ int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_spli
 int g_opt_range_guard = 1, g_opt_fuse_front = 1;   // fuse_front: conv_front.hip (0: stem -> conv_split -> conv_dma stride 2, three kernels)
 int g_opt_normalize = 1;   // normalize_ranges: per-channel power-of-two scaling of the stored activations, fixed at plan creation
 extern int g_opt_use_tuned;
+int g_opt_train_side = 1;   // train_side_stream: weight gradients on the training plan's own stream (train_plan.hip)
 }
 
 extern "C" int pf_set_option(const char *name, int value) {
@@ -89,6 +90,7 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "fuse_front")) g_opt_fuse_front = value;
     else if (!strcmp(name, "normalize_ranges")) g_opt_normalize = value;
     else if (!strcmp(name, "profile_tag_ops")) g_opt_tag_ops = value;
+    else if (!strcmp(name, "train_side_stream")) g_opt_train_side = value;
     else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);
     return PF_OK;
 }
@@ -622,9 +624,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             a.logits = tptr(o.src[0].tensor);
             a.out_seg = out_seg; a.out_logits = out_logits; a.out_is_i64 = out_seg_is_i64;
             a.B = B; a.C = (int)o.cin; a.Hin = in.h; a.Win = in.w; a.Hout = out_h; a.Wout = out_w;
-            if (out_orig)
-                PF_HIP_CHECK(hipMemcpyAsync(out_orig, a.logits, (size_t)B * a.C * in.h * in.w * sizeof(float),
-                                            hipMemcpyDeviceToDevice, s));
+            if (out_orig && (rc = launch_copy(out_orig, a.logits, (size_t)B * a.C * in.h * in.w * sizeof(float), s))) return rc;
             if ((rc = launch_head(a, s))) return rc;
         }
     }
@@ -1024,15 +1024,17 @@ extern "C" int pf_hardnet_status_sticky(void *ws, unsigned *status, int clear, v
     if (!ws || !status) return fail(PF_EINVAL, "pf_hardnet_status_sticky: null argument");
     char *w = (char *)ws + PF_WS_STICKY_OFFSET;
     PF_HIP_CHECK(hipMemcpyAsync(status, w, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    if (clear) PF_HIP_CHECK(hipMemsetAsync(w, 0, sizeof(unsigned), (hipStream_t)stream));
+    if (clear) {
+        int rc = launch_zero_fill(w, sizeof(unsigned), (hipStream_t)stream);
+        if (rc) return rc;
+    }
     PF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return PF_OK;
 }
 
 extern "C" int pf_hardnet_status_reset(void *ws, void *stream) {
     if (!ws) return fail(PF_EINVAL, "pf_hardnet_status_reset: null argument");
-    PF_HIP_CHECK(hipMemsetAsync(ws, 0, PF_WS_STATUS_BYTES, (hipStream_t)stream));
-    return PF_OK;
+    return launch_zero_fill(ws, PF_WS_STATUS_BYTES, (hipStream_t)stream);
 }
 
 extern "C" int pf_hardnet_range_maxima(const pf_plan *p, const void *ws, float *maxima, int cap, int *n_ops, void *stream) {
@@ -1086,7 +1088,8 @@ extern "C" int pf_hardnet_tensor_read(const pf_plan *p, const char *name, int B,
     if (t < p->last_fmt.size() && p->last_fmt[t]) {
         if ((rc = launch_s4_unpack(src, dst, B, c, h, w, (hipStream_t)stream))) return rc;
     } else {
-        PF_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)B * c * h * w * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        int rc = launch_copy(dst, src, (size_t)B * c * h * w * sizeof(float), (hipStream_t)stream);
+        if (rc) return rc;
     }
     // tensors are stored multiplied by the plan's per-channel powers of two (normalize_ranges): undo it for the caller
     if (p->inv_scale_off[t]) {

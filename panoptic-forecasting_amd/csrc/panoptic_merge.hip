@@ -325,7 +325,7 @@ extern "C" int pf_panoptic_encode(const void *seg, int seg_is_i64, int convert_t
     const size_t n = (size_t)H * W;
     if (n % 4) return pf::fail(PF_EUNSUPPORTED, "pf_panoptic_encode: H*W must be a multiple of 4");
     hipStream_t s = (hipStream_t)stream;
-    PF_HIP_CHECK(hipMemsetAsync(out_present, 0, (size_t)B * pf::kMaxIds, s));
+    if (int rc = pf::launch_zero_fill(out_present, (size_t)B * pf::kMaxIds, s)) return rc;
     pf::EncodeArgs a{seg, out_rgb, out_ids, out_present, n, B, seg_is_i64 ? 1 : 0, convert_to_ids ? 1 : 0};
     size_t blocks = ((n >> 2) + 255) / 256;
     blocks = blocks > 2048 ? 2048 : blocks;

@@ -34,6 +34,10 @@ int fail(int code, const char *fmt, ...);
 #endif
 static inline const char *ab_env(const char *name) { return PF_AB ? getenv(name) : nullptr; }
 
+// pf_fill.hip: zero fill / device-to-device copy as kernels (a captured call of the library holds kernel nodes only - see there)
+int launch_zero_fill(void *p, size_t bytes, hipStream_t s);
+int launch_copy(void *dst, const void *src, size_t bytes, hipStream_t s);
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace pf

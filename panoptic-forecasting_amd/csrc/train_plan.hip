@@ -35,7 +35,16 @@ struct pf_train {
     std::vector<int> bn;                  // per op: 1 = conv + BN (+ ReLU), 0 = plain conv with bias
     size_t n_params = 0;
     float *dev_zero = nullptr;            // 1024 zeros (bias of the BN-less generic conv launches)
+    // the weight gradients are leaves of the backward pass: they run on this plan's own lower-priority stream, forked from and
+    // joined to the caller's stream inside every pf_train_forward_backward (so a stream capture of the call stays one graph).
+    // Option "train_side_stream" (read when the plan is created; 0 = everything on the caller's stream)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_dy[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr}, ev_join = nullptr;
 };
+
+namespace pf {
+extern int g_opt_train_side;
+}
 
 namespace {
 
@@ -70,6 +79,7 @@ struct TLayout {
     std::vector<size_t> ypre, stat;    // per op: pre-BN conv output, {mean[cout], invstd[cout]}
     size_t dy = 0, wpk = 0, wpart = 0, dfull = 0, cepart = 0, bnpart = 0, sums = 0, out3 = 0, total = 0;
     size_t pad_in = 0, pad_out = 0;    // odd-width convs: gathered input / result with the row pitch rounded up to 4
+    size_t dy2 = 0, pad_in_w = 0, pad_out_w = 0;   // side stream: the second dy slot, the weight-gradient's own padded copies
     size_t grad_begin = 0, grad_end = 0;
     // every tiled weight packing of the step (forward convs in op order, then the backward-data convs of every op and input
     // range in op order): packed by ONE batch of launches at the start of the step into wpk_arena
@@ -175,6 +185,11 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
         L.wpk_arena = take(arena * sizeof(float) + 256);
     }
     L.dy = take(max_dy + 256);
+    if (p->side) {
+        L.dy2 = take(max_dy + 256);
+        L.pad_in_w = take(max_pin);
+        L.pad_out_w = take(max_pout);
+    }
     L.wpk = take(max_wpk * sizeof(float));
     L.wpart = take(max_wpart * sizeof(float));
     L.pad_in = take(max_pin);
@@ -239,12 +254,25 @@ extern "C" int pf_train_create(const void *blob, size_t bytes, int in_ch, int n_
         delete p;
         return fail(PF_EHIP, "pf_train_create: device allocation failed");
     }
+    if (g_opt_train_side) {
+        int lo = 0, hi = 0;
+        bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, lo) == hipSuccess;
+        hipEvent_t *evs[5] = {&p->ev_dy[0], &p->ev_dy[1], &p->ev_wg[0], &p->ev_wg[1], &p->ev_join};
+        for (int i = 0; ok && i < 5; ++i) ok = hipEventCreateWithFlags(evs[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            pf_train_destroy(p);
+            return fail(PF_EHIP, "pf_train_create: could not create the weight-gradient stream");
+        }
+    }
     *out = p;
     return PF_OK;
 }
 
 extern "C" void pf_train_destroy(pf_train *p) {
     if (!p) return;
+    for (hipEvent_t e : {p->ev_dy[0], p->ev_dy[1], p->ev_wg[0], p->ev_wg[1], p->ev_join})
+        if (e) (void)hipEventDestroy(e);
+    if (p->side) (void)hipStreamDestroy(p->side);
     if (p->dev_zero) (void)hipFree(p->dev_zero);
     delete p;
 }
@@ -310,7 +338,7 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
     auto gradt = [&](uint32_t t) { return reinterpret_cast<float *>(wsb + L.grad[t]); };
     const uint32_t input = p->ops[0].src[0].tensor;
     const int in_ch = (int)p->tensors[input].channels, n_cls = (int)p->hdr.n_cls;
-    float *dy = reinterpret_cast<float *>(wsb + L.dy);
+    float *const dy_slot[2] = {reinterpret_cast<float *>(wsb + L.dy), reinterpret_cast<float *>(wsb + (p->side ? L.dy2 : L.dy))};
     float *wpk = reinterpret_cast<float *>(wsb + L.wpk);
     float *wpart = reinterpret_cast<float *>(wsb + L.wpart);
     float *pad_in = reinterpret_cast<float *>(wsb + L.pad_in), *pad_out = reinterpret_cast<float *>(wsb + L.pad_out);
@@ -322,15 +350,15 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
 
     // ---- input tensor (bg_model.py:61-69)
     if (x_dense) {
-        PF_HIP_CHECK(hipMemcpyAsync(act(input), x_dense, (size_t)B * in_ch * H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if ((rc = launch_copy(act(input), x_dense, (size_t)B * in_ch * H * W * sizeof(float), s))) return rc;
     } else {
         if (T * (n_cls + 1) != in_ch) return fail(PF_EINVAL, "T=%d frames x (%d classes + depth) != %d input channels", T, n_cls, in_ch);
         if ((rc = launch_onehot_dense(seg, seg_is_i64, depth, depth_mask, depth_mean, depth_std, B, T, n_cls, H, W, act(input), s))) return rc;
     }
     float *wpk_arena = reinterpret_cast<float *>(wsb + L.wpk_arena);
     if ((rc = launch_pack_weights_batch(theta, wpk_arena, L.jobs.data(), (int)L.jobs.size(), s))) return rc;   // theta does not move inside this call
-    PF_HIP_CHECK(hipMemsetAsync(wsb + L.grad_begin, 0, L.grad_end - L.grad_begin, s));
-    if (!accumulate_grads) PF_HIP_CHECK(hipMemsetAsync(grad, 0, p->n_params * sizeof(float), s));
+    if ((rc = launch_zero_fill(wsb + L.grad_begin, L.grad_end - L.grad_begin, s))) return rc;
+    if (!accumulate_grads && (rc = launch_zero_fill(grad, p->n_params * sizeof(float), s))) return rc;
 
     auto conv_args = [&](const BlobOp &o, const TDims &in, const TDims &out, ConvArgs &a) {
         memset(&a, 0, sizeof(a));
@@ -436,11 +464,15 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
             if ((rc = launch_ce_fwd_bwd(act(o.src[0].tensor), B, (int)o.cin, in.h, in.w, labels, labels_i64, out_h, out_w, ignore_index, dfull,
                                         cepart, loss3, s)))
                 return rc;
-            PF_HIP_CHECK(hipMemcpyAsync(out3, loss3, 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+            if ((rc = launch_copy(out3, loss3, 3 * sizeof(double), s))) return rc;
         }
     }
 
     // ================================================================ backward
+    // With the side stream: layer n's conv-output gradient goes to dy slot n & 1; the weight gradient (and its padded copies)
+    // reads it on the side stream while the caller's stream goes on to the input gradients and the next layer, whose own dy
+    // waits for the weight gradient of layer n - 1 ... n - 2 that last read its slot.
+    int n_conv = 0;
     for (size_t ii = p->ops.size(); ii-- > 0;) {
         const BlobOp &o = p->ops[ii];
         const TDims in = d[o.src[0].tensor];
@@ -455,6 +487,10 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
         } else if (o.kind == OP_STEM || o.kind == OP_CONV) {
             const int t_ctotal = (int)p->tensors[o.dst].channels;
             float *aux = theta + p->aux_off[ii], *gaux = grad + p->aux_off[ii];
+            const int slot = n_conv & 1;
+            float *dy = dy_slot[slot];
+            if (p->side && n_conv >= 2) PF_HIP_CHECK(hipStreamWaitEvent(s, p->ev_wg[slot], 0));
+            ++n_conv;
             if (p->bn[ii]) {
                 const float *stat = reinterpret_cast<const float *>(wsb + L.stat[ii]);
                 if ((rc = launch_bn_backward(gradt(o.dst), act(o.dst), t_ctotal, (int)o.dst_choff, reinterpret_cast<const float *>(wsb + L.ypre[ii]),
@@ -466,28 +502,38 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
                 if ((rc = launch_bias_backward(gradt(o.dst), t_ctotal, (int)o.dst_choff, B, (int)o.cout, out.h, out.w, gaux, bnpart, dy, s))) return rc;
             }
             // dW
+            hipStream_t sw = s;
+            float *wpad_in = pad_in, *wpad_out = pad_out;
+            if (p->side) {
+                PF_HIP_CHECK(hipEventRecord(p->ev_dy[slot], s));
+                PF_HIP_CHECK(hipStreamWaitEvent(p->side, p->ev_dy[slot], 0));
+                sw = p->side;
+                wpad_in = reinterpret_cast<float *>(wsb + L.pad_in_w);
+                wpad_out = reinterpret_cast<float *>(wsb + L.pad_out_w);
+            }
             ConvArgs a;
             conv_args(o, in, out, a);
             if ((in.w & 3) != 0 && o.stride == 1) {
                 // odd width: the tiled kernel on padded copies of x (all ranges gathered) and dy; zero pad columns add nothing
                 const int Wp = (in.w + 3) / 4 * 4;
-                if ((rc = launch_pad_gather(a, B, Wp, pad_in, s))) return rc;
+                if ((rc = launch_pad_gather(a, B, Wp, wpad_in, sw))) return rc;
                 ConvArgs gdy;
                 memset(&gdy, 0, sizeof(gdy));
                 gdy.n_src = 1;
                 gdy.src[0] = dy; gdy.src_ctotal[0] = (int)o.cout; gdy.src_cstart[0] = 0;
                 for (int k = 1; k <= kConvMaxSrc; ++k) gdy.src_cstart[k] = (int)o.cout;
                 gdy.Cin = (int)o.cout; gdy.Hin = out.h; gdy.Win = out.w;
-                if ((rc = launch_pad_gather(gdy, B, Wp, pad_out, s))) return rc;
+                if ((rc = launch_pad_gather(gdy, B, Wp, wpad_out, sw))) return rc;
                 ConvArgs ap = a;
                 ap.n_src = 1;
-                ap.src[0] = pad_in; ap.src_ctotal[0] = (int)o.cin; ap.src_choff[0] = 0; ap.src_cstart[0] = 0;
+                ap.src[0] = wpad_in; ap.src_ctotal[0] = (int)o.cin; ap.src_choff[0] = 0; ap.src_cstart[0] = 0;
                 for (int k = 1; k <= kConvMaxSrc; ++k) ap.src_cstart[k] = (int)o.cin;
                 ap.Win = Wp; ap.Wout = Wp;
-                if ((rc = launch_wgrad(ap, (int)o.k, 1, pad_out, B, wpart, grad + p->w_off[ii], s))) return rc;
-            } else if ((rc = launch_wgrad(a, (int)o.k, (int)o.stride, dy, B, wpart, grad + p->w_off[ii], s))) {
+                if ((rc = launch_wgrad(ap, (int)o.k, 1, wpad_out, B, wpart, grad + p->w_off[ii], sw))) return rc;
+            } else if ((rc = launch_wgrad(a, (int)o.k, (int)o.stride, dy, B, wpart, grad + p->w_off[ii], sw))) {
                 return rc;
             }
+            if (p->side) PF_HIP_CHECK(hipEventRecord(p->ev_wg[slot], p->side));
             // dX per input range (the network input needs none)
             const float *dsrc = dy;
             if (o.stride == 2) {
@@ -516,6 +562,10 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
                 c0 += ch;
             }
         }
+    }
+    if (p->side && n_conv) {   // join: the caller's stream carries every gradient when this call's work is done
+        PF_HIP_CHECK(hipEventRecord(p->ev_join, p->side));
+        PF_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join, 0));
     }
     return PF_OK;
 }

@@ -760,7 +760,7 @@ extern "C" int pf_warp_splat(const float *depth, const uint8_t *depth_mask, cons
     {
         pf::ProfScope ps(s, "inv_mark_memset", 0, (double)L.mark_bytes);
         // zmax slots (ordered-u32 encoding: 0 is below every float) + invalid-point marks, contiguous
-        PF_HIP_CHECK(hipMemsetAsync(a.zmax_part, 0, (L.mark_off - L.zmax_off) + L.mark_bytes, s));
+        if (int rc = pf::launch_zero_fill(a.zmax_part, (L.mark_off - L.zmax_off) + L.mark_bytes, s)) return rc;
     }
     {
         pf::ProfScope ps(s, "pf::bin_kernel(pf::SplatArgs)", 0, src_px * (5.0 + (out_result2d ? 16.0 : 0.0)));

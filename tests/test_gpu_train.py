@@ -181,6 +181,30 @@ def test_gradient_accumulation_and_loss_scale():
     assert torch.equal(tr.grad, ga)
 
 
+@pytest.mark.parametrize('graph', [False, True])
+def test_weight_gradient_stream_and_graph_replays_change_no_bit(graph):
+    """training.weight_gradient_stream (library option train_side_stream: the weight gradients on the plan's own stream, forked
+    and joined inside the call) against everything on the caller's stream; eagerly, and captured + replayed four times."""
+    from panoptic_forecasting_amd.bg_train import BGTrainer
+    z, batches = _fixture()
+    a_in, a_lab = (_cuda(d) for d in batches[0])
+    got = {}
+    for side in (False, True):
+        tr = BGTrainer(_params(use_hip_graph=graph, weight_gradient_stream=side))
+        assert tr.side_stream == side and tr.use_graph == graph
+        tr.load_state_dict(_sd())
+        res = []
+        for _ in range(6):      # with the graph: eager, capture + replay, 4 more replays
+            tr.grad.fill_(3.0)
+            out = tr.forward_backward(a_in, a_lab, update_running_stats=False)
+            torch.cuda.synchronize()
+            res.append((tr.grad.clone(), float(out['loss'])))
+        for g, l in res[1:]:
+            assert torch.equal(g, res[0][0]) and l == res[0][1]
+        got[side] = res[0]
+    assert torch.equal(got[False][0], got[True][0]) and got[False][1] == got[True][1]
+
+
 @pytest.mark.parametrize('clip', ['norm', 'value', 'none'])
 def test_sgd_step_vs_torch(clip):
     import ctypes
