@@ -36,9 +36,9 @@ int launch_bn_forward(const float *y, int B, int C, int H, int W, float eps, flo
                       int dst_choff, int relu, hipStream_t s);
 int launch_bn_backward(const float *g, const float *z, int t_ctotal, int choff, const float *y, const float *mean, const float *invstd,
                        const float *gamma, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial, float *sums,
-                       float *dy, hipStream_t s);
+                       float *dy, int dy_pitch /* 0 = dense rows; else floats per row (>= W), pad columns zeroed */, hipStream_t s);
 int launch_bias_backward(const float *g, int t_ctotal, int choff, int B, int C, int H, int W, float *dbias, double *partial /* bn_partial_doubles(C) */,
-                         float *dy, hipStream_t s);
+                         float *dy, int dy_pitch /* as launch_bn_backward */, hipStream_t s);
 int wgrad_slabs(int cout, int cin, int B, int Hout, int Win, int Wout);
 size_t wgrad_partial_floats(int cout, int cin, int ks, int B, int Hout, int Win, int Wout);
 // a: the forward conv's arguments (sources, Cin/Cout, Hin/Win/Hout/Wout); dw (OIHW) accumulates
@@ -46,6 +46,8 @@ int launch_wgrad(const ConvArgs &a, int ks, int stride, const float *dy, int B, 
 // odd-width convs on copies with a row pitch rounded up to 4 (train_kernels.hip): all input ranges of `a` -> [B][Cin][Hin][Wp];
 // [B][C][H][Wp] -> channels [dst_choff, dst_choff + C) of a [B][dst_ctotal][H][W] tensor
 int launch_pad_gather(const ConvArgs &a, int B, int Wp, float *dst, hipStream_t s);
+int launch_unpad_scatter_multi(const float *src, int B, int C, int H, int W, int Wp, float *const *dst /* null = skip */, const int *ctotal,
+                               const int *choff, const int *ch, int n, hipStream_t s);
 int launch_unpad_scatter(const float *src, int B, int C, int H, int W, int Wp, float *dst, int dst_ctotal, int dst_choff, int accum, hipStream_t s);
 int launch_zero_stuff(const float *dy, int planes, int Hout, int Wout, int Hin, int Win, float *up, hipStream_t s);
 int launch_avgpool2_bwd(const float *gout, int planes, int Hin, int Win, float *gin, hipStream_t s);

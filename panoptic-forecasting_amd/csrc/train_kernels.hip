@@ -5,6 +5,8 @@
 //   weights, see train_plan.hip), average-pool / bilinear-upsample backward, bilinear-upsampled cross entropy with its
 //   gradient, global-norm / value clipping and SGD with momentum and weight decay.
 // All reductions are two-stage with fp64 partials in a fixed order: a step is bit-reproducible run to run.
+#include <cstring>
+
 #include "conv_epilogue.h"
 #include "pf_prof.h"
 #include "train_kernels.h"
@@ -423,9 +425,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *g, const
     dy[(long long)bc * HW + i] = gamma[c] * invstd[c] * (gp - sums[c] / n - xh * sums[C + c] / n);
 }
 
+// the same, dy written with a row pitch of Wp >= W floats and zeros in the pad columns: the layout the tiled convolutions of an
+// odd-width level read (launch_pad_gather's, without the copy)
+__global__ __launch_bounds__(256) void bn_bwd_apply_pitch_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
+                                                                 const float *mean, const float *invstd, const float *gamma, const float *sums,
+                                                                 int B, int C, int H, int W, int Wp, int relu, float *dy) {
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
+    const int ip = blockIdx.x * 256 + threadIdx.x;
+    if (ip >= H * Wp) return;
+    const int yy = ip / Wp, x = ip - yy * Wp;
+    float o = 0.f;
+    if (x < W) {
+        const long long HW = (long long)H * W, i = (long long)yy * W + x;
+        const float n = (float)((double)B * (double)HW);
+        const long long ti = ((long long)b * t_ctotal + choff + c) * HW + i;
+        const float gp = (!relu || z[ti] > 0.f) ? g[ti] : 0.f;
+        const float xh = (y[(long long)bc * HW + i] - mean[c]) * invstd[c];
+        o = gamma[c] * invstd[c] * (gp - sums[c] / n - xh * sums[C + c] / n);
+    }
+    dy[(long long)bc * H * Wp + ip] = o;
+}
+
 int launch_bn_backward(const float *g, const float *z, int t_ctotal, int choff, const float *y, const float *mean, const float *invstd,
                        const float *gamma, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial, float *sums,
-                       float *dy, hipStream_t s) {
+                       float *dy, int dy_pitch, hipStream_t s) {
     const long long HW = (long long)H * W;
     const bool vec = (HW & 3) == 0 && HW / 4 < (1ll << 31);
     if (vec)
@@ -434,7 +457,10 @@ int launch_bn_backward(const float *g, const float *z, int t_ctotal, int choff, 
     else
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd, B, C, HW, relu, partial);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, C, dgamma, dbeta, sums);
-    if (vec)
+    if (dy_pitch > 0 && dy_pitch != W)
+        hipLaunchKernelGGL(bn_bwd_apply_pitch_kernel, dim3((unsigned)((H * dy_pitch + 255) / 256), B * C), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean,
+                           invstd, gamma, sums, B, C, H, W, dy_pitch, relu, dy);
+    else if (vec)
         hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), B * C), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean,
                            invstd, gamma, sums, B, C, (int)(HW / 4), relu, dy);
     else
@@ -446,17 +472,17 @@ int launch_bn_backward(const float *g, const float *z, int t_ctotal, int choff, 
 
 // bias gradient of a conv without BN (finalConv): dbias[c] += sum over (b, pixels) of g; also copies g -> dy (contiguous).
 // Grid (C, kBnSlabs) with fp64 partials reduced in slab order (one block per channel took 0.49 ms for the 11 logit planes)
-__global__ __launch_bounds__(256) void bias_bwd_kernel(const float *g, int t_ctotal, int choff, int B, int C, long long HW, double *partial,
-                                                       float *dy) {
+__global__ __launch_bounds__(256) void bias_bwd_kernel(const float *g, int t_ctotal, int choff, int B, int C, long long HW, int W, int Wp,
+                                                       double *partial, float *dy) {
     const int c = blockIdx.x, slab = blockIdx.y;
     __shared__ double sm[4];
     double v[1] = {0.0};
     for (int b = 0; b < B; ++b) {
         const float *gp = g + ((long long)b * t_ctotal + choff + c) * HW;
-        float *dp = dy + ((long long)b * C + c) * HW;
+        float *dp = dy + ((long long)b * C + c) * (HW / W) * Wp;      // rows of Wp >= W floats (pad columns: zeroed by the launcher)
         for (long long p = (long long)slab * 256 + threadIdx.x; p < HW; p += (long long)kBnSlabs * 256) {
             const float x = gp[p];
-            dp[p] = x;
+            dp[W == Wp ? p : (p / W) * Wp + p % W] = x;
             v[0] += (double)x;
         }
     }
@@ -471,8 +497,13 @@ __global__ void bias_bwd_final_kernel(const double *partial, int C, float *dbias
     dbias[c] += (float)s;
 }
 int launch_bias_backward(const float *g, int t_ctotal, int choff, int B, int C, int H, int W, float *dbias, double *partial, float *dy,
-                         hipStream_t s) {
-    hipLaunchKernelGGL(bias_bwd_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, t_ctotal, choff, B, C, (long long)H * W, partial, dy);
+                         int dy_pitch, hipStream_t s) {
+    const int Wp = dy_pitch > 0 ? dy_pitch : W;
+    if (Wp != W) {
+        int rc = launch_zero_fill(dy, (size_t)B * C * H * Wp * sizeof(float), s);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(bias_bwd_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, t_ctotal, choff, B, C, (long long)H * W, W, Wp, partial, dy);
     hipLaunchKernelGGL(bias_bwd_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, C, dbias);
     PF_LAUNCH_CHECK("bias_bwd_kernel");
     return PF_OK;
@@ -800,6 +831,40 @@ __global__ __launch_bounds__(256) void unpad_scatter_kernel(const float *src, in
     float *d = dst + ((long long)b * dst_ctotal + dst_choff + c) * H * W + i;
     const float v = src[((long long)bc * H + y) * Wp + x];
     *d = accum ? *d + v : v;
+}
+// the result of ONE backward-data convolution over all input ranges of a layer ([B][C][H][Wp]) added to the gradient of each
+// range's tensor (a null destination - the network input - is skipped)
+struct ScatterArgs {
+    float *dst[kConvMaxSrc];
+    int ctotal[kConvMaxSrc], choff[kConvMaxSrc], cstart[kConvMaxSrc + 1], n;
+};
+__global__ __launch_bounds__(256) void unpad_scatter_multi_kernel(const float *src, int C, int H, int W, int Wp, ScatterArgs t) {
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    int j = 0;
+    while (j + 1 < t.n && c >= t.cstart[j + 1]) ++j;
+    if (!t.dst[j]) return;
+    const int y = i / W, x = i - y * W;
+    float *d = t.dst[j] + ((long long)b * t.ctotal[j] + t.choff[j] + (c - t.cstart[j])) * H * W + i;
+    *d += src[((long long)bc * H + y) * Wp + x];
+}
+int launch_unpad_scatter_multi(const float *src, int B, int C, int H, int W, int Wp, float *const *dst, const int *ctotal, const int *choff,
+                               const int *ch, int n, hipStream_t s) {
+    if (n < 1 || n > kConvMaxSrc) return fail(PF_EINVAL, "unpad_scatter_multi: %d ranges", n);
+    ScatterArgs t;
+    memset(&t, 0, sizeof(t));
+    t.n = n;
+    int c0 = 0;
+    for (int j = 0; j < n; ++j) {
+        t.dst[j] = dst[j]; t.ctotal[j] = ctotal[j]; t.choff[j] = choff[j]; t.cstart[j] = c0;
+        c0 += ch[j];
+    }
+    for (int j = n; j <= kConvMaxSrc; ++j) t.cstart[j] = c0;
+    if (c0 != C) return fail(PF_EINVAL, "unpad_scatter_multi: ranges cover %d of %d channels", c0, C);
+    hipLaunchKernelGGL(unpad_scatter_multi_kernel, dim3((unsigned)((H * W + 255) / 256), B * C), dim3(256), 0, s, src, C, H, W, Wp, t);
+    PF_LAUNCH_CHECK("unpad_scatter_multi_kernel");
+    return PF_OK;
 }
 int launch_pad_gather(const ConvArgs &a, int B, int Wp, float *dst, hipStream_t s) {
     PadGatherArgs g;

@@ -79,13 +79,14 @@ struct TLayout {
     std::vector<size_t> ypre, stat;    // per op: pre-BN conv output, {mean[cout], invstd[cout]}
     size_t dy = 0, wpk = 0, wpart = 0, dfull = 0, cepart = 0, bnpart = 0, sums = 0, out3 = 0, total = 0;
     size_t pad_in = 0, pad_out = 0;    // odd-width convs: gathered input / result with the row pitch rounded up to 4
-    size_t dy2 = 0, pad_in_w = 0, pad_out_w = 0;   // side stream: the second dy slot, the weight-gradient's own padded copies
+    size_t dy2 = 0, pad_in_w = 0;   // side stream: the second dy slot, the weight-gradient's own padded copy of x
     size_t grad_begin = 0, grad_end = 0;
     // every tiled weight packing of the step (forward convs in op order, then the backward-data convs of every op and input
     // range in op order): packed by ONE batch of launches at the start of the step into wpk_arena
     std::vector<PackJob> jobs;
     std::vector<int> fwd_job;                  // per op: its forward job, or -1
     std::vector<std::vector<int>> bwd_job;     // per op, per input range: its backward-data job, or -1 (the network input needs none)
+    std::vector<int> bwd_all_job;              // per op of an odd-width level: ONE backward-data conv over all input ranges, or -1
     size_t wpk_arena = 0;
 };
 
@@ -122,6 +123,7 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
         }
         // dy scratch: the conv-output gradient, and (stride 2) its zero-stuffed copy at the input resolution
         size_t need = ybytes;
+        if ((in.w & 3) && o.stride == 1) need = (size_t)B * o.cout * out.h * ((out.w + 3) / 4 * 4) * sizeof(float);   // written with padded rows
         if (o.stride == 2) need += align_up((size_t)B * o.cout * in.h * in.w * sizeof(float), 256);
         max_dy = need > max_dy ? need : max_dy;
         const ConvTiling tf = choose_tiling((int)o.k, (int)o.stride, (int)o.cin, (int)o.cout, 0);
@@ -153,6 +155,7 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
         const uint32_t input_t = p->ops[0].src[0].tensor;
         L.fwd_job.assign(p->ops.size(), -1);
         L.bwd_job.assign(p->ops.size(), std::vector<int>());
+        L.bwd_all_job.assign(p->ops.size(), -1);
         size_t arena = 0;
         auto add = [&](size_t w_off, int cin_f, int cout_f, int ks, int stride, const int *chs, int ns, int tflip, int c0, int ch) {
             PackJob q;
@@ -177,6 +180,10 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
             L.bwd_job[i].assign(o.n_src, -1);
             int c0 = 0;
             const int dy_ch = (int)o.cout;
+            if ((d[o.src[0].tensor].w & 3) && o.stride == 1) {
+                L.bwd_all_job[i] = add(p->w_off[i], (int)o.cin, (int)o.cout, (int)o.k, 1, &dy_ch, 1, 1, 0, (int)o.cin);
+                continue;
+            }
             for (uint32_t j = 0; j < o.n_src; ++j) {
                 if (o.src[j].tensor != input_t) L.bwd_job[i][j] = add(p->w_off[i], (int)o.cin, (int)o.cout, (int)o.k, 1, &dy_ch, 1, 1, c0, (int)o.src[j].ch);
                 c0 += (int)o.src[j].ch;
@@ -188,7 +195,6 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
     if (p->side) {
         L.dy2 = take(max_dy + 256);
         L.pad_in_w = take(max_pin);
-        L.pad_out_w = take(max_pout);
     }
     L.wpk = take(max_wpk * sizeof(float));
     L.wpart = take(max_wpart * sizeof(float));
@@ -489,47 +495,42 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
             float *aux = theta + p->aux_off[ii], *gaux = grad + p->aux_off[ii];
             const int slot = n_conv & 1;
             float *dy = dy_slot[slot];
+            // odd-width levels (stride 1): dy goes out with its rows padded to a multiple of 4 floats and zero pad columns - the
+            // form the tiled weight-gradient and backward-data kernels read - and ONE backward-data conv covers all input ranges
+            const bool odd = (in.w & 3) != 0 && o.stride == 1;
+            const int Wp = (in.w + 3) / 4 * 4;
             if (p->side && n_conv >= 2) PF_HIP_CHECK(hipStreamWaitEvent(s, p->ev_wg[slot], 0));
             ++n_conv;
             if (p->bn[ii]) {
                 const float *stat = reinterpret_cast<const float *>(wsb + L.stat[ii]);
                 if ((rc = launch_bn_backward(gradt(o.dst), act(o.dst), t_ctotal, (int)o.dst_choff, reinterpret_cast<const float *>(wsb + L.ypre[ii]),
                                              stat, stat + o.cout, aux, B, (int)o.cout, out.h, out.w, (int)o.relu, gaux, gaux + o.cout, bnpart, sums,
-                                             dy, s)))
+                                             dy, odd ? Wp : 0, s)))
                     return rc;
             } else {
                 if (o.relu) return fail(PF_EUNSUPPORTED, "training: ReLU without BatchNorm (op %zu)", ii);
-                if ((rc = launch_bias_backward(gradt(o.dst), t_ctotal, (int)o.dst_choff, B, (int)o.cout, out.h, out.w, gaux, bnpart, dy, s))) return rc;
+                if ((rc = launch_bias_backward(gradt(o.dst), t_ctotal, (int)o.dst_choff, B, (int)o.cout, out.h, out.w, gaux, bnpart, dy, odd ? Wp : 0, s))) return rc;
             }
             // dW
             hipStream_t sw = s;
-            float *wpad_in = pad_in, *wpad_out = pad_out;
+            float *wpad_in = pad_in;
             if (p->side) {
                 PF_HIP_CHECK(hipEventRecord(p->ev_dy[slot], s));
                 PF_HIP_CHECK(hipStreamWaitEvent(p->side, p->ev_dy[slot], 0));
                 sw = p->side;
                 wpad_in = reinterpret_cast<float *>(wsb + L.pad_in_w);
-                wpad_out = reinterpret_cast<float *>(wsb + L.pad_out_w);
             }
             ConvArgs a;
             conv_args(o, in, out, a);
-            if ((in.w & 3) != 0 && o.stride == 1) {
-                // odd width: the tiled kernel on padded copies of x (all ranges gathered) and dy; zero pad columns add nothing
-                const int Wp = (in.w + 3) / 4 * 4;
+            if (odd) {
+                // odd width: the tiled kernel on a padded copy of x (all ranges gathered) and the padded dy; zero pad columns add nothing
                 if ((rc = launch_pad_gather(a, B, Wp, wpad_in, sw))) return rc;
-                ConvArgs gdy;
-                memset(&gdy, 0, sizeof(gdy));
-                gdy.n_src = 1;
-                gdy.src[0] = dy; gdy.src_ctotal[0] = (int)o.cout; gdy.src_cstart[0] = 0;
-                for (int k = 1; k <= kConvMaxSrc; ++k) gdy.src_cstart[k] = (int)o.cout;
-                gdy.Cin = (int)o.cout; gdy.Hin = out.h; gdy.Win = out.w;
-                if ((rc = launch_pad_gather(gdy, B, Wp, wpad_out, sw))) return rc;
                 ConvArgs ap = a;
                 ap.n_src = 1;
                 ap.src[0] = wpad_in; ap.src_ctotal[0] = (int)o.cin; ap.src_choff[0] = 0; ap.src_cstart[0] = 0;
                 for (int k = 1; k <= kConvMaxSrc; ++k) ap.src_cstart[k] = (int)o.cin;
                 ap.Win = Wp; ap.Wout = Wp;
-                if ((rc = launch_wgrad(ap, (int)o.k, 1, wpad_out, B, wpart, grad + p->w_off[ii], sw))) return rc;
+                if ((rc = launch_wgrad(ap, (int)o.k, 1, dy, B, wpart, grad + p->w_off[ii], sw))) return rc;
             } else if ((rc = launch_wgrad(a, (int)o.k, (int)o.stride, dy, B, wpart, grad + p->w_off[ii], sw))) {
                 return rc;
             }
@@ -542,6 +543,36 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
                 for (uint32_t j = 0; j < o.n_src; ++j) needed = needed || o.src[j].tensor != input;
                 if (needed && (rc = launch_zero_stuff(dy, B * (int)o.cout, out.h, out.w, in.h, in.w, up, s))) return rc;
                 dsrc = up;
+            }
+            if (odd) {
+                const PackJob &q = L.jobs[L.bwd_all_job[ii]];
+                ConvArgs b;
+                memset(&b, 0, sizeof(b));
+                b.n_src = 1;
+                b.src[0] = dy; b.src_ctotal[0] = (int)o.cout; b.src_choff[0] = 0; b.src_cstart[0] = 0;
+                for (int k = 1; k <= kConvMaxSrc; ++k) b.src_cstart[k] = (int)o.cout;
+                b.bias = p->dev_zero; b.zero_page = p->dev_zero;
+                b.dst = pad_out; b.dst_ctotal = (int)o.cin; b.dst_choff = 0;
+                b.Cin = (int)o.cout; b.Cout = (int)o.cin; b.Hin = in.h; b.Win = Wp; b.Hout = in.h; b.Wout = Wp;
+                b.ntiles = ((int)o.cin + 15) / 16; b.src_end = 1;
+                b.wpk = wpk_arena + q.out_off;
+                const int kc = dma_kc((int)o.k, 1);
+                b.src_chunk0[0] = 0;
+                for (int j = 0; j < kConvMaxSrc; ++j) b.src_chunk0[j + 1] = j == 0 ? ((int)o.cout + kc - 1) / kc : b.src_chunk0[j];
+                b.nchunks = b.src_chunk0[1];
+                b.chunk_begin = 0;
+                b.chunk_end = b.nchunks;
+                if ((rc = launch_conv_dma(b, (int)o.k, 1, B, s))) return rc;
+                float *dsts[kMaxSrc];
+                int ct[kMaxSrc], co[kMaxSrc], chs[kMaxSrc];
+                for (uint32_t j = 0; j < o.n_src; ++j) {
+                    dsts[j] = o.src[j].tensor != input ? gradt(o.src[j].tensor) : nullptr;
+                    ct[j] = (int)p->tensors[o.src[j].tensor].channels;
+                    co[j] = (int)o.src[j].choff;
+                    chs[j] = (int)o.src[j].ch;
+                }
+                if ((rc = launch_unpad_scatter_multi(pad_out, B, (int)o.cin, in.h, in.w, Wp, dsts, ct, co, chs, (int)o.n_src, s))) return rc;
+                continue;
             }
             int c0 = 0;
             for (uint32_t j = 0; j < o.n_src; ++j) {
