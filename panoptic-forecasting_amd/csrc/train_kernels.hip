@@ -228,36 +228,72 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float *y, i
     }
 }
 
-// mean / invstd of the batch + running-stat update (nn.BatchNorm2d: momentum 0.1, unbiased variance in the running stat)
-__global__ void bn_stats_final_kernel(const double *partial, int C, double n, float eps, float momentum, float *mean, float *invstd,
-                                      float *running_mean, float *running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < kBnSlabs; ++k) {
-        s += partial[((long long)c * kBnSlabs + k) * 2 + 0];
-        q += partial[((long long)c * kBnSlabs + k) * 2 + 1];
+// The second pass of a BatchNorm (forward: statistics -> scale / shift; backward: sums -> dy) needs the channel's 64 slab
+// partials added up.  Every WAVE of the second-pass kernels does that itself - one partial pair per lane, a butterfly of
+// shuffles (a fixed order: every wave gets the same bits) - instead of a tiny kernel between the passes: 138 launches of ~5 us
+// fewer per training step, on the critical path of the backward chain.  One designated thread per channel (block x = 0 of
+// sample 0) writes what the step keeps (mean / invstd / running statistics; dgamma / dbeta).
+static_assert(kBnSlabs == 64, "one slab partial per lane");
+__device__ __forceinline__ void bn_wave_sums(const double *partial, int c, double &s, double &q) {
+    const double *p = partial + ((long long)c * kBnSlabs + (threadIdx.x & 63)) * 2;
+    s = p[0];
+    q = p[1];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
     }
-    const double m = s / n;
-    double var = q / n - m * m;
+}
+struct BnStats {        // forward statistics of one layer (kernel argument)
+    const double *partial;
+    double n;
+    float eps, momentum;
+    float *mean, *invstd, *running_mean, *running_var;   // running_*: null = leave them
+};
+// mean / invstd of the batch (+ running-stat update by the designated thread: nn.BatchNorm2d, momentum 0.1, unbiased variance
+// in the running stat).  Called by all lanes of a wave
+__device__ __forceinline__ void bn_finish_stats(const BnStats &st, int c, bool writer, float &mean_f, float &invstd_f) {
+    double s, q;
+    bn_wave_sums(st.partial, c, s, q);
+    const double m = s / st.n;
+    double var = q / st.n - m * m;
     var = var < 0.0 ? 0.0 : var;
-    mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
-        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    mean_f = (float)m;
+    invstd_f = (float)(1.0 / sqrt(var + (double)st.eps));
+    if (writer) {
+        st.mean[c] = mean_f;
+        st.invstd[c] = invstd_f;
+        if (st.running_mean) {
+            const double unbiased = st.n > 1.0 ? var * st.n / (st.n - 1.0) : var;
+            st.running_mean[c] = (float)((1.0 - st.momentum) * (double)st.running_mean[c] + st.momentum * m);
+            st.running_var[c] = (float)((1.0 - st.momentum) * (double)st.running_var[c] + st.momentum * unbiased);
+        }
+    }
+}
+
+// the channel's sums for the second backward pass (dbeta = sum g', dgamma = sum g' xhat, rounded to fp32 as the gradient arenas
+// hold them); the designated thread adds them to the arenas (zeroed once per step)
+__device__ __forceinline__ void bn_finish_bwd(const double *partial, int c, bool writer, float *dgamma, float *dbeta, float &s_f, float &q_f) {
+    double s, q;
+    bn_wave_sums(partial, c, s, q);
+    s_f = (float)s;
+    q_f = (float)q;
+    if (writer) {
+        dbeta[c] += s_f;
+        dgamma[c] += q_f;
     }
 }
 
 // z = relu(gamma * (y - mean) * invstd + beta) into channel slice [choff, choff + C) of the destination tensor
-__global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *y, const float *mean, const float *invstd, const float *gamma,
+__global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *y, BnStats st, const float *gamma,
                                                             const float *beta, int C, long long HW, float *dst, int dst_ctotal, int dst_choff,
                                                             int relu) {
     const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
     const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    float mean_c, invstd_c;
+    bn_finish_stats(st, c, blockIdx.x == 0 && b == 0 && threadIdx.x == 0, mean_c, invstd_c);
     if (i4 >= HW) return;
-    const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+    const float sc = gamma[c] * invstd_c, sh = beta[c] - mean_c * sc;
     const float *yp = y + (long long)bc * HW + i4;
     float *dp = dst + ((long long)b * dst_ctotal + dst_choff + c) * HW + i4;
 #pragma unroll
@@ -289,12 +325,14 @@ __global__ __launch_bounds__(256) void bn_stats_partial4_kernel(const float *y, 
         partial[((long long)c * kBnSlabs + slab) * 2 + 1] = v[1];
     }
 }
-__global__ __launch_bounds__(256) void bn_apply_relu4_kernel(const float *y, const float *mean, const float *invstd, const float *gamma,
+__global__ __launch_bounds__(256) void bn_apply_relu4_kernel(const float *y, BnStats st, const float *gamma,
                                                              const float *beta, int C, int HW4, float *dst, int dst_ctotal, int dst_choff, int relu) {
     const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    float mean_c, invstd_c;
+    bn_finish_stats(st, c, blockIdx.x == 0 && b == 0 && threadIdx.x == 0, mean_c, invstd_c);
     if (i >= HW4) return;
-    const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+    const float sc = gamma[c] * invstd_c, sh = beta[c] - mean_c * sc;
     tr_f32x4 v = reinterpret_cast<const tr_f32x4 *>(y)[(long long)bc * HW4 + i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -334,17 +372,19 @@ __global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float *g, co
     }
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
-                                                            const float *mean, const float *invstd, const float *gamma, const float *sums,
-                                                            int B, int C, int HW4, int relu, float *dy) {
+                                                            const float *mean, const float *invstd, const float *gamma, const double *partial,
+                                                            float *dgamma, float *dbeta, int B, int C, int HW4, int relu, float *dy) {
     const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    float sum_g, sum_gx;
+    bn_finish_bwd(partial, c, blockIdx.x == 0 && b == 0 && threadIdx.x == 0, dgamma, dbeta, sum_g, sum_gx);
     if (i >= HW4) return;
     const float n = (float)((double)B * 4.0 * (double)HW4);
     const long long ti = ((long long)b * t_ctotal + choff + c) * HW4 + i;
     const tr_f32x4 g4 = reinterpret_cast<const tr_f32x4 *>(g)[ti], y4 = reinterpret_cast<const tr_f32x4 *>(y)[(long long)bc * HW4 + i];
     tr_f32x4 z4 = tr_f32x4{1.f, 1.f, 1.f, 1.f};
     if (relu) z4 = reinterpret_cast<const tr_f32x4 *>(z)[ti];
-    const float mu = mean[c], is = invstd[c], ga = gamma[c], s0 = sums[c] / n, s1 = sums[C + c] / n;
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], s0 = sum_g / n, s1 = sum_gx / n;
     tr_f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -362,13 +402,12 @@ int launch_bn_forward(const float *y, int B, int C, int H, int W, float eps, flo
     const bool vec = (HW & 3) == 0 && HW / 4 < (1ll << 31);
     if (vec) hipLaunchKernelGGL(bn_stats_partial4_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, y, B, C, (int)(HW / 4), partial);
     else hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, y, B, C, HW, partial);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, C, (double)B * HW, eps, momentum, mean, invstd,
-                       running_mean, running_var);
+    const BnStats st{partial, (double)B * HW, eps, momentum, mean, invstd, running_mean, running_var};
     if (vec)
-        hipLaunchKernelGGL(bn_apply_relu4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), B * C), dim3(256), 0, s, y, mean, invstd, gamma, beta, C,
+        hipLaunchKernelGGL(bn_apply_relu4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), B * C), dim3(256), 0, s, y, st, gamma, beta, C,
                            (int)(HW / 4), dst, dst_ctotal, dst_choff, relu);
     else
-        hipLaunchKernelGGL(bn_apply_relu_kernel, dim3((unsigned)((HW / 4 + 256) / 256), B * C), dim3(256), 0, s, y, mean, invstd, gamma, beta, C, HW,
+        hipLaunchKernelGGL(bn_apply_relu_kernel, dim3((unsigned)((HW / 4 + 256) / 256), B * C), dim3(256), 0, s, y, st, gamma, beta, C, HW,
                            dst, dst_ctotal, dst_choff, relu);
     PF_LAUNCH_CHECK("bn_forward");
     return PF_OK;
@@ -399,39 +438,30 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *g, con
         partial[((long long)c * kBnSlabs + slab) * 2 + 1] = v[1];
     }
 }
-__global__ void bn_bwd_final_kernel(const double *partial, int C, float *dgamma, float *dbeta, float *sums /* [2][C] */) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < kBnSlabs; ++k) {
-        s += partial[((long long)c * kBnSlabs + k) * 2 + 0];
-        q += partial[((long long)c * kBnSlabs + k) * 2 + 1];
-    }
-    dbeta[c] += (float)s;      // gradient arenas accumulate (zeroed once per step)
-    dgamma[c] += (float)q;
-    sums[c] = (float)s;
-    sums[C + c] = (float)q;
-}
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
-                                                           const float *mean, const float *invstd, const float *gamma, const float *sums,
-                                                           int B, int C, long long HW, int relu, float *dy) {
+                                                           const float *mean, const float *invstd, const float *gamma, const double *partial,
+                                                           float *dgamma, float *dbeta, int B, int C, long long HW, int relu, float *dy) {
     const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float sum_g, sum_gx;
+    bn_finish_bwd(partial, c, blockIdx.x == 0 && b == 0 && threadIdx.x == 0, dgamma, dbeta, sum_g, sum_gx);
     if (i >= HW) return;
     const float n = (float)((double)B * (double)HW);
     const long long ti = ((long long)b * t_ctotal + choff + c) * HW + i;
     const float gp = (!relu || z[ti] > 0.f) ? g[ti] : 0.f;
     const float xh = (y[(long long)bc * HW + i] - mean[c]) * invstd[c];
-    dy[(long long)bc * HW + i] = gamma[c] * invstd[c] * (gp - sums[c] / n - xh * sums[C + c] / n);
+    dy[(long long)bc * HW + i] = gamma[c] * invstd[c] * (gp - sum_g / n - xh * sum_gx / n);
 }
 
 // the same, dy written with a row pitch of Wp >= W floats and zeros in the pad columns: the layout the tiled convolutions of an
 // odd-width level read (launch_pad_gather's, without the copy)
 __global__ __launch_bounds__(256) void bn_bwd_apply_pitch_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
-                                                                 const float *mean, const float *invstd, const float *gamma, const float *sums,
-                                                                 int B, int C, int H, int W, int Wp, int relu, float *dy) {
+                                                                 const float *mean, const float *invstd, const float *gamma, const double *partial,
+                                                                 float *dgamma, float *dbeta, int B, int C, int H, int W, int Wp, int relu, float *dy) {
     const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
     const int ip = blockIdx.x * 256 + threadIdx.x;
+    float sum_g, sum_gx;
+    bn_finish_bwd(partial, c, blockIdx.x == 0 && b == 0 && threadIdx.x == 0, dgamma, dbeta, sum_g, sum_gx);
     if (ip >= H * Wp) return;
     const int yy = ip / Wp, x = ip - yy * Wp;
     float o = 0.f;
@@ -441,14 +471,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pitch_kernel(const float *g,
         const long long ti = ((long long)b * t_ctotal + choff + c) * HW + i;
         const float gp = (!relu || z[ti] > 0.f) ? g[ti] : 0.f;
         const float xh = (y[(long long)bc * HW + i] - mean[c]) * invstd[c];
-        o = gamma[c] * invstd[c] * (gp - sums[c] / n - xh * sums[C + c] / n);
+        o = gamma[c] * invstd[c] * (gp - sum_g / n - xh * sum_gx / n);
     }
     dy[(long long)bc * H * Wp + ip] = o;
 }
 
 int launch_bn_backward(const float *g, const float *z, int t_ctotal, int choff, const float *y, const float *mean, const float *invstd,
-                       const float *gamma, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial, float *sums,
-                       float *dy, int dy_pitch, hipStream_t s) {
+                       const float *gamma, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial, float *dy,
+                       int dy_pitch, hipStream_t s) {
     const long long HW = (long long)H * W;
     const bool vec = (HW & 3) == 0 && HW / 4 < (1ll << 31);
     if (vec)
@@ -456,16 +486,15 @@ int launch_bn_backward(const float *g, const float *z, int t_ctotal, int choff, 
                            relu, partial);
     else
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd, B, C, HW, relu, partial);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, C, dgamma, dbeta, sums);
     if (dy_pitch > 0 && dy_pitch != W)
         hipLaunchKernelGGL(bn_bwd_apply_pitch_kernel, dim3((unsigned)((H * dy_pitch + 255) / 256), B * C), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean,
-                           invstd, gamma, sums, B, C, H, W, dy_pitch, relu, dy);
+                           invstd, gamma, partial, dgamma, dbeta, B, C, H, W, dy_pitch, relu, dy);
     else if (vec)
         hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), B * C), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean,
-                           invstd, gamma, sums, B, C, (int)(HW / 4), relu, dy);
+                           invstd, gamma, partial, dgamma, dbeta, B, C, (int)(HW / 4), relu, dy);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((HW + 255) / 256), B * C), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd,
-                           gamma, sums, B, C, HW, relu, dy);
+                           gamma, partial, dgamma, dbeta, B, C, HW, relu, dy);
     PF_LAUNCH_CHECK("bn_backward");
     return PF_OK;
 }

@@ -27,6 +27,14 @@
 
 using namespace pf;
 
+#ifndef PF_TRAIN_SIDE_STREAMS
+#define PF_TRAIN_SIDE_STREAMS 1
+#endif
+#ifndef PF_TRAIN_DY_SLOTS
+#define PF_TRAIN_DY_SLOTS 4
+#endif
+static_assert(PF_TRAIN_DY_SLOTS % PF_TRAIN_SIDE_STREAMS == 0, "a dy slot belongs to one side stream");
+
 struct pf_train {
     BlobHeader hdr;
     std::vector<BlobTensor> tensors;
@@ -38,8 +46,12 @@ struct pf_train {
     // the weight gradients are leaves of the backward pass: they run on this plan's own lower-priority stream, forked from and
     // joined to the caller's stream inside every pf_train_forward_backward (so a stream capture of the call stays one graph).
     // Option "train_side_stream" (read when the plan is created; 0 = everything on the caller's stream)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_dy[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr}, ev_join = nullptr;
+    // kSideStreams of them, layer n on stream n % kSideStreams; kDySlots conv-output-gradient buffers decouple the two sides:
+    // the caller's stream may run kDySlots layers ahead of the weight gradients
+    static constexpr int kSideStreams = PF_TRAIN_SIDE_STREAMS, kDySlots = PF_TRAIN_DY_SLOTS;
+    hipStream_t side = nullptr;             // == sides[0]; non-null <=> the side streams are in use
+    hipStream_t sides[kSideStreams] = {};
+    hipEvent_t ev_dy[kDySlots] = {}, ev_wg[kDySlots] = {}, ev_join[kSideStreams] = {};
 };
 
 namespace pf {
@@ -77,9 +89,9 @@ int t_propagate(const pf_train *p, int H, int W, std::vector<TDims> &d) {
 struct TLayout {
     std::vector<size_t> act, grad;     // per tensor (bytes); act[input] = the dense one-hot/depth tensor
     std::vector<size_t> ypre, stat;    // per op: pre-BN conv output, {mean[cout], invstd[cout]}
-    size_t dy = 0, wpk = 0, wpart = 0, dfull = 0, cepart = 0, bnpart = 0, sums = 0, out3 = 0, total = 0;
+    size_t dy = 0, wpk = 0, wpart = 0, dfull = 0, cepart = 0, bnpart = 0, out3 = 0, total = 0;
     size_t pad_in = 0, pad_out = 0;    // odd-width convs: gathered input / result with the row pitch rounded up to 4
-    size_t dy2 = 0, pad_in_w = 0;   // side stream: the second dy slot, the weight-gradient's own padded copy of x
+    size_t dy_more[pf_train::kDySlots] = {}, pad_in_w[pf_train::kSideStreams] = {}, wpart_more[pf_train::kSideStreams] = {};   // side streams: further dy slots, per stream the padded copy of x and the partial sums
     size_t grad_begin = 0, grad_end = 0;
     // every tiled weight packing of the step (forward convs in op order, then the backward-data convs of every op and input
     // range in op order): packed by ONE batch of launches at the start of the step into wpk_arena
@@ -193,17 +205,18 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
     }
     L.dy = take(max_dy + 256);
     if (p->side) {
-        L.dy2 = take(max_dy + 256);
-        L.pad_in_w = take(max_pin);
+        for (int k = 1; k < pf_train::kDySlots; ++k) L.dy_more[k] = take(max_dy + 256);
+        for (int k = 0; k < pf_train::kSideStreams; ++k) L.pad_in_w[k] = take(max_pin);
     }
     L.wpk = take(max_wpk * sizeof(float));
     L.wpart = take(max_wpart * sizeof(float));
+    if (p->side)
+        for (int k = 1; k < pf_train::kSideStreams; ++k) L.wpart_more[k] = take(max_wpart * sizeof(float));
     L.pad_in = take(max_pin);
     L.pad_out = take(max_pout);
     L.dfull = take((size_t)B * p->hdr.n_cls * out_h * out_w * sizeof(float));
     L.cepart = take(ce_partial_doubles(B, out_h, out_w) * sizeof(double));
     L.bnpart = take(bn_partial_doubles((int)max_c) * sizeof(double));
-    L.sums = take(2 * max_c * sizeof(float));
     L.out3 = take(4 * sizeof(double));
     L.total = cur;
     return L;
@@ -262,9 +275,12 @@ extern "C" int pf_train_create(const void *blob, size_t bytes, int in_ch, int n_
     }
     if (g_opt_train_side) {
         int lo = 0, hi = 0;
-        bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, lo) == hipSuccess;
-        hipEvent_t *evs[5] = {&p->ev_dy[0], &p->ev_dy[1], &p->ev_wg[0], &p->ev_wg[1], &p->ev_join};
-        for (int i = 0; ok && i < 5; ++i) ok = hipEventCreateWithFlags(evs[i], hipEventDisableTiming) == hipSuccess;
+        bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+        for (int k = 0; ok && k < pf_train::kSideStreams; ++k) ok = hipStreamCreateWithPriority(&p->sides[k], hipStreamNonBlocking, lo) == hipSuccess;
+        p->side = p->sides[0];
+        for (int k = 0; ok && k < pf_train::kDySlots; ++k)
+            ok = hipEventCreateWithFlags(&p->ev_dy[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&p->ev_wg[k], hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; ok && k < pf_train::kSideStreams; ++k) ok = hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             pf_train_destroy(p);
             return fail(PF_EHIP, "pf_train_create: could not create the weight-gradient stream");
@@ -276,9 +292,14 @@ extern "C" int pf_train_create(const void *blob, size_t bytes, int in_ch, int n_
 
 extern "C" void pf_train_destroy(pf_train *p) {
     if (!p) return;
-    for (hipEvent_t e : {p->ev_dy[0], p->ev_dy[1], p->ev_wg[0], p->ev_wg[1], p->ev_join})
-        if (e) (void)hipEventDestroy(e);
-    if (p->side) (void)hipStreamDestroy(p->side);
+    for (int k = 0; k < pf_train::kDySlots; ++k) {
+        if (p->ev_dy[k]) (void)hipEventDestroy(p->ev_dy[k]);
+        if (p->ev_wg[k]) (void)hipEventDestroy(p->ev_wg[k]);
+    }
+    for (int k = 0; k < pf_train::kSideStreams; ++k) {
+        if (p->ev_join[k]) (void)hipEventDestroy(p->ev_join[k]);
+        if (p->sides[k]) (void)hipStreamDestroy(p->sides[k]);
+    }
     if (p->dev_zero) (void)hipFree(p->dev_zero);
     delete p;
 }
@@ -344,14 +365,14 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
     auto gradt = [&](uint32_t t) { return reinterpret_cast<float *>(wsb + L.grad[t]); };
     const uint32_t input = p->ops[0].src[0].tensor;
     const int in_ch = (int)p->tensors[input].channels, n_cls = (int)p->hdr.n_cls;
-    float *const dy_slot[2] = {reinterpret_cast<float *>(wsb + L.dy), reinterpret_cast<float *>(wsb + (p->side ? L.dy2 : L.dy))};
+    float *dy_slot[pf_train::kDySlots];
+    for (int k = 0; k < pf_train::kDySlots; ++k) dy_slot[k] = reinterpret_cast<float *>(wsb + (p->side && k ? L.dy_more[k] : L.dy));
     float *wpk = reinterpret_cast<float *>(wsb + L.wpk);
     float *wpart = reinterpret_cast<float *>(wsb + L.wpart);
     float *pad_in = reinterpret_cast<float *>(wsb + L.pad_in), *pad_out = reinterpret_cast<float *>(wsb + L.pad_out);
     float *dfull = reinterpret_cast<float *>(wsb + L.dfull);
     double *cepart = reinterpret_cast<double *>(wsb + L.cepart);
     double *bnpart = reinterpret_cast<double *>(wsb + L.bnpart);
-    float *sums = reinterpret_cast<float *>(wsb + L.sums);
     double *loss3 = reinterpret_cast<double *>(wsb + L.out3);
 
     // ---- input tensor (bg_model.py:61-69)
@@ -475,9 +496,9 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
     }
 
     // ================================================================ backward
-    // With the side stream: layer n's conv-output gradient goes to dy slot n & 1; the weight gradient (and its padded copies)
-    // reads it on the side stream while the caller's stream goes on to the input gradients and the next layer, whose own dy
-    // waits for the weight gradient of layer n - 1 ... n - 2 that last read its slot.
+    // With the side streams: layer n's conv-output gradient goes to dy slot n % kDySlots; the weight gradient (and its padded
+    // copy of x) reads it on side stream n % kSideStreams while the caller's stream goes on to the input gradients and the next
+    // layers; before it overwrites a slot it waits for the weight gradient of layer n - kDySlots that last read it.
     int n_conv = 0;
     for (size_t ii = p->ops.size(); ii-- > 0;) {
         const BlobOp &o = p->ops[ii];
@@ -493,18 +514,18 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
         } else if (o.kind == OP_STEM || o.kind == OP_CONV) {
             const int t_ctotal = (int)p->tensors[o.dst].channels;
             float *aux = theta + p->aux_off[ii], *gaux = grad + p->aux_off[ii];
-            const int slot = n_conv & 1;
+            const int slot = n_conv % pf_train::kDySlots, sidx = n_conv % pf_train::kSideStreams;
             float *dy = dy_slot[slot];
             // odd-width levels (stride 1): dy goes out with its rows padded to a multiple of 4 floats and zero pad columns - the
             // form the tiled weight-gradient and backward-data kernels read - and ONE backward-data conv covers all input ranges
             const bool odd = (in.w & 3) != 0 && o.stride == 1;
             const int Wp = (in.w + 3) / 4 * 4;
-            if (p->side && n_conv >= 2) PF_HIP_CHECK(hipStreamWaitEvent(s, p->ev_wg[slot], 0));
+            if (p->side && n_conv >= pf_train::kDySlots) PF_HIP_CHECK(hipStreamWaitEvent(s, p->ev_wg[slot], 0));
             ++n_conv;
             if (p->bn[ii]) {
                 const float *stat = reinterpret_cast<const float *>(wsb + L.stat[ii]);
                 if ((rc = launch_bn_backward(gradt(o.dst), act(o.dst), t_ctotal, (int)o.dst_choff, reinterpret_cast<const float *>(wsb + L.ypre[ii]),
-                                             stat, stat + o.cout, aux, B, (int)o.cout, out.h, out.w, (int)o.relu, gaux, gaux + o.cout, bnpart, sums,
+                                             stat, stat + o.cout, aux, B, (int)o.cout, out.h, out.w, (int)o.relu, gaux, gaux + o.cout, bnpart,
                                              dy, odd ? Wp : 0, s)))
                     return rc;
             } else {
@@ -513,12 +534,13 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
             }
             // dW
             hipStream_t sw = s;
-            float *wpad_in = pad_in;
+            float *wpad_in = pad_in, *wpart_l = wpart;
             if (p->side) {
                 PF_HIP_CHECK(hipEventRecord(p->ev_dy[slot], s));
-                PF_HIP_CHECK(hipStreamWaitEvent(p->side, p->ev_dy[slot], 0));
-                sw = p->side;
-                wpad_in = reinterpret_cast<float *>(wsb + L.pad_in_w);
+                sw = p->sides[sidx];
+                PF_HIP_CHECK(hipStreamWaitEvent(sw, p->ev_dy[slot], 0));
+                wpad_in = reinterpret_cast<float *>(wsb + L.pad_in_w[sidx]);
+                if (sidx) wpart_l = reinterpret_cast<float *>(wsb + L.wpart_more[sidx]);
             }
             ConvArgs a;
             conv_args(o, in, out, a);
@@ -530,11 +552,11 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
                 ap.src[0] = wpad_in; ap.src_ctotal[0] = (int)o.cin; ap.src_choff[0] = 0; ap.src_cstart[0] = 0;
                 for (int k = 1; k <= kConvMaxSrc; ++k) ap.src_cstart[k] = (int)o.cin;
                 ap.Win = Wp; ap.Wout = Wp;
-                if ((rc = launch_wgrad(ap, (int)o.k, 1, dy, B, wpart, grad + p->w_off[ii], sw))) return rc;
-            } else if ((rc = launch_wgrad(a, (int)o.k, (int)o.stride, dy, B, wpart, grad + p->w_off[ii], sw))) {
+                if ((rc = launch_wgrad(ap, (int)o.k, 1, dy, B, wpart_l, grad + p->w_off[ii], sw))) return rc;
+            } else if ((rc = launch_wgrad(a, (int)o.k, (int)o.stride, dy, B, wpart_l, grad + p->w_off[ii], sw))) {
                 return rc;
             }
-            if (p->side) PF_HIP_CHECK(hipEventRecord(p->ev_wg[slot], p->side));
+            if (p->side) PF_HIP_CHECK(hipEventRecord(p->ev_wg[slot], sw));
             // dX per input range (the network input needs none)
             const float *dsrc = dy;
             if (o.stride == 2) {
@@ -595,8 +617,10 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
         }
     }
     if (p->side && n_conv) {   // join: the caller's stream carries every gradient when this call's work is done
-        PF_HIP_CHECK(hipEventRecord(p->ev_join, p->side));
-        PF_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join, 0));
+        for (int k = 0; k < pf_train::kSideStreams && k < n_conv; ++k) {   // (a stream that got no layer was never forked)
+            PF_HIP_CHECK(hipEventRecord(p->ev_join[k], p->sides[k]));
+            PF_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join[k], 0));
+        }
     }
     return PF_OK;
 }

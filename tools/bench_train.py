@@ -25,8 +25,11 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--graph', action='store_true', help='training.use_hip_graph: replay a captured step (one stream) instead of eager launches')
     ap.add_argument('--no-side-stream', action='store_true', help='training.weight_gradient_stream = False: weight gradients on the caller\'s stream')
+    ap.add_argument('--lib', default='', help='another build of libpfhip.so (A/B runs)')
     ap.add_argument('--out', default='', help='also write the JSON line here')
     a = ap.parse_args()
+    if a.lib:
+        pflib.LIB_PATH = os.path.abspath(a.lib)
     params = {'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])]},
               'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True},
               'training': {'lr': 2e-3, 'mom': 0.9, 'wd': 1e-4, 'clip_grad_norm': 5.0, 'use_hip_graph': a.graph, 'weight_gradient_stream': not (a.graph or a.no_side_stream)}}
