@@ -34,8 +34,8 @@ size_t bn_partial_doubles(int C);
 int launch_bn_forward(const float *y, int B, int C, int H, int W, float eps, float momentum, const float *gamma, const float *beta,
                       float *running_mean, float *running_var, float *mean, float *invstd, double *partial, float *dst, int dst_ctotal,
                       int dst_choff, int relu, hipStream_t s);
-int launch_bn_backward(const float *g, const float *z, int t_ctotal, int choff, const float *y, const float *mean, const float *invstd,
-                       const float *gamma, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial,
+int launch_bn_backward(const float *g, int t_ctotal, int choff, const float *y, const float *mean, const float *invstd,
+                       const float *gamma, const float *beta, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial,
                        float *dy, int dy_pitch /* 0 = dense rows; else floats per row (>= W), pad columns zeroed */, hipStream_t s);
 int launch_bias_backward(const float *g, int t_ctotal, int choff, int B, int C, int H, int W, float *dbias, double *partial /* bn_partial_doubles(C) */,
                          float *dy, int dy_pitch /* as launch_bn_backward */, hipStream_t s);

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *y, BnSt
     for (int k = 0; k < 4; ++k)
         if (i4 + k < HW) {
             // (y - mean) * invstd * gamma + beta, written as one scale/shift like ATen's batch_norm CPU/CUDA transforms
-            float v = yp[k] * sc + sh;
+            float v = __builtin_fmaf(yp[k], sc, sh);      // (the backward pass redoes exactly this to know where the ReLU cut)
             dp[k] = relu ? fmaxf(v, 0.f) : v;
         }
 }
@@ -336,28 +336,29 @@ __global__ __launch_bounds__(256) void bn_apply_relu4_kernel(const float *y, BnS
     tr_f32x4 v = reinterpret_cast<const tr_f32x4 *>(y)[(long long)bc * HW4 + i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        v[k] = v[k] * sc + sh;
+        v[k] = __builtin_fmaf(v[k], sc, sh);
         if (relu) v[k] = fmaxf(v[k], 0.f);
     }
     reinterpret_cast<tr_f32x4 *>(dst)[((long long)b * dst_ctotal + dst_choff + c) * HW4 + i] = v;
 }
-__global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
-                                                              const float *mean, const float *invstd, int B, int C, int HW4, int relu,
-                                                              double *partial) {
+// Where the ReLU cut (z = relu(fma(y, sc, sh)) <= 0) is recomputed from y, which these kernels read anyway, with the forward
+// pass's own instruction - the stored activation is not read again (2 of the 7 tensor passes of a BatchNorm backward)
+__global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float *g, const float *gamma, const float *beta, int t_ctotal, int choff,
+                                                              const float *y, const float *mean, const float *invstd, int B, int C, int HW4,
+                                                              int relu, double *partial) {
     const int c = blockIdx.x, slab = blockIdx.y;
     __shared__ double sm[2 * 4];
     double v[2] = {0.0, 0.0};
     const float mu = mean[c], is = invstd[c];
+    const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
     for (int b = 0; b < B; ++b) {
         const long long ti = ((long long)b * t_ctotal + choff + c) * HW4, yi = ((long long)b * C + c) * HW4;
         for (int i = slab * 256 + threadIdx.x; i < HW4; i += kBnSlabs * 256) {
             const tr_f32x4 g4 = reinterpret_cast<const tr_f32x4 *>(g)[ti + i], y4 = reinterpret_cast<const tr_f32x4 *>(y)[yi + i];
-            tr_f32x4 z4 = tr_f32x4{1.f, 1.f, 1.f, 1.f};
-            if (relu) z4 = reinterpret_cast<const tr_f32x4 *>(z)[ti + i];
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float gp = z4[k] > 0.f ? g4[k] : 0.f;
+                const float gp = (!relu || __builtin_fmaf(y4[k], sc, sh) > 0.f) ? g4[k] : 0.f;
                 s0 += gp;
                 s1 += gp * ((y4[k] - mu) * is);
             }
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float *g, co
         partial[((long long)c * kBnSlabs + slab) * 2 + 1] = v[1];
     }
 }
-__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float *g, const float *beta, int t_ctotal, int choff, const float *y,
                                                             const float *mean, const float *invstd, const float *gamma, const double *partial,
                                                             float *dgamma, float *dbeta, int B, int C, int HW4, int relu, float *dy) {
     const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
@@ -382,13 +383,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float *g, cons
     const float n = (float)((double)B * 4.0 * (double)HW4);
     const long long ti = ((long long)b * t_ctotal + choff + c) * HW4 + i;
     const tr_f32x4 g4 = reinterpret_cast<const tr_f32x4 *>(g)[ti], y4 = reinterpret_cast<const tr_f32x4 *>(y)[(long long)bc * HW4 + i];
-    tr_f32x4 z4 = tr_f32x4{1.f, 1.f, 1.f, 1.f};
-    if (relu) z4 = reinterpret_cast<const tr_f32x4 *>(z)[ti];
     const float mu = mean[c], is = invstd[c], ga = gamma[c], s0 = sum_g / n, s1 = sum_gx / n;
+    const float sc = ga * is, sh = beta[c] - mu * sc;
     tr_f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float gp = z4[k] > 0.f ? g4[k] : 0.f;
+        const float gp = (!relu || __builtin_fmaf(y4[k], sc, sh) > 0.f) ? g4[k] : 0.f;
         const float xh = (y4[k] - mu) * is;
         o[k] = ga * is * (gp - s0 - xh * s1);       // the scalar kernel's expression, term for term
     }
@@ -416,19 +416,21 @@ size_t bn_partial_doubles(int C) { return (size_t)C * kBnSlabs * 2; }
 
 // backward through ReLU + BN:  g' = g * [z > 0];  dbeta = sum g';  dgamma = sum g' * xhat;
 //                              dy = gamma * invstd * (g' - dbeta / N - xhat * dgamma / N)
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
-                                                             const float *mean, const float *invstd, int B, int C, long long HW, int relu,
-                                                             double *partial) {
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *g, const float *gamma, const float *beta, int t_ctotal, int choff,
+                                                             const float *y, const float *mean, const float *invstd, int B, int C, long long HW,
+                                                             int relu, double *partial) {
     const int c = blockIdx.x, slab = blockIdx.y;
     __shared__ double sm[2 * 4];
     double v[2] = {0.0, 0.0};
     const long long per = (long long)B * HW;
     const float mu = mean[c], is = invstd[c];
+    const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
     for (long long i = (long long)slab * 256 + threadIdx.x; i < per; i += (long long)kBnSlabs * 256) {
         const long long b = i / HW, p = i - b * HW;
         const long long ti = ((long long)b * t_ctotal + choff + c) * HW + p;
-        const float gp = (!relu || z[ti] > 0.f) ? g[ti] : 0.f;
-        const float xh = (y[((long long)b * C + c) * HW + p] - mu) * is;
+        const float yv = y[((long long)b * C + c) * HW + p];
+        const float gp = (!relu || __builtin_fmaf(yv, sc, sh) > 0.f) ? g[ti] : 0.f;
+        const float xh = (yv - mu) * is;
         v[0] += (double)gp;
         v[1] += (double)gp * (double)xh;
     }
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *g, con
         partial[((long long)c * kBnSlabs + slab) * 2 + 1] = v[1];
     }
 }
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *g, const float *beta, int t_ctotal, int choff, const float *y,
                                                            const float *mean, const float *invstd, const float *gamma, const double *partial,
                                                            float *dgamma, float *dbeta, int B, int C, long long HW, int relu, float *dy) {
     const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
@@ -448,14 +450,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *g, const
     if (i >= HW) return;
     const float n = (float)((double)B * (double)HW);
     const long long ti = ((long long)b * t_ctotal + choff + c) * HW + i;
-    const float gp = (!relu || z[ti] > 0.f) ? g[ti] : 0.f;
-    const float xh = (y[(long long)bc * HW + i] - mean[c]) * invstd[c];
+    const float yv = y[(long long)bc * HW + i], sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+    const float gp = (!relu || __builtin_fmaf(yv, sc, sh) > 0.f) ? g[ti] : 0.f;
+    const float xh = (yv - mean[c]) * invstd[c];
     dy[(long long)bc * HW + i] = gamma[c] * invstd[c] * (gp - sum_g / n - xh * sum_gx / n);
 }
 
 // the same, dy written with a row pitch of Wp >= W floats and zeros in the pad columns: the layout the tiled convolutions of an
 // odd-width level read (launch_pad_gather's, without the copy)
-__global__ __launch_bounds__(256) void bn_bwd_apply_pitch_kernel(const float *g, const float *z, int t_ctotal, int choff, const float *y,
+__global__ __launch_bounds__(256) void bn_bwd_apply_pitch_kernel(const float *g, const float *beta, int t_ctotal, int choff, const float *y,
                                                                  const float *mean, const float *invstd, const float *gamma, const double *partial,
                                                                  float *dgamma, float *dbeta, int B, int C, int H, int W, int Wp, int relu, float *dy) {
     const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
@@ -469,31 +472,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pitch_kernel(const float *g,
         const long long HW = (long long)H * W, i = (long long)yy * W + x;
         const float n = (float)((double)B * (double)HW);
         const long long ti = ((long long)b * t_ctotal + choff + c) * HW + i;
-        const float gp = (!relu || z[ti] > 0.f) ? g[ti] : 0.f;
-        const float xh = (y[(long long)bc * HW + i] - mean[c]) * invstd[c];
+        const float yv = y[(long long)bc * HW + i], sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+        const float gp = (!relu || __builtin_fmaf(yv, sc, sh) > 0.f) ? g[ti] : 0.f;
+        const float xh = (yv - mean[c]) * invstd[c];
         o = gamma[c] * invstd[c] * (gp - sum_g / n - xh * sum_gx / n);
     }
     dy[(long long)bc * H * Wp + ip] = o;
 }
 
-int launch_bn_backward(const float *g, const float *z, int t_ctotal, int choff, const float *y, const float *mean, const float *invstd,
-                       const float *gamma, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial, float *dy,
+int launch_bn_backward(const float *g, int t_ctotal, int choff, const float *y, const float *mean, const float *invstd,
+                       const float *gamma, const float *beta, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial, float *dy,
                        int dy_pitch, hipStream_t s) {
     const long long HW = (long long)H * W;
     const bool vec = (HW & 3) == 0 && HW / 4 < (1ll << 31);
     if (vec)
-        hipLaunchKernelGGL(bn_bwd_partial4_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd, B, C, (int)(HW / 4),
-                           relu, partial);
+        hipLaunchKernelGGL(bn_bwd_partial4_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, gamma, beta, t_ctotal, choff, y, mean, invstd, B, C,
+                           (int)(HW / 4), relu, partial);
     else
-        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd, B, C, HW, relu, partial);
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, gamma, beta, t_ctotal, choff, y, mean, invstd, B, C, HW, relu,
+                           partial);
     if (dy_pitch > 0 && dy_pitch != W)
-        hipLaunchKernelGGL(bn_bwd_apply_pitch_kernel, dim3((unsigned)((H * dy_pitch + 255) / 256), B * C), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean,
+        hipLaunchKernelGGL(bn_bwd_apply_pitch_kernel, dim3((unsigned)((H * dy_pitch + 255) / 256), B * C), dim3(256), 0, s, g, beta, t_ctotal, choff, y, mean,
                            invstd, gamma, partial, dgamma, dbeta, B, C, H, W, dy_pitch, relu, dy);
     else if (vec)
-        hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), B * C), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean,
+        hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), B * C), dim3(256), 0, s, g, beta, t_ctotal, choff, y, mean,
                            invstd, gamma, partial, dgamma, dbeta, B, C, (int)(HW / 4), relu, dy);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((HW + 255) / 256), B * C), dim3(256), 0, s, g, z, t_ctotal, choff, y, mean, invstd,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((HW + 255) / 256), B * C), dim3(256), 0, s, g, beta, t_ctotal, choff, y, mean, invstd,
                            gamma, partial, dgamma, dbeta, B, C, HW, relu, dy);
     PF_LAUNCH_CHECK("bn_backward");
     return PF_OK;

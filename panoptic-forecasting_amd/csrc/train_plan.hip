@@ -524,8 +524,8 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
             ++n_conv;
             if (p->bn[ii]) {
                 const float *stat = reinterpret_cast<const float *>(wsb + L.stat[ii]);
-                if ((rc = launch_bn_backward(gradt(o.dst), act(o.dst), t_ctotal, (int)o.dst_choff, reinterpret_cast<const float *>(wsb + L.ypre[ii]),
-                                             stat, stat + o.cout, aux, B, (int)o.cout, out.h, out.w, (int)o.relu, gaux, gaux + o.cout, bnpart,
+                if ((rc = launch_bn_backward(gradt(o.dst), t_ctotal, (int)o.dst_choff, reinterpret_cast<const float *>(wsb + L.ypre[ii]),
+                                             stat, stat + o.cout, aux, aux + o.cout, B, (int)o.cout, out.h, out.w, (int)o.relu, gaux, gaux + o.cout, bnpart,
                                              dy, odd ? Wp : 0, s)))
                     return rc;
             } else {
