@@ -790,7 +790,10 @@ static bool wgrad_tiled_ok(int Win, int Wout) { return (Win & 3) == 0 && (Wout &
 int wgrad_slabs(int cout, int cin, int B, int Hout, int Win, int Wout) {
     const bool tiled = wgrad_tiled_ok(Win, Wout);
     const long long tiles = (long long)(tiled ? (cout + 31) / 32 : (cout + 15) / 16) * ((cin + 15) / 16);
-    long long s = (tiled ? 1024 : 2048) / tiles;     // tiled: 2 workgroups per CU resident, 2 rounds
+    // tiled: 512 workgroups per layer (2 per CU).  1024 gave each kernel more latency hiding alone, but twice the partial sums to
+    // write and reduce, beside a backward chain that fills the other half of the chip anyway: 16.45 -> 16.2 ms per step (256: 17.9,
+    // 384: 16.7, 768: 16.65 - same-box runs, profiles/r04_experiments.md)
+    long long s = (tiled ? 512 : 2048) / tiles;
     s = s < 1 ? 1 : s;
     const long long units = tiled ? (long long)B * Hout * ((Wout + 63) / 64) : (long long)B * Hout;
     return (int)(s > units ? units : s);
