@@ -281,6 +281,16 @@ int pf_hardnet_plan_set_option(pf_plan *plan, const char *name, int value);
 typedef struct pf_train pf_train;
 int pf_train_create(const void *blob, size_t blob_bytes, int in_ch, int n_cls, pf_train **out);
 void pf_train_destroy(pf_train *t);
+/* enable != 0: the workgroup shape of every forward / backward-data convolution is measured (all candidates, a few launches
+ * each, hipEvents + a stream synchronisation) the first time its geometry runs outside a stream capture, then kept for the life
+ * of the plan; 0 (default): the shapes of the cost model, and the measured ones are forgotten.  The measured choice depends on
+ * timing: with it, two runs need not pick the same summation order for the K-split shapes (results equal to rounding, not
+ * to the bit, from run to run; within one plan they are reproducible once every geometry has been seen). */
+int pf_train_autotune(pf_train *t, int enable);
+/* what pf_train_autotune has measured so far: rows of 10 ints {ks, stride, Cin, Cout, Hin, Win, B, accumulate, pixel waves,
+ * cout tiles} ({.., 0, 0} = the cost model's own shape won); *n_rows = rows available, at most cap_rows are written.
+ * tools/tune_train.py turns them into csrc/train_tuned.inc, the table plans that do not measure consult (option "use_tuned_table"). */
+int pf_train_tuned_shapes(const pf_train *t, int *rows, int cap_rows, int *n_rows);
 int pf_train_param_count(const pf_train *t, size_t *n_floats);
 int pf_train_param_layout(const pf_train *t, int op_index, size_t *w_off, size_t *aux_off, int *has_bn);
 int pf_train_workspace(const pf_train *t, int B, int H, int W, int out_h, int out_w, size_t *bytes);

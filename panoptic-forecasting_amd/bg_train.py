@@ -72,6 +72,9 @@ class BGTrainer:
         #    cross-stream edge of a hipGraph costs a barrier packet on ROCm 7.2 (30.5 ms with the fork per layer).
         self.use_graph = bool(tr.get('use_hip_graph', False))
         self.side_stream = bool(tr.get('weight_gradient_stream', not self.use_graph))
+        # ``training.autotune``: measure the workgroup shape of every forward / backward-data convolution on first sight instead of
+        # taking the cost model's (include/pfhip.h: pf_train_autotune) - faster, but the shapes then depend on timing
+        self.autotune = bool(tr.get('autotune', False))
         self._graphs = {}
         dn = params['data'].get('depth_norm_params')
         self.depth_mean, self.depth_std = (float(dn[0]), float(dn[1])) if dn is not None else (0., 0.)
@@ -90,6 +93,8 @@ class BGTrainer:
             _lib.check(L.pf_train_create(self._buf, len(blob), self.in_ch, self.n_cls, ctypes.byref(self._t)), 'pf_train_create')
         finally:
             L.pf_set_option(b'train_side_stream', 1)
+        if self.autotune:
+            _lib.check(L.pf_train_autotune(self._t, 1), 'pf_train_autotune')
         n = ctypes.c_size_t()
         _lib.check(L.pf_train_param_count(self._t, ctypes.byref(n)), 'pf_train_param_count')
         if n.value != self.n:

@@ -17,7 +17,10 @@
 // weights re-packed on the device every step (forward order, or transposed + flipped per input range; stride-2
 // backward-data = stride-1 conv over the zero-stuffed gradient; a tensor's gradient accumulates over its consumers in
 // the store), backward-weight through the LDS-tiled wgrad kernels of train_kernels.hip.
+#include <algorithm>
+#include <array>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "net_kernels.h"
@@ -52,13 +55,77 @@ struct pf_train {
     hipStream_t side = nullptr;             // == sides[0]; non-null <=> the side streams are in use
     hipStream_t sides[kSideStreams] = {};
     hipEvent_t ev_dy[kDySlots] = {}, ev_wg[kDySlots] = {}, ev_join[kSideStreams] = {};
+    // pf_train_autotune: the workgroup shape (pixel waves x cout tiles) of every forward / backward-data convolution is MEASURED
+    // the first time its geometry is seen outside a stream capture (every candidate of conv_dma's shape list, 3 launches each,
+    // hipEvents) instead of taken from the inference path's cost model, which was calibrated on 1024x2048 batches.  Off by default:
+    // the choice (and with it the summation order of K-split shapes) then depends on timing, i.e. may differ from run to run.
+    int autotune = 0;
+    mutable std::map<std::array<int, 8>, std::pair<int, int>> tuned;   // (ks, stride, Cin, Cout, Hin, Win, B, accum) -> (wm, nt)
+    mutable hipEvent_t tune_ev[2] = {nullptr, nullptr};
 };
 
 namespace pf {
-extern int g_opt_train_side;
+extern int g_opt_train_side, g_opt_use_tuned;
 }
 
 namespace {
+
+// measured shapes of the training step's convolutions for the configurations tools/tune_train.py was run on (the reference's
+// configs/bg/bg_train.yaml: batch 8 of 800x800 crops): {ks, stride, Cin, Cout, Hin, Win, B, accum, wm, nt}.  Consulted when option
+// "use_tuned_table" is on (default) and the plan does not measure for itself; other geometries take the cost model's shape
+struct TrainTuned {
+    int key[8], wm, nt;
+};
+const TrainTuned kTrainTuned[] = {
+#include "train_tuned.inc"
+    {{0, 0, 0, 0, 0, 0, 0, 0}, 0, 0}};
+
+// conv_dma with the measured shape for the geometry: this plan's own measurement (pf_train::autotune, measuring first if need
+// be), else the table's, else the cost model's
+int train_conv_dma(const pf_train *p, const ConvArgs &c, int ks, int stride, int B, hipStream_t s) {
+    const std::array<int, 8> key{ks, stride, c.Cin, c.Cout, c.Hin, c.Win, B, c.accum};
+    if (!p->autotune) {
+        if (g_opt_use_tuned)
+            for (const TrainTuned &t : kTrainTuned)
+                if (t.wm && std::equal(key.begin(), key.end(), t.key)) return launch_conv_dma(c, ks, stride, B, s, t.wm, t.nt);
+        return launch_conv_dma(c, ks, stride, B, s);
+    }
+    auto it = p->tuned.find(key);
+    if (it == p->tuned.end()) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return launch_conv_dma(c, ks, stride, B, s);
+        if (!p->tune_ev[0] && (hipEventCreate(&p->tune_ev[0]) != hipSuccess || hipEventCreate(&p->tune_ev[1]) != hipSuccess))
+            return fail(PF_EHIP, "autotune: hipEventCreate failed");
+        // candidate (0, 0) = the cost model's own choice: measured first, kept unless a forced shape is at least 3 % faster
+        float model_ms = 0.f, best = 1e30f;
+        std::pair<int, int> pick{0, 0};
+        const int wms[4] = {0, 4, 2, 1};
+        for (int wi = 0; wi < 4; ++wi) {
+            const int wm = wms[wi], ntmax = wm == 0 ? 1 : (wm == 1 ? 2 : 4);
+            for (int nt = 1; nt <= ntmax && (wm == 0 || nt <= c.ntiles); ++nt) {
+                int rc = PF_OK;
+                for (int rep = 0; rep < 4 && rc == PF_OK; ++rep) {      // 1 warm-up + 3 timed
+                    if (rep == 1) PF_HIP_CHECK(hipEventRecord(p->tune_ev[0], s));
+                    rc = wm ? launch_conv_dma(c, ks, stride, B, s, wm, nt) : launch_conv_dma(c, ks, stride, B, s);
+                }
+                if (rc == PF_EUNSUPPORTED && wm) continue;
+                if (rc) return rc;
+                PF_HIP_CHECK(hipEventRecord(p->tune_ev[1], s));
+                PF_HIP_CHECK(hipEventSynchronize(p->tune_ev[1]));
+                float ms = 0.f;
+                PF_HIP_CHECK(hipEventElapsedTime(&ms, p->tune_ev[0], p->tune_ev[1]));
+                if (!wm) model_ms = ms;
+                else if (ms < best) {
+                    best = ms;
+                    pick = {wm, nt};
+                }
+            }
+        }
+        if (!(best < 0.97f * model_ms)) pick = {0, 0};
+        it = p->tuned.emplace(key, pick).first;
+    }
+    return it->second.first ? launch_conv_dma(c, ks, stride, B, s, it->second.first, it->second.second) : launch_conv_dma(c, ks, stride, B, s);
+}
 
 struct TDims {
     int h = 0, w = 0;
@@ -296,12 +363,35 @@ extern "C" void pf_train_destroy(pf_train *p) {
         if (p->ev_dy[k]) (void)hipEventDestroy(p->ev_dy[k]);
         if (p->ev_wg[k]) (void)hipEventDestroy(p->ev_wg[k]);
     }
+    for (hipEvent_t e : p->tune_ev)
+        if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < pf_train::kSideStreams; ++k) {
         if (p->ev_join[k]) (void)hipEventDestroy(p->ev_join[k]);
         if (p->sides[k]) (void)hipStreamDestroy(p->sides[k]);
     }
     if (p->dev_zero) (void)hipFree(p->dev_zero);
     delete p;
+}
+
+extern "C" int pf_train_autotune(pf_train *p, int enable) {
+    if (!p) return fail(PF_EINVAL, "pf_train_autotune: null plan");
+    p->autotune = enable != 0;
+    if (!enable) p->tuned.clear();
+    return PF_OK;
+}
+
+extern "C" int pf_train_tuned_shapes(const pf_train *p, int *rows, int cap_rows, int *n_rows) {
+    if (!p || !n_rows || (cap_rows > 0 && !rows)) return fail(PF_EINVAL, "pf_train_tuned_shapes: null argument");
+    *n_rows = (int)p->tuned.size();
+    int i = 0;
+    for (const auto &kv : p->tuned) {
+        if (i >= cap_rows) break;
+        for (int k = 0; k < 8; ++k) rows[i * 10 + k] = kv.first[k];
+        rows[i * 10 + 8] = kv.second.first;
+        rows[i * 10 + 9] = kv.second.second;
+        ++i;
+    }
+    return PF_OK;
 }
 
 extern "C" int pf_train_param_count(const pf_train *p, size_t *n_floats) {
@@ -428,7 +518,7 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
             c.chunk_begin = 0;
             c.chunk_end = c.nchunks;
             c.rem = 0;
-            return launch_conv_dma(c, ks, stride, B, s);
+            return train_conv_dma(p, c, ks, stride, B, s);
         };
         if ((a.Win & 3) == 0) {
             rc2 = fast(a, src_ch, n_src);
@@ -584,7 +674,7 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
                 b.nchunks = b.src_chunk0[1];
                 b.chunk_begin = 0;
                 b.chunk_end = b.nchunks;
-                if ((rc = launch_conv_dma(b, (int)o.k, 1, B, s))) return rc;
+                if ((rc = train_conv_dma(p, b, (int)o.k, 1, B, s))) return rc;
                 float *dsts[kMaxSrc];
                 int ct[kMaxSrc], co[kMaxSrc], chs[kMaxSrc];
                 for (uint32_t j = 0; j < o.n_src; ++j) {

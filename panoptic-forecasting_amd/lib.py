@@ -45,6 +45,8 @@ SIGNATURES = {
     'pf_seg_loss': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'pf_train_create': (_i, [_vp, _sz, _i, _i, _c.POINTER(_vp)]),
     'pf_train_destroy': (None, [_vp]),
+    'pf_train_autotune': (_i, [_vp, _i]),
+    'pf_train_tuned_shapes': (_i, [_vp, _c.POINTER(_i), _i, _c.POINTER(_i)]),
     'pf_train_param_count': (_i, [_vp, _c.POINTER(_sz)]),
     'pf_train_param_layout': (_i, [_vp, _i, _c.POINTER(_sz), _c.POINTER(_sz), _c.POINTER(_i)]),
     'pf_train_workspace': (_i, [_vp, _i, _i, _i, _i, _i, _c.POINTER(_sz)]),

@@ -205,6 +205,42 @@ def test_weight_gradient_stream_and_graph_replays_change_no_bit(graph):
     assert torch.equal(got[False][0], got[True][0]) and got[False][1] == got[True][1]
 
 
+def test_measured_conv_shapes_change_rounding_only():
+    """pf_train_autotune (training.autotune): every forward / backward-data convolution's workgroup shape measured on first sight.
+    Same function, other tilings: gradients agree to rounding with the cost-model shapes; the choices can be read back, and a
+    second step with them is bit-identical to the first."""
+    import ctypes
+    from panoptic_forecasting_amd import lib as pflib
+    from panoptic_forecasting_amd.bg_train import BGTrainer
+    z, batches = _fixture()
+    a_in, a_lab = (_cuda(d) for d in batches[0])
+    L = pflib.load()
+    pflib.check(L.pf_set_option(b'use_tuned_table', 0), 'pf_set_option')     # the reference point: the cost model alone
+    try:
+        ref = BGTrainer(_params())
+        ref.load_state_dict(_sd())
+        want = ref.forward_backward(a_in, a_lab, update_running_stats=False)
+        g_ref = ref.grad.clone()
+    finally:
+        L.pf_set_option(b'use_tuned_table', 1)
+    tr = BGTrainer(_params(autotune=True))
+    tr.load_state_dict(_sd())
+    got = tr.forward_backward(a_in, a_lab, update_running_stats=False)      # measures, then runs with the measured shapes
+    g1 = tr.grad.clone()
+    n = ctypes.c_int()
+    pflib.check(L.pf_train_tuned_shapes(tr._t, None, 0, ctypes.byref(n)), 'pf_train_tuned_shapes')
+    assert n.value >= 10
+    rows = (ctypes.c_int * (10 * n.value))()
+    pflib.check(L.pf_train_tuned_shapes(tr._t, rows, n.value, ctypes.byref(n)), 'pf_train_tuned_shapes')
+    for i in range(n.value):
+        ks, stride, cin, cout, h, w, b, accum, wm, nt = rows[i * 10:i * 10 + 10]
+        assert ks in (1, 3) and stride in (1, 2) and b == a_in['seg'].shape[0] and wm in (0, 1, 2, 4) and 0 <= nt <= 4 and accum in (0, 1)
+    assert abs(float(got['loss']) - float(want['loss'])) <= 1e-6 * abs(float(want['loss']))
+    assert _rel(g1, g_ref) <= 1e-5
+    tr.forward_backward(a_in, a_lab, update_running_stats=False)
+    assert torch.equal(tr.grad, g1)
+
+
 @pytest.mark.parametrize('clip', ['norm', 'value', 'none'])
 def test_sgd_step_vs_torch(clip):
     import ctypes

@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--graph', action='store_true', help='training.use_hip_graph: replay a captured step (one stream) instead of eager launches')
     ap.add_argument('--no-side-stream', action='store_true', help='training.weight_gradient_stream = False: weight gradients on the caller\'s stream')
+    ap.add_argument('--autotune', action='store_true', help='training.autotune: measured conv shapes')
     ap.add_argument('--lib', default='', help='another build of libpfhip.so (A/B runs)')
     ap.add_argument('--out', default='', help='also write the JSON line here')
     a = ap.parse_args()
@@ -32,7 +33,7 @@ def main():
         pflib.LIB_PATH = os.path.abspath(a.lib)
     params = {'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])]},
               'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True},
-              'training': {'lr': 2e-3, 'mom': 0.9, 'wd': 1e-4, 'clip_grad_norm': 5.0, 'use_hip_graph': a.graph, 'weight_gradient_stream': not (a.graph or a.no_side_stream)}}
+              'training': {'lr': 2e-3, 'mom': 0.9, 'wd': 1e-4, 'clip_grad_norm': 5.0, 'use_hip_graph': a.graph, 'weight_gradient_stream': not (a.graph or a.no_side_stream), 'autotune': a.autotune}}
     tr = BGTrainer(params)
     tr.load_state_dict(synth.make_state_dict(seed=1234))
     inp = {k: v.cuda() for k, v in synth.make_bg_inputs(b=a.batch, h=a.size, w=a.size, seed=1).items()}
@@ -57,7 +58,7 @@ def main():
     top = sorted(recs, key=lambda r: -r['ms'])
     line = {'ms_per_step': ms, 'samples_per_s': a.batch / ms * 1e3, 'batch': a.batch, 'size': a.size, 'loss': float(out['loss']),
             'launch': 'hipGraph replay of forward + loss + backward, eager SGD step' if graph else ('eager, weight gradients on their own stream' if tr.side_stream else 'eager, one stream'), 'steps': a.steps,
-            'weight_gradient_stream': tr.side_stream, 'workspace_GB': tr._ws.numel() / 1e9, 'kernel_ms_sum': sum(r['ms'] for r in recs),
+            'weight_gradient_stream': tr.side_stream, 'autotune': tr.autotune, 'workspace_GB': tr._ws.numel() / 1e9, 'kernel_ms_sum': sum(r['ms'] for r in recs),
             'profiled_kernels': {r['label'][:70]: {'ms': round(r['ms'], 3), 'launches': r['launches'],
                                                    'TFLOPs': round(r['flops'] / max(r['ms'], 1e-9) / 1e9, 1),
                                                    'GBps': round(r['bytes'] / max(r['ms'], 1e-9) / 1e6, 0)} for r in top}}
