@@ -282,8 +282,10 @@ typedef struct pf_train pf_train;
 int pf_train_create(const void *blob, size_t blob_bytes, int in_ch, int n_cls, pf_train **out);
 void pf_train_destroy(pf_train *t);
 /* enable != 0: the workgroup shape of every forward / backward-data convolution is measured (all candidates, a few launches
- * each, hipEvents + a stream synchronisation) the first time its geometry runs outside a stream capture, then kept for the life
- * of the plan; 0 (default): the shapes of the cost model, and the measured ones are forgotten.  The measured choice depends on
+ * each, hipEvents + a stream synchronisation) in a pass of its own in front of the first pf_train_forward_backward of a
+ * configuration (B, H, W, out size) that runs outside a stream capture - that pass leaves theta, grad and the running statistics
+ * alone - then kept for the life of the plan; 0 (default): the shapes of csrc/train_tuned.inc / the cost model, and the measured
+ * ones are forgotten.  Call it before pf_train_workspace: the measuring pass needs n_params floats more.  The measured choice depends on
  * timing: with it, two runs need not pick the same summation order for the K-split shapes (results equal to rounding, not
  * to the bit, from run to run; within one plan they are reproducible once every geometry has been seen). */
 int pf_train_autotune(pf_train *t, int enable);

@@ -62,6 +62,10 @@ struct pf_train {
     int autotune = 0;
     mutable std::map<std::array<int, 8>, std::pair<int, int>> tuned;   // (ks, stride, Cin, Cout, Hin, Win, B, accum) -> (wm, nt)
     mutable hipEvent_t tune_ev[2] = {nullptr, nullptr};
+    // the measurements run in a pass of their own in front of the first real pass of a configuration (B, H, W, out_h, out_w):
+    // its launches repeat, so what they accumulate is garbage - it goes to a scratch gradient and leaves theta alone
+    mutable bool measuring = false;
+    mutable std::vector<std::array<int, 5>> measured_configs;
 };
 
 namespace pf {
@@ -84,16 +88,14 @@ const TrainTuned kTrainTuned[] = {
 // be), else the table's, else the cost model's
 int train_conv_dma(const pf_train *p, const ConvArgs &c, int ks, int stride, int B, hipStream_t s) {
     const std::array<int, 8> key{ks, stride, c.Cin, c.Cout, c.Hin, c.Win, B, c.accum};
-    if (!p->autotune) {
+    auto it = p->autotune ? p->tuned.find(key) : p->tuned.end();
+    if (it == p->tuned.end() && !p->measuring) {
         if (g_opt_use_tuned)
             for (const TrainTuned &t : kTrainTuned)
                 if (t.wm && std::equal(key.begin(), key.end(), t.key)) return launch_conv_dma(c, ks, stride, B, s, t.wm, t.nt);
         return launch_conv_dma(c, ks, stride, B, s);
     }
-    auto it = p->tuned.find(key);
     if (it == p->tuned.end()) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return launch_conv_dma(c, ks, stride, B, s);
         if (!p->tune_ev[0] && (hipEventCreate(&p->tune_ev[0]) != hipSuccess || hipEventCreate(&p->tune_ev[1]) != hipSuccess))
             return fail(PF_EHIP, "autotune: hipEventCreate failed");
         // candidate (0, 0) = the cost model's own choice: measured first, kept unless a forced shape is at least 3 % faster
@@ -159,6 +161,7 @@ struct TLayout {
     size_t dy = 0, wpk = 0, wpart = 0, dfull = 0, cepart = 0, bnpart = 0, out3 = 0, total = 0;
     size_t pad_in = 0, pad_out = 0;    // odd-width convs: gathered input / result with the row pitch rounded up to 4
     size_t dy_more[pf_train::kDySlots] = {}, pad_in_w[pf_train::kSideStreams] = {}, wpart_more[pf_train::kSideStreams] = {};   // side streams: further dy slots, per stream the padded copy of x and the partial sums
+    size_t tune_grad = 0;              // autotune: the measuring pass's parameter gradients (discarded)
     size_t grad_begin = 0, grad_end = 0;
     // every tiled weight packing of the step (forward convs in op order, then the backward-data convs of every op and input
     // range in op order): packed by ONE batch of launches at the start of the step into wpk_arena
@@ -270,6 +273,7 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
         }
         L.wpk_arena = take(arena * sizeof(float) + 256);
     }
+    if (p->autotune) L.tune_grad = take(p->n_params * sizeof(float));
     L.dy = take(max_dy + 256);
     if (p->side) {
         for (int k = 1; k < pf_train::kDySlots; ++k) L.dy_more[k] = take(max_dy + 256);
@@ -375,8 +379,11 @@ extern "C" void pf_train_destroy(pf_train *p) {
 
 extern "C" int pf_train_autotune(pf_train *p, int enable) {
     if (!p) return fail(PF_EINVAL, "pf_train_autotune: null plan");
-    p->autotune = enable != 0;
-    if (!enable) p->tuned.clear();
+    p->autotune = enable != 0;      // (changes pf_train_workspace: the measuring pass has its own parameter-gradient buffer)
+    if (!enable) {
+        p->tuned.clear();
+        p->measured_configs.clear();
+    }
     return PF_OK;
 }
 
@@ -436,11 +443,11 @@ extern "C" int pf_train_tensor_view(const pf_train *p, const char *name, int wan
     return fail(PF_EINVAL, "no tensor named '%s'", name);
 }
 
-extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float *grad, int accumulate_grads, const void *seg, int seg_is_i64,
-                                         const float *depth, const uint8_t *depth_mask, float depth_mean, float depth_std, int T,
-                                         const float *x_dense, int B, int H, int W, const void *labels, int labels_i64, int out_h, int out_w,
-                                         int ignore_index, float loss_scale, float bn_momentum, float bn_eps, int update_running_stats,
-                                         double *out3, void *ws, size_t ws_bytes, void *stream) {
+static int train_pass(const pf_train *p, float *theta, float *grad, int accumulate_grads, const void *seg, int seg_is_i64,
+                      const float *depth, const uint8_t *depth_mask, float depth_mean, float depth_std, int T,
+                      const float *x_dense, int B, int H, int W, const void *labels, int labels_i64, int out_h, int out_w,
+                      int ignore_index, float loss_scale, float bn_momentum, float bn_eps, int update_running_stats,
+                      double *out3, void *ws, size_t ws_bytes, void *stream) {
     if (!p || !theta || !grad || !labels || !out3 || !ws) return fail(PF_EINVAL, "pf_train_forward_backward: null pointer argument");
     if (!x_dense && (!seg || !depth || !depth_mask)) return fail(PF_EINVAL, "pf_train_forward_backward: pass seg+depth+depth_mask or x_dense");
     if (B <= 0 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) return fail(PF_EINVAL, "pf_train_forward_backward: bad dims");
@@ -713,6 +720,33 @@ extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float 
         }
     }
     return PF_OK;
+}
+
+extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float *grad, int accumulate_grads, const void *seg, int seg_is_i64,
+                                         const float *depth, const uint8_t *depth_mask, float depth_mean, float depth_std, int T,
+                                         const float *x_dense, int B, int H, int W, const void *labels, int labels_i64, int out_h, int out_w,
+                                         int ignore_index, float loss_scale, float bn_momentum, float bn_eps, int update_running_stats,
+                                         double *out3, void *ws, size_t ws_bytes, void *stream) {
+    if (p && p->autotune && ws) {
+        const std::array<int, 5> cfg{B, H, W, out_h, out_w};
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool seen = std::find(p->measured_configs.begin(), p->measured_configs.end(), cfg) != p->measured_configs.end();
+        if (!seen && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+            std::vector<TDims> d;
+            int rc = t_propagate(p, H, W, d);
+            if (rc) return rc;
+            const TLayout L = t_layout(p, B, d, out_h, out_w);
+            if (ws_bytes < L.total) return fail(PF_EWORKSPACE, "workspace %zu B < required %zu B", ws_bytes, L.total);
+            p->measuring = true;
+            rc = train_pass(p, theta, reinterpret_cast<float *>((char *)ws + L.tune_grad), 0, seg, seg_is_i64, depth, depth_mask, depth_mean, depth_std, T,
+                            x_dense, B, H, W, labels, labels_i64, out_h, out_w, ignore_index, loss_scale, bn_momentum, bn_eps, 0, out3, ws, ws_bytes, stream);
+            p->measuring = false;
+            if (rc) return rc;
+            p->measured_configs.push_back(cfg);
+        }
+    }
+    return train_pass(p, theta, grad, accumulate_grads, seg, seg_is_i64, depth, depth_mask, depth_mean, depth_std, T, x_dense, B, H, W, labels,
+                      labels_i64, out_h, out_w, ignore_index, loss_scale, bn_momentum, bn_eps, update_running_stats, out3, ws, ws_bytes, stream);
 }
 
 extern "C" int pf_sgd_workspace(size_t *bytes) {
