@@ -242,6 +242,9 @@ int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void 
  *                   (tests/test_gpu_bg_model.py), 39 % fewer front-end bytes, 0.42 ms against 0.83 ms for the two separate kernels
  *                   per 16 frames at 1024x2048; 0 = stem -> conv_split -> conv_dma stride 2;
  *   "profile_tag_ops" (default 0; process-wide only) pf_profile_* records carry one label per op of the table (tools/);
+ *   "upsample_bwd_two_pass" (default 1; read by pf_train_forward_backward) the transposed bilinear interpolations of the training
+ *                   step (the loss head's 4x above all) as a row pass and a column pass over a scratch tensor when the planes are
+ *                   large - the one-pass kernel's own nesting and order, so the same bits; 0 = always one pass;
  *   "train_side_stream" (default 1; process-wide only, read by pf_train_create) the weight gradients of the training step - leaves
  *                   of the backward pass - run on the training plan's own lower-priority stream, forked from and joined to the
  *                   caller's stream inside every pf_train_forward_backward (a stream capture of the call stays one graph; the

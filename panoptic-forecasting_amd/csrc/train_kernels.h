@@ -51,9 +51,11 @@ int launch_unpad_scatter_multi(const float *src, int B, int C, int H, int W, int
 int launch_unpad_scatter(const float *src, int B, int C, int H, int W, int Wp, float *dst, int dst_ctotal, int dst_choff, int accum, hipStream_t s);
 int launch_zero_stuff(const float *dy, int planes, int Hout, int Wout, int Hin, int Win, float *up, hipStream_t s);
 int launch_avgpool2_bwd(const float *gout, int planes, int Hin, int Win, float *gin, hipStream_t s);
-// gin (+)= bilinear^T(gout) [* scale / *count when count != nullptr]
+// gin (+)= bilinear^T(gout) [* scale / *count when count != nullptr].  tmp: upsample_bwd_tmp_floats() floats of scratch (0 =
+// small planes, none needed; tmp may be null: the one-pass kernel, same bits)
+size_t upsample_bwd_tmp_floats(int planes, int Hi, int Wi, int Ho, int Wo);
 int launch_upsample_bwd(const float *gout, int planes, int Hi, int Wi, int Ho, int Wo, const double *count, float scale, int accumulate,
-                        float *gin, hipStream_t s);
+                        float *gin, float *tmp, hipStream_t s);
 size_t ce_partial_doubles(int B, int Ho, int Wo);
 int launch_ce_fwd_bwd(const float *logits, int B, int C, int Hi, int Wi, const void *labels, int lab_i64, int Ho, int Wo, int ignore,
                       float *dfull, double *partial, double *out3, hipStream_t s);

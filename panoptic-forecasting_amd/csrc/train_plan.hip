@@ -69,7 +69,7 @@ struct pf_train {
 };
 
 namespace pf {
-extern int g_opt_train_side, g_opt_use_tuned;
+extern int g_opt_train_side, g_opt_use_tuned, g_opt_up_two_pass;
 }
 
 namespace {
@@ -161,6 +161,7 @@ struct TLayout {
     size_t dy = 0, wpk = 0, wpart = 0, dfull = 0, cepart = 0, bnpart = 0, out3 = 0, total = 0;
     size_t pad_in = 0, pad_out = 0;    // odd-width convs: gathered input / result with the row pitch rounded up to 4
     size_t dy_more[pf_train::kDySlots] = {}, pad_in_w[pf_train::kSideStreams] = {}, wpart_more[pf_train::kSideStreams] = {};   // side streams: further dy slots, per stream the padded copy of x and the partial sums
+    size_t up_tmp = 0;                 // scratch of the two-pass bilinear transpose
     size_t tune_grad = 0;              // autotune: the measuring pass's parameter gradients (discarded)
     size_t grad_begin = 0, grad_end = 0;
     // every tiled weight packing of the step (forward convs in op order, then the backward-data convs of every op and input
@@ -286,6 +287,18 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
     L.pad_in = take(max_pin);
     L.pad_out = take(max_pout);
     L.dfull = take((size_t)B * p->hdr.n_cls * out_h * out_w * sizeof(float));
+    {
+        size_t mx = 0;
+        for (size_t i = 0; i < p->ops.size(); ++i) {
+            const BlobOp &o = p->ops[i];
+            const TDims in = d[o.src[0].tensor];
+            size_t n = 0;
+            if (o.kind == OP_HEAD) n = upsample_bwd_tmp_floats(B * (int)o.cin, in.h, in.w, out_h, out_w);
+            else if (o.kind == OP_UPSAMPLE) n = upsample_bwd_tmp_floats(B * (int)o.cin, in.h, in.w, d[o.dst].h, d[o.dst].w);
+            mx = n > mx ? n : mx;
+        }
+        L.up_tmp = take(mx * sizeof(float) + 256);
+    }
     L.cepart = take(ce_partial_doubles(B, out_h, out_w) * sizeof(double));
     L.bnpart = take(bn_partial_doubles((int)max_c) * sizeof(double));
     L.out3 = take(4 * sizeof(double));
@@ -469,6 +482,7 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
     float *pad_in = reinterpret_cast<float *>(wsb + L.pad_in), *pad_out = reinterpret_cast<float *>(wsb + L.pad_out);
     float *dfull = reinterpret_cast<float *>(wsb + L.dfull);
     double *cepart = reinterpret_cast<double *>(wsb + L.cepart);
+    float *up_tmp = g_opt_up_two_pass ? reinterpret_cast<float *>(wsb + L.up_tmp) : nullptr;
     double *bnpart = reinterpret_cast<double *>(wsb + L.bnpart);
     double *loss3 = reinterpret_cast<double *>(wsb + L.out3);
 
@@ -603,11 +617,11 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
         const TDims out = o.kind == OP_HEAD ? in : d[o.dst];
         if (o.kind == OP_HEAD) {
             // d loss / d logits = bilinear^T (softmax - onehot) * loss_scale / n_valid   (mean over the valid pixels, bg_model.py:81)
-            if ((rc = launch_upsample_bwd(dfull, B * (int)o.cin, in.h, in.w, out_h, out_w, loss3 + 1, loss_scale, 0, gradt(o.src[0].tensor), s))) return rc;
+            if ((rc = launch_upsample_bwd(dfull, B * (int)o.cin, in.h, in.w, out_h, out_w, loss3 + 1, loss_scale, 0, gradt(o.src[0].tensor), up_tmp, s))) return rc;
         } else if (o.kind == OP_POOL) {
             if ((rc = launch_avgpool2_bwd(gradt(o.dst), B * (int)o.cin, in.h, in.w, gradt(o.src[0].tensor), s))) return rc;
         } else if (o.kind == OP_UPSAMPLE) {
-            if ((rc = launch_upsample_bwd(gradt(o.dst), B * (int)o.cin, in.h, in.w, out.h, out.w, nullptr, 1.f, 1, gradt(o.src[0].tensor), s))) return rc;
+            if ((rc = launch_upsample_bwd(gradt(o.dst), B * (int)o.cin, in.h, in.w, out.h, out.w, nullptr, 1.f, 1, gradt(o.src[0].tensor), up_tmp, s))) return rc;
         } else if (o.kind == OP_STEM || o.kind == OP_CONV) {
             const int t_ctotal = (int)p->tensors[o.dst].channels;
             float *aux = theta + p->aux_off[ii], *gaux = grad + p->aux_off[ii];

@@ -205,6 +205,32 @@ def test_weight_gradient_stream_and_graph_replays_change_no_bit(graph):
     assert torch.equal(got[False][0], got[True][0]) and got[False][1] == got[True][1]
 
 
+def test_two_pass_bilinear_transpose_is_the_one_pass_sum():
+    """The loss head's transposed 4x interpolation runs as a row pass + a column pass once its planes are large (here 2 x 11 x
+    512 x 512 outputs); option upsample_bwd_two_pass = 0 keeps the one-pass gather.  Same nesting, same order: same bits."""
+    from panoptic_forecasting_amd import lib as pflib, synth
+    from panoptic_forecasting_amd.bg_train import BGTrainer
+    L = pflib.load()
+    inp = {k: v.cuda() for k, v in synth.make_bg_inputs(b=2, h=512, w=512, seed=5).items()}
+    gen = torch.Generator().manual_seed(9)
+    lab = torch.randint(0, 12, (2, 512, 512), generator=gen)
+    lab[lab == 11] = 255
+    lab = {'seg': lab.cuda()}
+    got = {}
+    for two in (1, 0):
+        pflib.check(L.pf_set_option(b'upsample_bwd_two_pass', two), 'pf_set_option')
+        try:
+            tr = BGTrainer(_params())
+            tr.load_state_dict(_sd())
+            out = tr.forward_backward(inp, lab, update_running_stats=False)
+            torch.cuda.synchronize()
+            got[two] = (tr.grad.clone(), float(out['loss']))
+        finally:
+            L.pf_set_option(b'upsample_bwd_two_pass', 1)
+    assert got[1][1] == got[0][1] and torch.isfinite(got[1][0]).all() and float(got[1][0].abs().max()) > 0
+    assert torch.equal(got[1][0], got[0][0])
+
+
 def test_measured_conv_shapes_change_rounding_only():
     """pf_train_autotune (training.autotune): every forward / backward-data convolution's workgroup shape measured on first sight.
     Same function, other tilings: gradients agree to rounding with the cost-model shapes; the choices can be read back, and a
