@@ -69,7 +69,7 @@ class BGTrainer:
         #  * ``training.use_hip_graph`` - the call is captured into a hipGraph the second time a configuration (shapes, dtypes,
         #    accumulate / loss-scale / running-stat flags) is seen and replayed from then on, on static copies of the inputs:
         #    no host launch cost (a busy host, many ranks per socket), 19.6 ms.  A captured step stays on one stream: every
-        #    cross-stream edge of a hipGraph costs a barrier packet on ROCm 7.2 (30.5 ms with the fork per layer).
+        #    cross-stream edge of a hipGraph costs a barrier packet on this runtime (30.5 ms with the fork per layer).
         self.use_graph = bool(tr.get('use_hip_graph', False))
         self.side_stream = bool(tr.get('weight_gradient_stream', not self.use_graph))
         # ``training.autotune``: measure the workgroup shape of every forward / backward-data convolution on first sight instead of

@@ -1,10 +1,12 @@
 // Zero fill and device-to-device copy as kernels of this library.
 //
 // Why not hipMemsetAsync / hipMemcpyAsync: every entry point of the library may be captured into a hipGraph by its caller
-// (bench.py, bg_train.py).  On ROCm 7.2 a captured memset NODE inside a graph that is one linear chain of nodes executed
-// correctly on the first launch of the graph and not on later ones (round 4: the z-buffer slots of the splat and the gradient
-// arenas of the training step kept their previous contents from the second replay on; graphs with forked branches were not
-// affected) - tests/test_gpu_graph_replay.py holds the cases.  A captured call of this library therefore holds kernel nodes only.
+// (bench.py, bg_train.py).  Under torch.cuda.graph (torch 2.10 with its bundled HIP 7.0.2 runtime) a captured memset NODE inside a
+// graph that is one linear chain of nodes did its job on the first replay and filled its range with a stale 64-bit pattern on
+// later ones (round 4: the z-buffer slots of the splat and the gradient arenas of the training step held garbage from the second
+// replay on; graphs with forked branches were not affected; tools/ubench/graph_memset_torch.py reproduces it, the plain HIP
+// program tools/ubench/graph_memset.hip does not).  A captured call of this library therefore holds kernel nodes only;
+// tests/test_gpu_graph_replay.py replays every captured path five times against the eager result.
 #include "pf_common.h"
 
 namespace pf {

@@ -1,8 +1,8 @@
 """Captured calls replay to the same bits as eager ones - on EVERY replay, not only the first.
 
 Round 4 found that a captured hipMemsetAsync node inside a graph that is one linear chain (one stream, no forks) executed on
-the first launch of the graph and not on later ones (ROCm 7.2): the splat's z-buffer slots and the training step's gradient
-arenas kept their previous contents from the second replay on, while the forked four-stream graph of the headline bench was not
+the first launch of the graph and not on later ones (torch 2.10 capture + replay; tools/ubench/graph_memset_torch.py): the splat's z-buffer slots and the training step's gradient
+arenas held garbage from the second replay on, while the forked four-stream graph of the headline bench was not
 affected.  The library now enqueues kernels only (csrc/pf_fill.hip); these tests replay each captured path five times."""
 import json
 import os
