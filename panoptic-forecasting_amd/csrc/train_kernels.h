@@ -39,7 +39,7 @@ int launch_bn_backward(const float *g, int t_ctotal, int choff, const float *y, 
                        float *dy, int dy_pitch /* 0 = dense rows; else floats per row (>= W), pad columns zeroed */, hipStream_t s);
 int launch_bias_backward(const float *g, int t_ctotal, int choff, int B, int C, int H, int W, float *dbias, double *partial /* bn_partial_doubles(C) */,
                          float *dy, int dy_pitch /* as launch_bn_backward */, hipStream_t s);
-int wgrad_slabs(int cout, int cin, int B, int Hout, int Win, int Wout);
+int wgrad_slabs(int cout, int cin, int ks, int B, int Hout, int Win, int Wout);
 size_t wgrad_partial_floats(int cout, int cin, int ks, int B, int Hout, int Win, int Wout);
 // a: the forward conv's arguments (sources, Cin/Cout, Hin/Win/Hout/Wout); dw (OIHW) accumulates
 int launch_wgrad(const ConvArgs &a, int ks, int stride, const float *dy, int B, float *partial, float *dw, hipStream_t s);

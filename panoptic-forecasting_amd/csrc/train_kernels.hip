@@ -787,23 +787,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
 
 static bool wgrad_tiled_ok(int Win, int Wout) { return (Win & 3) == 0 && (Wout & 3) == 0; }
 // cout tiles per workgroup: 2 in the tiled form
-int wgrad_slabs(int cout, int cin, int B, int Hout, int Win, int Wout) {
+int wgrad_slabs(int cout, int cin, int ks, int B, int Hout, int Win, int Wout) {
     const bool tiled = wgrad_tiled_ok(Win, Wout);
     const long long tiles = (long long)(tiled ? (cout + 31) / 32 : (cout + 15) / 16) * ((cin + 15) / 16);
     // tiled: 512 workgroups per layer (2 per CU).  1024 gave each kernel more latency hiding alone, but twice the partial sums to
     // write and reduce, beside a backward chain that fills the other half of the chip anyway: 16.45 -> 16.2 ms per step (256: 17.9,
     // 384: 16.7, 768: 16.65 - same-box runs, profiles/r04_experiments.md)
-    long long s = (tiled ? 512 : 2048) / tiles;
+    // (the 1x1 form - 15 KB of LDS, 58 registers, 8 workgroups per CU - wants the deeper queue: 2048, 15.65 -> 15.4 ms)
+    long long s = (tiled ? (ks == 1 ? 2048 : 512) : 2048) / tiles;
     s = s < 1 ? 1 : s;
     const long long units = tiled ? (long long)B * Hout * ((Wout + 63) / 64) : (long long)B * Hout;
     return (int)(s > units ? units : s);
 }
 size_t wgrad_partial_floats(int cout, int cin, int ks, int B, int Hout, int Win, int Wout) {
-    return (size_t)wgrad_slabs(cout, cin, B, Hout, Win, Wout) * ((cout + 31) / 32 * 32) * ((cin + 15) / 16 * 16) * ks * ks;
+    return (size_t)wgrad_slabs(cout, cin, ks, B, Hout, Win, Wout) * ((cout + 31) / 32 * 32) * ((cin + 15) / 16 * 16) * ks * ks;
 }
 
 int launch_wgrad(const ConvArgs &a, int ks, int stride, const float *dy, int B, float *partial, float *dw, hipStream_t s) {
-    int slabs = wgrad_slabs(a.Cout, a.Cin, B, a.Hout, a.Win, a.Wout);
+    int slabs = wgrad_slabs(a.Cout, a.Cin, ks, B, a.Hout, a.Win, a.Wout);
     const bool tiled = wgrad_tiled_ok(a.Win, a.Wout);
     const bool two_rows = tiled && ks == 3 && stride == 1;      // R = 2: half as many work items (the partial buffer is sized for R = 1)
     if (two_rows) {
