@@ -158,9 +158,10 @@ int t_propagate(const pf_train *p, int H, int W, std::vector<TDims> &d) {
 struct TLayout {
     std::vector<size_t> act, grad;     // per tensor (bytes); act[input] = the dense one-hot/depth tensor
     std::vector<size_t> ypre, stat;    // per op: pre-BN conv output, {mean[cout], invstd[cout]}
+    std::vector<size_t> xpad;          // per op of an odd-width level: its gathered, row-padded input, kept from the forward pass for the weight gradient
     size_t dy = 0, wpk = 0, wpart = 0, dfull = 0, cepart = 0, bnpart = 0, out3 = 0, total = 0;
     size_t pad_in = 0, pad_out = 0;    // odd-width convs: gathered input / result with the row pitch rounded up to 4
-    size_t dy_more[pf_train::kDySlots] = {}, pad_in_w[pf_train::kSideStreams] = {}, wpart_more[pf_train::kSideStreams] = {};   // side streams: further dy slots, per stream the padded copy of x and the partial sums
+    size_t dy_more[pf_train::kDySlots] = {}, wpart_more[pf_train::kSideStreams] = {};   // side streams: further dy slots, per stream the partial sums
     size_t up_tmp = 0;                 // scratch of the two-pass bilinear transpose
     size_t tune_grad = 0;              // autotune: the measuring pass's parameter gradients (discarded)
     size_t grad_begin = 0, grad_end = 0;
@@ -180,6 +181,7 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
     L.grad.assign(nt, (size_t)-1);
     L.ypre.assign(p->ops.size(), (size_t)-1);
     L.stat.assign(p->ops.size(), (size_t)-1);
+    L.xpad.assign(p->ops.size(), (size_t)-1);
     size_t cur = 0;
     auto take = [&](size_t bytes) {
         const size_t o = cur;
@@ -222,6 +224,7 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
             tp = tiled_packed_floats(&one, 1, (int)o.src[j].ch, (int)o.k, 1);
             max_wpk = tp > max_wpk ? tp : max_wpk;
         }
+        if ((in.w & 3) && o.stride == 1) L.xpad[i] = take((size_t)B * o.cin * in.h * ((in.w + 3) / 4 * 4) * sizeof(float));
         if (in.w & 3) {     // padded copies (forward: cin -> cout at the output size; backward-data: cout -> cin at the input size)
             const size_t wp_in = (size_t)(in.w + 3) / 4 * 4, cmax = o.cin > o.cout ? o.cin : o.cout;
             const size_t bytes = (size_t)B * cmax * in.h * wp_in * sizeof(float);
@@ -278,7 +281,6 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
     L.dy = take(max_dy + 256);
     if (p->side) {
         for (int k = 1; k < pf_train::kDySlots; ++k) L.dy_more[k] = take(max_dy + 256);
-        for (int k = 0; k < pf_train::kSideStreams; ++k) L.pad_in_w[k] = take(max_pin);
     }
     L.wpk = take(max_wpk * sizeof(float));
     L.wpart = take(max_wpart * sizeof(float));
@@ -480,6 +482,7 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
     float *wpk = reinterpret_cast<float *>(wsb + L.wpk);
     float *wpart = reinterpret_cast<float *>(wsb + L.wpart);
     float *pad_in = reinterpret_cast<float *>(wsb + L.pad_in), *pad_out = reinterpret_cast<float *>(wsb + L.pad_out);
+    float *gather_to = pad_in;      // where run_conv's odd-width path puts its gathered input (forward: the op's kept copy)
     float *dfull = reinterpret_cast<float *>(wsb + L.dfull);
     double *cepart = reinterpret_cast<double *>(wsb + L.cepart);
     float *up_tmp = g_opt_up_two_pass ? reinterpret_cast<float *>(wsb + L.up_tmp) : nullptr;
@@ -548,10 +551,10 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
             // odd width: the same kernels on copies whose rows are padded to a multiple of 4 (train_kernels.hip)
             const int Wp = (a.Win + 3) / 4 * 4, pad = ks / 2;
             const int Wop = (Wp + 2 * pad - ks) / stride + 1;
-            if ((rc2 = launch_pad_gather(a, B, Wp, pad_in, s))) return rc2;
+            if ((rc2 = launch_pad_gather(a, B, Wp, gather_to, s))) return rc2;
             ConvArgs c = a;
             c.n_src = 1;
-            c.src[0] = pad_in; c.src_ctotal[0] = a.Cin; c.src_choff[0] = 0; c.src_cstart[0] = 0;
+            c.src[0] = gather_to; c.src_ctotal[0] = a.Cin; c.src_choff[0] = 0; c.src_cstart[0] = 0;
             for (int k = 1; k <= kConvMaxSrc; ++k) c.src_cstart[k] = a.Cin;
             c.src_begin = 0; c.src_end = 1;
             c.Win = Wp; c.Wout = Wop;
@@ -578,6 +581,7 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
             for (uint32_t j = 0; j < o.n_src; ++j) src_ch[j] = (int)o.src[j].ch;
             ConvArgs a;
             conv_args(o, in, out, a);
+            gather_to = L.xpad[i] != (size_t)-1 ? reinterpret_cast<float *>(wsb + L.xpad[i]) : pad_in;
             if (p->bn[i]) {
                 float *y = reinterpret_cast<float *>(wsb + L.ypre[i]);
                 a.dst = y; a.dst_ctotal = (int)o.cout; a.dst_choff = 0; a.relu = 0;
@@ -607,6 +611,7 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
     }
 
     // ================================================================ backward
+    gather_to = pad_in;
     // With the side streams: layer n's conv-output gradient goes to dy slot n % kDySlots; the weight gradient (and its padded
     // copy of x) reads it on side stream n % kSideStreams while the caller's stream goes on to the input gradients and the next
     // layers; before it overwrites a slot it waits for the weight gradient of layer n - kDySlots that last read it.
@@ -645,22 +650,21 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
             }
             // dW
             hipStream_t sw = s;
-            float *wpad_in = pad_in, *wpart_l = wpart;
+            float *wpart_l = wpart;
             if (p->side) {
                 PF_HIP_CHECK(hipEventRecord(p->ev_dy[slot], s));
                 sw = p->sides[sidx];
                 PF_HIP_CHECK(hipStreamWaitEvent(sw, p->ev_dy[slot], 0));
-                wpad_in = reinterpret_cast<float *>(wsb + L.pad_in_w[sidx]);
                 if (sidx) wpart_l = reinterpret_cast<float *>(wsb + L.wpart_more[sidx]);
             }
             ConvArgs a;
             conv_args(o, in, out, a);
             if (odd) {
-                // odd width: the tiled kernel on a padded copy of x (all ranges gathered) and the padded dy; zero pad columns add nothing
-                if ((rc = launch_pad_gather(a, B, Wp, wpad_in, sw))) return rc;
+                // odd width: the tiled kernel on the padded copy of x the forward pass gathered (all ranges) and the padded dy; zero
+                // pad columns add nothing
                 ConvArgs ap = a;
                 ap.n_src = 1;
-                ap.src[0] = wpad_in; ap.src_ctotal[0] = (int)o.cin; ap.src_choff[0] = 0; ap.src_cstart[0] = 0;
+                ap.src[0] = reinterpret_cast<float *>(wsb + L.xpad[ii]); ap.src_ctotal[0] = (int)o.cin; ap.src_choff[0] = 0; ap.src_cstart[0] = 0;
                 for (int k = 1; k <= kConvMaxSrc; ++k) ap.src_cstart[k] = (int)o.cin;
                 ap.Win = Wp; ap.Wout = Wp;
                 if ((rc = launch_wgrad(ap, (int)o.k, 1, dy, B, wpart_l, grad + p->w_off[ii], sw))) return rc;
