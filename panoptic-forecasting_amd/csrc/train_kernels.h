@@ -47,10 +47,11 @@ int launch_wgrad(const ConvArgs &a, int ks, int stride, const float *dy, int B, 
 // [B][C][H][Wp] -> channels [dst_choff, dst_choff + C) of a [B][dst_ctotal][H][W] tensor
 int launch_pad_gather(const ConvArgs &a, int B, int Wp, float *dst, hipStream_t s);
 int launch_unpad_scatter_multi(const float *src, int B, int C, int H, int W, int Wp, float *const *dst /* null = skip */, const int *ctotal,
-                               const int *choff, const int *ch, int n, hipStream_t s);
+                               const int *choff, const int *ch, const int *overwrite /* per range: 1 = store, 0 = add */, int n, hipStream_t s);
 int launch_unpad_scatter(const float *src, int B, int C, int H, int W, int Wp, float *dst, int dst_ctotal, int dst_choff, int accum, hipStream_t s);
 int launch_zero_stuff(const float *dy, int planes, int Hout, int Wout, int Hin, int Win, float *up, hipStream_t s);
-int launch_avgpool2_bwd(const float *gout, int planes, int Hin, int Win, float *gin, hipStream_t s);
+int launch_avgpool2_bwd(const float *gout, int planes, int Hin, int Win, int overwrite /* 0: gin += */, float *gin, hipStream_t s);
+int launch_zero_channels(float *t, int B, int ctotal, int c0, int n, long long HW, hipStream_t s);
 // gin (+)= bilinear^T(gout) [* scale / *count when count != nullptr].  tmp: upsample_bwd_tmp_floats() floats of scratch (0 =
 // small planes, none needed; tmp may be null: the one-pass kernel, same bits)
 size_t upsample_bwd_tmp_floats(int planes, int Hi, int Wi, int Ho, int Wo);

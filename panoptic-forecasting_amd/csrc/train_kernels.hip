@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void unpad_scatter_kernel(const float *src, in
 // range's tensor (a null destination - the network input - is skipped)
 struct ScatterArgs {
     float *dst[kConvMaxSrc];
-    int ctotal[kConvMaxSrc], choff[kConvMaxSrc], cstart[kConvMaxSrc + 1], n;
+    int ctotal[kConvMaxSrc], choff[kConvMaxSrc], cstart[kConvMaxSrc + 1], overwrite[kConvMaxSrc], n;
 };
 __global__ __launch_bounds__(256) void unpad_scatter_multi_kernel(const float *src, int C, int H, int W, int Wp, ScatterArgs t) {
     const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
@@ -885,23 +885,37 @@ __global__ __launch_bounds__(256) void unpad_scatter_multi_kernel(const float *s
     if (!t.dst[j]) return;
     const int y = i / W, x = i - y * W;
     float *d = t.dst[j] + ((long long)b * t.ctotal[j] + t.choff[j] + (c - t.cstart[j])) * H * W + i;
-    *d += src[((long long)bc * H + y) * Wp + x];
+    const float v = src[((long long)bc * H + y) * Wp + x];
+    *d = t.overwrite[j] ? v : *d + v;
 }
 int launch_unpad_scatter_multi(const float *src, int B, int C, int H, int W, int Wp, float *const *dst, const int *ctotal, const int *choff,
-                               const int *ch, int n, hipStream_t s) {
+                               const int *ch, const int *overwrite, int n, hipStream_t s) {
     if (n < 1 || n > kConvMaxSrc) return fail(PF_EINVAL, "unpad_scatter_multi: %d ranges", n);
     ScatterArgs t;
     memset(&t, 0, sizeof(t));
     t.n = n;
     int c0 = 0;
     for (int j = 0; j < n; ++j) {
-        t.dst[j] = dst[j]; t.ctotal[j] = ctotal[j]; t.choff[j] = choff[j]; t.cstart[j] = c0;
+        t.dst[j] = dst[j]; t.ctotal[j] = ctotal[j]; t.choff[j] = choff[j]; t.cstart[j] = c0; t.overwrite[j] = overwrite[j];
         c0 += ch[j];
     }
     for (int j = n; j <= kConvMaxSrc; ++j) t.cstart[j] = c0;
     if (c0 != C) return fail(PF_EINVAL, "unpad_scatter_multi: ranges cover %d of %d channels", c0, C);
     hipLaunchKernelGGL(unpad_scatter_multi_kernel, dim3((unsigned)((H * W + 255) / 256), B * C), dim3(256), 0, s, src, C, H, W, Wp, t);
     PF_LAUNCH_CHECK("unpad_scatter_multi_kernel");
+    return PF_OK;
+}
+// zeros in channels [c0, c0 + n) of a [B][ctotal][HW] tensor (the few gradient channels whose first writer accumulates)
+__global__ __launch_bounds__(256) void zero_channels_kernel(float *t, long long run, long long batch_stride) {
+    float *p = t + (long long)blockIdx.y * batch_stride;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < run; i += (long long)gridDim.x * 256) p[i] = 0.f;
+}
+int launch_zero_channels(float *t, int B, int ctotal, int c0, int n, long long HW, hipStream_t s) {
+    const long long run = (long long)n * HW;
+    long long blocks = (run + 1023) / 1024;
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(zero_channels_kernel, dim3((unsigned)blocks, B), dim3(256), 0, s, t + (long long)c0 * HW, run, (long long)ctotal * HW);
+    PF_LAUNCH_CHECK("zero_channels_kernel");
     return PF_OK;
 }
 int launch_pad_gather(const ConvArgs &a, int B, int Wp, float *dst, hipStream_t s) {
@@ -940,15 +954,18 @@ int launch_zero_stuff(const float *dy, int planes, int Hout, int Wout, int Hin, 
 
 // ------------------------------------------------------------------------------------------------ pool / upsample backward
 // AvgPool2d(2,2): gin[2y+dy][2x+dx] += 0.25 * gout[y][x]   (rows/cols dropped by the floor division get no gradient)
-__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float *gout, int Hin, int Win, float *gin) {
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float *gout, int Hin, int Win, int overwrite, float *gin) {
     const int bc = blockIdx.y, Ho = Hin >> 1, Wo = Win >> 1;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)Hin * Win) return;
     const int y = (int)(i / Win), x = (int)(i - (long long)y * Win);
-    if ((y >> 1) < Ho && (x >> 1) < Wo) gin[(long long)bc * Hin * Win + i] += 0.25f * gout[((long long)bc * Ho + (y >> 1)) * Wo + (x >> 1)];
+    const float v = ((y >> 1) < Ho && (x >> 1) < Wo) ? 0.25f * gout[((long long)bc * Ho + (y >> 1)) * Wo + (x >> 1)] : 0.f;
+    float *d = gin + (long long)bc * Hin * Win + i;
+    if (overwrite) *d = v;
+    else *d += v;
 }
-int launch_avgpool2_bwd(const float *gout, int planes, int Hin, int Win, float *gin, hipStream_t s) {
-    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3((unsigned)(((long long)Hin * Win + 255) / 256), planes), dim3(256), 0, s, gout, Hin, Win, gin);
+int launch_avgpool2_bwd(const float *gout, int planes, int Hin, int Win, int overwrite, float *gin, hipStream_t s) {
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3((unsigned)(((long long)Hin * Win + 255) / 256), planes), dim3(256), 0, s, gout, Hin, Win, overwrite, gin);
     PF_LAUNCH_CHECK("avgpool2_bwd_kernel");
     return PF_OK;
 }
