@@ -33,10 +33,11 @@ int launch_pack_weights_batch(const float *theta, float *arena, const PackJob *j
 size_t bn_partial_doubles(int C);
 int launch_bn_forward(const float *y, int B, int C, int H, int W, float eps, float momentum, const float *gamma, const float *beta,
                       float *running_mean, float *running_var, float *mean, float *invstd, double *partial, float *dst, int dst_ctotal,
-                      int dst_choff, int relu, hipStream_t s);
+                      int dst_choff, int relu, int y_pitch /* 0 = dense; else floats per row of y (>= W) */, hipStream_t s);
 int launch_bn_backward(const float *g, int t_ctotal, int choff, const float *y, const float *mean, const float *invstd,
                        const float *gamma, const float *beta, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial,
-                       float *dy, int dy_pitch /* 0 = dense rows; else floats per row (>= W), pad columns zeroed */, hipStream_t s);
+                       float *dy, int dy_pitch /* 0 = dense rows; else floats per row (>= W), pad columns zeroed */,
+                       int y_pitch /* as launch_bn_forward; then dy_pitch must equal it */, hipStream_t s);
 int launch_bias_backward(const float *g, int t_ctotal, int choff, int B, int C, int H, int W, float *dbias, double *partial /* bn_partial_doubles(C) */,
                          float *dy, int dy_pitch /* as launch_bn_backward */, hipStream_t s);
 int wgrad_slabs(int cout, int cin, int ks, int B, int Hout, int Win, int Wout);

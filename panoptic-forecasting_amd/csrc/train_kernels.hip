@@ -210,14 +210,20 @@ int launch_pack_weights_batch(const float *theta, float *arena, const PackJob *j
 // partial[c][slab][k]: k = 0 sum(y), 1 sum(y^2)  (stats)   or   0 sum(g'), 1 sum(g' * xhat)  (backward)
 constexpr int kBnSlabs = 64;
 
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float *y, int B, int C, long long HW, double *partial) {
+// y of an odd-width layer is the tiled convolution's own output: rows of Wp >= W floats (pad columns hold garbage and are never
+// read).  Element p of plane (b, c) of a [..][H][W] tensor stored with row pitch Wp:
+__device__ __forceinline__ long long pitched(long long plane, long long p, long long HW, int W, int Wp) {
+    return W == Wp ? plane * HW + p : (plane * (HW / W) + p / W) * Wp + p % W;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float *y, int B, int C, long long HW, int W, int Wp, double *partial) {
     const int c = blockIdx.x, slab = blockIdx.y;
     __shared__ double sm[2 * 4];
     double v[2] = {0.0, 0.0};
     const long long per = (long long)B * HW;
     for (long long i = (long long)slab * 256 + threadIdx.x; i < per; i += (long long)kBnSlabs * 256) {
         const long long b = i / HW, p = i - b * HW;
-        const double x = (double)y[((long long)b * C + c) * HW + p];
+        const double x = (double)y[pitched((long long)b * C + c, p, HW, W, Wp)];
         v[0] += x;
         v[1] += x * x;
     }
@@ -286,21 +292,20 @@ __device__ __forceinline__ void bn_finish_bwd(const double *partial, int c, bool
 
 // z = relu(gamma * (y - mean) * invstd + beta) into channel slice [choff, choff + C) of the destination tensor
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float *y, BnStats st, const float *gamma,
-                                                            const float *beta, int C, long long HW, float *dst, int dst_ctotal, int dst_choff,
-                                                            int relu) {
+                                                            const float *beta, int C, long long HW, int W, int Wp, float *dst, int dst_ctotal,
+                                                            int dst_choff, int relu) {
     const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
     const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     float mean_c, invstd_c;
     bn_finish_stats(st, c, blockIdx.x == 0 && b == 0 && threadIdx.x == 0, mean_c, invstd_c);
     if (i4 >= HW) return;
     const float sc = gamma[c] * invstd_c, sh = beta[c] - mean_c * sc;
-    const float *yp = y + (long long)bc * HW + i4;
     float *dp = dst + ((long long)b * dst_ctotal + dst_choff + c) * HW + i4;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (i4 + k < HW) {
             // (y - mean) * invstd * gamma + beta, written as one scale/shift like ATen's batch_norm CPU/CUDA transforms
-            float v = __builtin_fmaf(yp[k], sc, sh);      // (the backward pass redoes exactly this to know where the ReLU cut)
+            float v = __builtin_fmaf(y[pitched(bc, i4 + k, HW, W, Wp)], sc, sh);      // (the backward pass redoes exactly this to know where the ReLU cut)
             dp[k] = relu ? fmaxf(v, 0.f) : v;
         }
 }
@@ -397,18 +402,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float *g, cons
 
 int launch_bn_forward(const float *y, int B, int C, int H, int W, float eps, float momentum, const float *gamma, const float *beta,
                       float *running_mean, float *running_var, float *mean, float *invstd, double *partial, float *dst, int dst_ctotal,
-                      int dst_choff, int relu, hipStream_t s) {
+                      int dst_choff, int relu, int y_pitch, hipStream_t s) {
     const long long HW = (long long)H * W;
-    const bool vec = (HW & 3) == 0 && HW / 4 < (1ll << 31);
+    const int Wp = y_pitch > 0 ? y_pitch : W;
+    const bool vec = (HW & 3) == 0 && HW / 4 < (1ll << 31) && Wp == W;
     if (vec) hipLaunchKernelGGL(bn_stats_partial4_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, y, B, C, (int)(HW / 4), partial);
-    else hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, y, B, C, HW, partial);
+    else hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, y, B, C, HW, W, Wp, partial);
     const BnStats st{partial, (double)B * HW, eps, momentum, mean, invstd, running_mean, running_var};
     if (vec)
         hipLaunchKernelGGL(bn_apply_relu4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), B * C), dim3(256), 0, s, y, st, gamma, beta, C,
                            (int)(HW / 4), dst, dst_ctotal, dst_choff, relu);
     else
         hipLaunchKernelGGL(bn_apply_relu_kernel, dim3((unsigned)((HW / 4 + 256) / 256), B * C), dim3(256), 0, s, y, st, gamma, beta, C, HW,
-                           dst, dst_ctotal, dst_choff, relu);
+                           W, Wp, dst, dst_ctotal, dst_choff, relu);
     PF_LAUNCH_CHECK("bn_forward");
     return PF_OK;
 }
@@ -418,7 +424,7 @@ size_t bn_partial_doubles(int C) { return (size_t)C * kBnSlabs * 2; }
 //                              dy = gamma * invstd * (g' - dbeta / N - xhat * dgamma / N)
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *g, const float *gamma, const float *beta, int t_ctotal, int choff,
                                                              const float *y, const float *mean, const float *invstd, int B, int C, long long HW,
-                                                             int relu, double *partial) {
+                                                             int W, int Wp, int relu, double *partial) {
     const int c = blockIdx.x, slab = blockIdx.y;
     __shared__ double sm[2 * 4];
     double v[2] = {0.0, 0.0};
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *g, con
     for (long long i = (long long)slab * 256 + threadIdx.x; i < per; i += (long long)kBnSlabs * 256) {
         const long long b = i / HW, p = i - b * HW;
         const long long ti = ((long long)b * t_ctotal + choff + c) * HW + p;
-        const float yv = y[((long long)b * C + c) * HW + p];
+        const float yv = y[pitched((long long)b * C + c, p, HW, W, Wp)];
         const float gp = (!relu || __builtin_fmaf(yv, sc, sh) > 0.f) ? g[ti] : 0.f;
         const float xh = (yv - mu) * is;
         v[0] += (double)gp;
@@ -460,7 +466,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *g, const
 // odd-width level read (launch_pad_gather's, without the copy)
 __global__ __launch_bounds__(256) void bn_bwd_apply_pitch_kernel(const float *g, const float *beta, int t_ctotal, int choff, const float *y,
                                                                  const float *mean, const float *invstd, const float *gamma, const double *partial,
-                                                                 float *dgamma, float *dbeta, int B, int C, int H, int W, int Wp, int relu, float *dy) {
+                                                                 float *dgamma, float *dbeta, int B, int C, int H, int W, int Wp, int relu, int y_pitched,
+                                                                 float *dy) {
     const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
     const int ip = blockIdx.x * 256 + threadIdx.x;
     float sum_g, sum_gx;
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pitch_kernel(const float *g,
         const long long HW = (long long)H * W, i = (long long)yy * W + x;
         const float n = (float)((double)B * (double)HW);
         const long long ti = ((long long)b * t_ctotal + choff + c) * HW + i;
-        const float yv = y[(long long)bc * HW + i], sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+        const float yv = y[y_pitched ? (long long)bc * H * Wp + ip : (long long)bc * HW + i], sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
         const float gp = (!relu || __builtin_fmaf(yv, sc, sh) > 0.f) ? g[ti] : 0.f;
         const float xh = (yv - mean[c]) * invstd[c];
         o = gamma[c] * invstd[c] * (gp - sum_g / n - xh * sum_gx / n);
@@ -482,18 +489,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pitch_kernel(const float *g,
 
 int launch_bn_backward(const float *g, int t_ctotal, int choff, const float *y, const float *mean, const float *invstd,
                        const float *gamma, const float *beta, int B, int C, int H, int W, int relu, float *dgamma, float *dbeta, double *partial, float *dy,
-                       int dy_pitch, hipStream_t s) {
+                       int dy_pitch, int y_pitch, hipStream_t s) {
     const long long HW = (long long)H * W;
-    const bool vec = (HW & 3) == 0 && HW / 4 < (1ll << 31);
+    const int Wyp = y_pitch > 0 ? y_pitch : W;
+    if (Wyp != W && dy_pitch != Wyp) return fail(PF_EINVAL, "bn_backward: a pitched y needs dy with the same pitch");
+    const bool vec = (HW & 3) == 0 && HW / 4 < (1ll << 31) && Wyp == W;
     if (vec)
         hipLaunchKernelGGL(bn_bwd_partial4_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, gamma, beta, t_ctotal, choff, y, mean, invstd, B, C,
                            (int)(HW / 4), relu, partial);
     else
-        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, gamma, beta, t_ctotal, choff, y, mean, invstd, B, C, HW, relu,
-                           partial);
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C, kBnSlabs), dim3(256), 0, s, g, gamma, beta, t_ctotal, choff, y, mean, invstd, B, C, HW, W, Wyp,
+                           relu, partial);
     if (dy_pitch > 0 && dy_pitch != W)
         hipLaunchKernelGGL(bn_bwd_apply_pitch_kernel, dim3((unsigned)((H * dy_pitch + 255) / 256), B * C), dim3(256), 0, s, g, beta, t_ctotal, choff, y, mean,
-                           invstd, gamma, partial, dgamma, dbeta, B, C, H, W, dy_pitch, relu, dy);
+                           invstd, gamma, partial, dgamma, dbeta, B, C, H, W, dy_pitch, relu, Wyp != W, dy);
     else if (vec)
         hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), B * C), dim3(256), 0, s, g, beta, t_ctotal, choff, y, mean,
                            invstd, gamma, partial, dgamma, dbeta, B, C, (int)(HW / 4), relu, dy);

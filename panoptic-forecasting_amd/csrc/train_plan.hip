@@ -256,7 +256,8 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
         const TDims in = d[o.src[0].tensor], out = d[o.dst];
         const size_t ybytes = (size_t)B * o.cout * out.h * out.w * sizeof(float);
         if (p->bn[i]) {
-            L.ypre[i] = take(ybytes);
+            // (odd width, stride 1: y keeps the tiled kernel's padded rows)
+            L.ypre[i] = take((in.w & 3) && o.stride == 1 ? (size_t)B * o.cout * out.h * ((out.w + 3) / 4 * 4) * sizeof(float) : ybytes);
             L.stat[i] = take(2 * (size_t)o.cout * sizeof(float));
         }
         // dy scratch: the conv-output gradient, and (stride 2) its zero-stuffed copy at the input resolution
@@ -536,6 +537,8 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
     float *wpart = reinterpret_cast<float *>(wsb + L.wpart);
     float *pad_in = reinterpret_cast<float *>(wsb + L.pad_in), *pad_out = reinterpret_cast<float *>(wsb + L.pad_out);
     float *gather_to = pad_in;      // where run_conv's odd-width path puts its gathered input (forward: the op's kept copy)
+    bool keep_padded = false;       // run_conv's odd-width path leaves its result in a.dst with padded rows (forward, conv + BN: the
+                                    // BatchNorm kernels read y with that pitch, forward and backward - no unpad pass)
     float *dfull = reinterpret_cast<float *>(wsb + L.dfull);
     double *cepart = reinterpret_cast<double *>(wsb + L.cepart);
     float *up_tmp = g_opt_up_two_pass ? reinterpret_cast<float *>(wsb + L.up_tmp) : nullptr;
@@ -613,9 +616,11 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
             for (int k = 1; k <= kConvMaxSrc; ++k) c.src_cstart[k] = a.Cin;
             c.src_begin = 0; c.src_end = 1;
             c.Win = Wp; c.Wout = Wop;
-            c.dst = pad_out; c.dst_ctotal = a.Cout; c.dst_choff = 0; c.accum = 0;
+            c.dst = keep_padded ? a.dst : pad_out; c.dst_ctotal = a.Cout; c.dst_choff = 0; c.accum = 0;
             const int one = a.Cin;
             rc2 = fast(c, &one, 1);
+            if (rc2 == PF_OK && keep_padded) return PF_OK;
+            if (keep_padded && rc2 == PF_EUNSUPPORTED) return fail(PF_EUNSUPPORTED, "training: no tiled kernel for an odd-width conv + BatchNorm layer");
             if (rc2 == PF_OK) return launch_unpad_scatter(pad_out, B, a.Cout, a.Hout, a.Wout, Wop, a.dst, a.dst_ctotal, a.dst_choff, a.accum, s);
             if (rc2 != PF_EUNSUPPORTED) return rc2;
         }
@@ -640,13 +645,17 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
             if (p->bn[i]) {
                 float *y = reinterpret_cast<float *>(wsb + L.ypre[i]);
                 a.dst = y; a.dst_ctotal = (int)o.cout; a.dst_choff = 0; a.relu = 0;
-                if ((rc = run_conv(a, (int)o.k, (int)o.stride, theta + p->w_off[i], (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, 0, 0, 0, L.fwd_job[i]))) return rc;
+                const bool odd_f = (in.w & 3) != 0 && o.stride == 1;
+                keep_padded = odd_f;
+                rc = run_conv(a, (int)o.k, (int)o.stride, theta + p->w_off[i], (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, 0, 0, 0, L.fwd_job[i]);
+                keep_padded = false;
+                if (rc) return rc;
                 float *aux = theta + p->aux_off[i];
                 float *stat = reinterpret_cast<float *>(wsb + L.stat[i]);
                 if ((rc = launch_bn_forward(y, B, (int)o.cout, out.h, out.w, bn_eps, bn_momentum, aux, aux + o.cout,
                                             update_running_stats ? aux + 2 * o.cout : nullptr, update_running_stats ? aux + 3 * o.cout : nullptr,
                                             stat, stat + o.cout, bnpart, act(o.dst), (int)p->tensors[o.dst].channels, (int)o.dst_choff,
-                                            (int)o.relu, s)))
+                                            (int)o.relu, odd_f ? (out.w + 3) / 4 * 4 : 0, s)))
                     return rc;
             } else {
                 a.bias = theta + p->aux_off[i];
@@ -697,7 +706,7 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
                 const float *stat = reinterpret_cast<const float *>(wsb + L.stat[ii]);
                 if ((rc = launch_bn_backward(gradt(o.dst), t_ctotal, (int)o.dst_choff, reinterpret_cast<const float *>(wsb + L.ypre[ii]),
                                              stat, stat + o.cout, aux, aux + o.cout, B, (int)o.cout, out.h, out.w, (int)o.relu, gaux, gaux + o.cout, bnpart,
-                                             dy, odd ? Wp : 0, s)))
+                                             dy, odd ? Wp : 0, odd ? Wp : 0, s)))
                     return rc;
             } else {
                 if (o.relu) return fail(PF_EUNSUPPORTED, "training: ReLU without BatchNorm (op %zu)", ii);
