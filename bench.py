@@ -22,13 +22,18 @@ when the ranks that joined differ from ``--gpus`` or the node has fewer GPUs tha
 
 At N=1 the same line also carries (driver-timed, same process):
     by_batch   frames/s of ONE stream at B = 1, 2, 4 frames per step (SURVEY.md 8d Config 2; the reference loop batches 2)
+    fresh_cameras  eager B = 2 / 16 with NEW camera tensors every step: inverses taken on the host batch vs read back by the model
+    other_resolution  512x1024 at B = 16, one stream: the heuristic (untuned) kernel choice, frames/s + dominant-kernel fraction
+    train_step  one bg training step at batch 8 of 800x800 (configs/bg/bg_train.yaml): ms, dominant kernel + its fraction of the fp32 matrix peak
     fp32_only  the headline workload with every convolution on the fp32 MFMA (no two-term fp16 operands) + its parity
     roofline   dominant kernel (live hipEvent timing) + ``step``: whole-step algorithmic bytes / kernel time, per stage
     cpu_baseline  the oracle pipeline on the host cores: at the best torch thread count of a short sweep (`value`) and on all of
                   them (`value_all_cores`)
-    range_overflow  false = no forward of the timed region met an activation outside the range of the fp16-pair path
-                  (PF_STATUS_RANGE / PF_STATUS_RANGE_LOW, include/pfhip.h; read from the workspaces' sticky status words after the
-                  timed region); a true here would invalidate the run and bench.py exits non-zero
+    range_overflow  false = no forward inside a captured graph of the timed region met an activation outside the range of the
+                  fp16-pair path (PF_STATUS_RANGE / PF_STATUS_RANGE_LOW, include/pfhip.h; read from the workspaces' sticky status
+                  words after the timed region); a true here would invalidate the run and bench.py exits non-zero.  Eager
+                  forwards (--no-graph) that were flagged have been re-run on fp32 MFMA (`range_reruns`): valid, not an error;
+                  `range_status_sticky` carries the raw word either way
 """
 import argparse
 import glob
@@ -406,6 +411,139 @@ class Workload:
         return {k: torch.cat([o[k] for o in self.out]) for k in self.out[0]}
 
 
+def fresh_cameras_leg(sd, dev, term):
+    """The reference-shaped loop makes NEW camera tensors every batch (loader -> batch2gpu -> predict,
+    export_cityscapes_segmentation_results.py:75-85), so the model's per-tensor inverse cache - which the replayed headline
+    hits - never does.  Eager predicts on one stream at B = 2 (the reference's batch size) and B = 16, the big tensors
+    resident, the camera tensors rebuilt from host memory every step, three ways:
+      cached          the same device tensors every step (what every other leg of this file times)
+      host_inverses   K^-1 / E^-1 taken on the host batch before the move (pc_transform_model.add_camera_inverses, what
+                      export_bg.py does): five small H2D copies per step, nothing read back, no stream synchronisation
+      device_cameras  fresh device tensors without inverses (an unmodified caller): the model reads K and E back, inverts with
+                      LAPACK and uploads - two stream synchronisations per predict"""
+    from panoptic_forecasting_amd.pc_transform_model import add_camera_inverses
+    cam_keys = ('intrinsics', 'extrinsics', 'target_T')
+    res = {}
+    for b, steps in ((2, 240), (16, 48)):
+        m = build_model(model_params())
+        m.load_state_dict(sd)
+        m.eval()
+        host = {k: torch.cat([synth.make_inputs(b=1, t=T, h=H, w=W, seed=i, **TERM[term])[k] for i in range(b)], 0)
+                for k in ('depth', 'depth_mask', 'seg') + cam_keys}
+        big = {k: host[k].to(dev) for k in ('depth', 'depth_mask', 'seg')}
+        cams_host = {k: host[k].pin_memory() for k in cam_keys}
+        cams_dev = {k: v.to(dev) for k, v in cams_host.items()}
+
+        def step(mode):
+            if mode == 'cached':
+                cams = cams_dev
+            elif mode == 'host_inverses':
+                fresh = add_camera_inverses({k: v.clone() for k, v in cams_host.items()})
+                cams = {k: v.pin_memory().to(dev, non_blocking=True) for k, v in fresh.items()}
+            else:
+                cams = {k: v.clone().to(dev, non_blocking=True) for k, v in cams_host.items()}
+            return m.predict(dict(big, **cams), None)
+        leg = {}
+        for mode in ('cached', 'host_inverses', 'device_cameras'):
+            for _ in range(5):
+                step(mode)
+            m.bg.settle()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(mode)
+            m.bg.settle()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            leg[mode] = {'value': b * steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / steps}
+        leg['steps'], leg['launch'] = steps, 'eager, one stream'
+        res[str(b)] = leg
+        del m, big, cams_dev
+        torch.cuda.empty_cache()
+    return res
+
+
+def other_resolution_leg(sd, dev, term, steps):
+    """A second resolution, 512x1024 at B = 16 on one stream (hipGraph replay): no row of the measured kernel tables
+    (csrc/conv_s4_tuned.inc, conv_tuned.inc: keyed on the 1024x2048 network's exact shapes) matches, so every layer runs the
+    kernel the heuristics of conv_select.cpp pick - frames/s plus the dominant kernel's roofline fraction of that untuned
+    choice.  Parity at this size: tests/test_gpu_bg_forecast.py::test_second_resolution_heuristic_kernel_choice_vs_oracle."""
+    h, w, b = 512, 1024, 16
+    parts = [synth.make_inputs(b=1, t=T, h=h, w=w, seed=i, **TERM[term]) for i in range(b)]
+    batch = {k: torch.cat([p[k] for p in parts], 0).to(dev) for k in parts[0]}
+    m = build_model(model_params(final_h=h, final_w=w))
+    m.load_state_dict(sd)
+    m.eval()
+    for _ in range(3):
+        m.predict(batch, None)
+    m.bg.settle()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        m.predict(batch, None)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sticky = m.bg.range_status_sticky(clear=True)
+    recs = profile_records(lambda: m.predict(batch, None), 2)
+    m.bg.settle()
+    r = roofline_of(recs, 2, b, 'one batch of %d frames at %dx%d, eager, hipEvents' % (b, h, w))
+    res = {'value': b * steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'frames_per_step': b,
+           'size': [h, w], 'streams': 1, 'launch': 'hipGraph replay', 'kernel_choice': 'heuristic (no tuned-table row matches)',
+           'range_status_sticky': int(sticky),
+           'roofline': {k: r[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'avg_launch_us', 'launches_per_step',
+                                          'kernel_ms_per_step')},
+           'roofline_step_frac': r['step']['frac']}
+    del m, batch, g
+    torch.cuda.empty_cache()
+    return res, sticky
+
+
+def train_step_leg(sd, steps=10):
+    """Scope row f4, driver-timed: one bg training step (forward with batch statistics + loss + backward + clipped SGD,
+    training/train.py:185-222) on the reference's configuration - batch 8 of 800x800 crops, 3 input frames
+    (configs/bg/bg_train.yaml:25,48) - with the library's defaults (eager launches, weight gradients on the plan's own stream).
+    The same configuration is parity-tested against the oracle in tests/test_gpu_train.py::test_timed_configuration_800x800_vs_oracle."""
+    from panoptic_forecasting_amd import lib as pflib
+    from panoptic_forecasting_amd.bg_train import BGTrainer
+    b, size = 8, 800
+    params = {'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])]},
+              'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True},
+              'training': {'lr': 2e-3, 'mom': 0.9, 'wd': 1e-4, 'clip_grad_norm': 5.0}}
+    tr = BGTrainer(params)
+    tr.load_state_dict(sd)
+    inp = {k: v.cuda() for k, v in synth.make_bg_inputs(b=b, h=size, w=size, seed=1).items()}
+    inp['seg'] = inp['seg'].to(torch.uint8)
+    lab = {'seg': torch.randint(0, 11, (b, size, size), dtype=torch.uint8, device='cuda')}
+    for _ in range(3):
+        tr.train_step(inp, lab)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tr.train_step(inp, lab)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    stats = tr.path_stats()
+    recs = profile_records(lambda: tr.train_step(inp, lab), 1)
+    dom = max(recs, key=lambda r: r['ms'])
+    tf = dom['flops'] / max(dom['ms'], 1e-9) / 1e9
+    res = {'ms_per_step': ms, 'samples_per_s': b / ms * 1e3, 'batch': b, 'size': size, 'steps': steps, 'dtype': 'f32',
+           'launch': 'eager, weight gradients on their own stream' if tr.side_stream else 'eager, one stream',
+           'loss': float(out['loss']), 'workspace_GB': tr._ws.numel() / 1e9,
+           'kernel_ms_sum': sum(r['ms'] for r in recs), 'launches': sum(r['launches'] for r in recs), 'path_stats': stats,
+           'dominant_kernel': {'kernel': dom['label'], 'ms_per_step': dom['ms'], 'launches': dom['launches'], 'TFLOPs': tf,
+                               'peak': PEAK_FP32_MFMA_TFLOPS, 'frac': tf / PEAK_FP32_MFMA_TFLOPS, 'bound': 'mfma',
+                               'peak_note': 'fp32 MFMA (= fp32 vector) peak; algorithmic flops of the launches / their hipEvent time'}}
+    del tr, inp, lab
+    torch.cuda.empty_cache()
+    return res
+
+
 STAGES = (('splat', ('bin_kernel', 'raster_kernel', 'splat')), ('stem', ('stem',)), ('head', ('head',)),
           ('convs', ('conv_',)))
 
@@ -584,8 +722,12 @@ def main():
     elapsed = wl.timed(args.steps, args.warmup, dev, barrier=True)
     frames = world * B * R * args.steps
     value = frames / elapsed
-    overflow = wl.range_overflow()
+    sticky = wl.range_overflow()
     reruns = sum(m.bg.range_reruns for m in wl.models)
+    # a flag raised inside a captured graph cannot have been acted on (nothing waits or re-runs under replay): the number is
+    # invalid.  An EAGER forward that was flagged has already been re-run on the fp32 matrix instructions into the same
+    # outputs (the 'rerun' default, counted in range_reruns): valid results - at the re-run's cost, which the line then shows
+    overflow = sticky if use_graph else 0
     # every rank's own step time and device identity: a straggler, or two ranks on one device, shows in the N > 1 line
     ident = pfdist.device_identity(local)
     per_rank = pfdist.gather_objects({'rank': rank, 'ms_per_step': 1e3 * wl.local_s / args.steps, 'device': ident})
@@ -615,7 +757,7 @@ def main():
                     r['label'][:70], r['launches'] // args.profile_steps, r['ms'] / args.profile_steps,
                     r['flops'] / max(r['ms'], 1e-9) / 1e9, r['bytes'] / max(r['ms'], 1e-9) / 1e6), file=sys.stderr)
 
-    cpu = parity = by_batch = fp32_only = None
+    cpu = parity = by_batch = fp32_only = fresh_cameras = train_step = other_resolution = None
     single = rank == 0 and world == 1
     ref = None
     n_done = 0
@@ -655,9 +797,17 @@ def main():
             dt = leg.timed(leg_steps, args.warmup, dev)
             by_batch[str(b)] = {'value': b * leg_steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / leg_steps,
                                 'steps': leg_steps, 'streams': 1}
-            overflow = overflow | leg.range_overflow()
+            st = leg.range_overflow()
+            sticky |= st
+            overflow |= st if use_graph else 0
+            reruns += sum(m.bg.range_reruns for m in leg.models)
             del leg
             torch.cuda.empty_cache()
+        fresh_cameras = fresh_cameras_leg(sd, dev, args.term)
+        if not args.fp32_mfma_only:
+            other_resolution, st = other_resolution_leg(sd, dev, args.term, max(args.steps, 30) * 4)
+            sticky |= st
+            overflow |= st
         if not args.fp32_mfma_only:
             # fp32-instruction configuration: no two-term fp16 operands anywhere (fp32 MFMA / fp32 VALU only)
             leg = Workload(sd, B, S, dev, seed0=0, term=args.term, use_graph=use_graph, stagger=bool(args.stagger), passes=R,
@@ -676,6 +826,9 @@ def main():
                 fp32_only['argmax_agreement_vs_oracle'] = p32['argmax_agreement_vs_oracle']
             del leg
             torch.cuda.empty_cache()
+        del shared_batch
+        torch.cuda.empty_cache()
+        train_step = train_step_leg(sd)
 
     if rank == 0:
         line = {'metric': 'forecast frames/sec @1024x2048, 3-in->dt=%d bg' % (3 if args.term == 'short' else 9), 'value': value, 'unit': 'frames/s',
@@ -689,7 +842,7 @@ def main():
                          'by powers of two chosen from the folded weights; a value beyond 65504 raises PF_STATUS_RANGE, a tensor whose '
                          'maximum is below 2^-6 raises PF_STATUS_RANGE_LOW, and a flagged forward is re-run on fp32 MFMA: see '
                          'range_overflow)', 'data': 'synthetic',
-                'range_overflow': bool(overflow), 'range_status_sticky': int(overflow), 'range_reruns': int(reruns),
+                'range_overflow': bool(overflow), 'range_status_sticky': int(sticky), 'range_reruns': int(reruns),
                 'config': {'workload': ('configs[1]: bg short-term forecast, 3 frames in, dt=3' if args.term == 'short' else
                                         'configs[2]: bg mid-term forecast, 3 frames in, dt=9, predicted-odometry ego chain') +
                                        ', 1024x2048, random-init calibrated weights; step = 3 warp/splats + HarDNet + upsample/argmax',
@@ -708,7 +861,7 @@ def main():
                 'per_rank_ms': [r['ms_per_step'] for r in per_rank],
                 'per_rank_ms_min_max': [min(r['ms_per_step'] for r in per_rank), max(r['ms_per_step'] for r in per_rank)],
                 'devices': [r['device'] for r in per_rank],
-                'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity, 'by_batch': by_batch, 'fp32_only': fp32_only,
+                'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity, 'by_batch': by_batch, 'fresh_cameras': fresh_cameras, 'other_resolution': other_resolution, 'fp32_only': fp32_only, 'train_step': train_step,
                 'pq_gather_check': {'pq_vs_last_input_labels': pq_synth, 'ranks_gathered': int(allacc.shape[0]),
                                     'note': 'random-init weights: value is meaningless, it exercises the sharded PQ all-gather'}}
         print(json.dumps(line))

@@ -249,6 +249,9 @@ int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void 
  *                   of the backward pass - run on the training plan's own lower-priority stream, forked from and joined to the
  *                   caller's stream inside every pf_train_forward_backward (a stream capture of the call stays one graph; the
  *                   results are bit-identical, the workspace grows by one dy slot); 0 = everything on the caller's stream;
+ *   "train_table_batch" (default 0; process-wide only, read by pf_train_forward_backward) n > 0: the measured shape table of the
+ *                   training step's convolutions (csrc/train_tuned.inc, keyed on the batch it was measured at) is consulted as if
+ *                   the batch were n - the kernels of the timed configuration (n = 8) on a batch a CPU checker can afford;
  *   "valu_remainder" (default 1) trailing cout % 16 <= 8 channels of a conv_dma layer on the vector ALU. */
 int pf_set_option(const char *name, int value);
 /* The same options per plan: a plan copies the process-wide values when it is created; this call changes them for
@@ -296,6 +299,12 @@ int pf_train_autotune(pf_train *t, int enable);
  * cout tiles} ({.., 0, 0} = the cost model's own shape won); *n_rows = rows available, at most cap_rows are written.
  * tools/tune_train.py turns them into csrc/train_tuned.inc, the table plans that do not measure consult (option "use_tuned_table"). */
 int pf_train_tuned_shapes(const pf_train *t, int *rows, int cap_rows, int *n_rows);
+/* which code paths the LAST pf_train_forward_backward of this plan took: stats[0] convolutions launched with a row of
+ * csrc/train_tuned.inc, [1] with the cost model's shape, [2] with a shape pf_train_autotune measured, [3] odd-width convolutions
+ * run on row-padded copies (gather), [4] of those, forward conv + BatchNorm layers whose output stayed in padded rows, [5]
+ * odd-width layers whose input gradients came from ONE backward-data conv over all ranges, [6] launches of the generic
+ * (register-staged) kernel.  *n = 7 values available, at most cap are written.  (Tests: the timed configuration's kernels ran.) */
+int pf_train_path_stats(const pf_train *t, int *stats, int cap, int *n);
 int pf_train_param_count(const pf_train *t, size_t *n_floats);
 int pf_train_param_layout(const pf_train *t, int op_index, size_t *w_off, size_t *aux_off, int *has_bn);
 int pf_train_workspace(const pf_train *t, int B, int H, int W, int out_h, int out_w, size_t *bytes);

@@ -6,6 +6,7 @@ Same constructor params, same ``predict``/``forward`` returns and the SAME state
 unchanged.  The nn.Modules here only *hold* parameters; the arithmetic is ``pf_bg_forward`` in
 libpfhip.so (BN folded and weights re-tiled when the plan is built).
 """
+import collections.abc
 import ctypes
 
 import torch
@@ -30,19 +31,31 @@ PF_WS_STATUS_BYTES = 2048
 
 class _Pending:
     """One enqueued forward whose status words are on their way to pinned host memory."""
-    __slots__ = ('slot', 'event', 'stream', 'args', 'outs', 'done')
+    __slots__ = ('slot', 'event', 'stream', 'args', 'outs', 'done', 'stamps')
 
 
-class LazyResult(dict):
-    """``predict``'s result dict.  The forward behind it was only ENQUEUED (the reference's ``predict`` is asynchronous
-    too, bg_model.py:91-102); its status words (include/pfhip.h) follow the outputs to pinned host memory, and the first
-    access of a value waits for that one forward and applies ``on_range_overflow`` - a flagged forward is re-run on the
-    fp32 matrix instructions INTO THE SAME output tensors before the caller sees them, or raises.  Keys can be listed
-    without waiting."""
+def _stamp(t):
+    """(storage address, in-place version) of a tensor argument at enqueue time: a late fp32 re-run reads the caller's input
+    tensors again, so it must see the numbers the flagged forward saw (see ``BGModel._resolve``)."""
+    return (t.data_ptr(), t._version) if torch.is_tensor(t) else None
+
+
+class LazyResult(collections.abc.MutableMapping):
+    """``predict``'s result.  The forward behind it was only ENQUEUED (the reference's ``predict`` is asynchronous too,
+    bg_model.py:91-102); its status words (include/pfhip.h) follow the outputs to pinned host memory, and the first access
+    of a VALUE waits for that one forward and applies ``on_range_overflow`` - a flagged forward is re-run on the fp32 matrix
+    instructions INTO THE SAME output tensors before the caller sees them, or raises.  Keys can be listed (``keys()``,
+    ``in``, ``len``, iteration) without waiting.
+
+    A Mapping, deliberately NOT a ``dict`` subclass: CPython's fast paths for dict subclasses (``dict(res)``, ``{**res}``,
+    ``res | other``, ``update``, pickling) read the underlying storage without calling overridden accessors and would hand out
+    tensors whose range check has not happened.  Here every road to a value goes through ``__getitem__``; ``dict(res)`` /
+    ``{**res}`` / ``copy()`` / pickling resolve and give a plain ``dict``."""
+
+    __slots__ = ('_data', '_model', '_token')
 
     def __init__(self, data, model, token):
-        super().__init__(data)
-        self._model, self._token = model, token
+        self._data, self._model, self._token = dict(data), model, token
 
     def _resolve(self):
         if self._token is not None:
@@ -51,27 +64,42 @@ class LazyResult(dict):
 
     def __getitem__(self, k):
         self._resolve()
-        return super().__getitem__(k)
+        return self._data[k]
 
-    def get(self, k, default=None):
-        self._resolve()
-        return super().get(k, default)
+    def __setitem__(self, k, v):
+        self._data[k] = v
 
-    def items(self):
-        self._resolve()
-        return super().items()
+    def __delitem__(self, k):
+        self._resolve()        # pop() reads the value on its way out
+        del self._data[k]
 
-    def values(self):
-        self._resolve()
-        return super().values()
+    def __iter__(self):
+        return iter(self._data)
 
-    def pop(self, *a):
-        self._resolve()
-        return super().pop(*a)
+    def __len__(self):
+        return len(self._data)
+
+    def __contains__(self, k):
+        return k in self._data
+
+    def keys(self):
+        return self._data.keys()
 
     def copy(self):
         self._resolve()
-        return dict(self)
+        return dict(self._data)
+
+    def __or__(self, other):
+        return {**self.copy(), **other}
+
+    def __ror__(self, other):
+        return {**other, **self.copy()}
+
+    def __reduce__(self):      # pickle / copy.copy / copy.deepcopy: a settled plain dict
+        return (dict, (self.copy(),))
+
+    def __repr__(self):
+        return 'LazyResult(%s%s)' % (list(self._data), ', unchecked' if self._token is not None else '')
 
 
 class _Node(nn.Module):
@@ -173,6 +201,14 @@ class BGModel(BaseModel):
         self.on_range_overflow = params['model'].get('on_range_overflow', 'rerun')
         if self.on_range_overflow not in ('rerun', 'raise', 'ignore'):
             raise ValueError("model.on_range_overflow must be 'rerun', 'raise' or 'ignore'")
+        # 'lazy' (default): predict() only enqueues and the check happens when a result is first touched - the caller must leave
+        # the INPUT tensors of a forward unchanged until then (a flagged forward is re-run from them; an in-place refill is
+        # detected through the tensors' version counters and raises).  'sync': predict() waits for its own forward's status
+        # before returning (one stream synchronisation per call, what round 3 did) - for callers that refill static input
+        # buffers or write them behind torch's back.
+        self.range_check = params['model'].get('range_check', 'lazy')
+        if self.range_check not in ('lazy', 'sync'):
+            raise ValueError("model.range_check must be 'lazy' or 'sync'")
         self.range_reruns = 0
         self._pending = []          # enqueued forwards not checked yet, oldest first
         self._pinned = None         # [ring, 2] int32 pinned: (status word, sticky word) per in-flight forward
@@ -283,19 +319,29 @@ class BGModel(BaseModel):
         """Wait for ONE forward's status words and apply the policy (see LazyResult)."""
         if token.done:
             return
-        token.event.synchronize()
+        if not token.event.query():      # (a fired event needs no wait: _poll() settles forwards without any synchronising call)
+            token.event.synchronize()
         token.done = True
         if token in self._pending:
             self._pending.remove(token)
         status = int(self._pinned[token.slot, 0])
-        args, outs = token.args, token.outs
-        token.args = token.outs = None
+        args, outs, stamps = token.args, token.outs, token.stamps
+        token.args = token.outs = token.stamps = None
         if not (status & PF_STATUS_ANY):
             return
         if self.on_range_overflow == 'raise':
             raise _lib.PfError('bg forward: status %d on the two-term fp16 operand path (PF_STATUS_RANGE = 1: an activation '
                                'exceeded 65504; PF_STATUS_RANGE_LOW = 2: a tensor of tiny values, max below 2^-6); run with '
                                "model.split_f16 = 0 or on_range_overflow = 'rerun'" % status)
+        # The re-run reads the caller's input tensors NOW, not when predict() was called.  If they were refilled in place since
+        # (a static input buffer with `static.copy_(batch)`, a pinned staging loop), re-running would silently put a newer
+        # frame's result into the older frame's outputs: refuse instead.  (Writes that bypass torch's version counter -
+        # `x.data.copy_`, a foreign kernel - are not seen: such callers use model.range_check = 'sync'.)
+        if stamps != tuple(_stamp(t) for t in args[:3]):
+            raise _lib.PfError('bg forward: status %d on the two-term fp16 operand path, and the input tensors of that forward were '
+                               'modified in place before its result was first touched - the fp32 re-run cannot see the original '
+                               "frame.  Keep a forward's inputs unchanged until its result has been read (or model.settle()), or "
+                               "build the model with model.range_check = 'sync'" % status)
         L, plan = _lib.load(), self._get_plan()
         self.range_reruns += 1
         prior = self.plan_options.get('split_f16', 1)
@@ -345,6 +391,7 @@ class BGModel(BaseModel):
         self._pinned[slot].copy_(self._ws[:8].view(torch.int32), non_blocking=True)
         token = _Pending()
         token.slot, token.args, token.outs, token.done = slot, args, outs, False
+        token.stamps = tuple(_stamp(t) for t in args[:3])
         token.stream = torch.cuda.current_stream()
         token.event = torch.cuda.Event()
         token.event.record(token.stream)
@@ -477,9 +524,17 @@ class BGModel(BaseModel):
 
     @torch.no_grad()
     def predict(self, inputs, labels=None):
+        """Reference ``BGModel.predict`` (bg_model.py:91-102): ``{'seg', 'orig_size_logits'[, 'logits']}``.  Only ENQUEUES (see
+        ``LazyResult``).  Lifetime rule of the default ``range_check = 'lazy'``: leave ``inputs['seg' / 'depth' / 'depth_mask']``
+        unchanged until a value of the result has been read (or ``settle()``): a forward flagged by the range guard is re-run
+        from them at that point.  An in-place refill in between raises PfError instead of re-running on the wrong frame;
+        ``model.range_check = 'sync'`` checks before returning."""
         (seg, logits, orig), token = self.run_async(inputs['seg'], inputs.get('depth'), inputs.get('depth_mask'),
                                                     want_logits=self.return_logits, want_orig=True)
         out = {'seg': seg, 'orig_size_logits': orig}
         if logits is not None:
             out['logits'] = logits
+        if token is not None and self.range_check == 'sync':
+            self._resolve(token)
+            token = None
         return LazyResult(out, self, token)

@@ -241,6 +241,8 @@ class BGTrainer:
         base = self.theta.data_ptr()
         return all(p.data_ptr() == base + 4 * off for p, (_, off, _, _) in zip(self._adopted, self.trainable_layout()))
 
+    MAX_GRAPHS = 8      # captured step configurations kept (see forward_backward)
+
     # ---- one micro-batch: forward + loss + backward ---------------------------------------------
     def _workspace(self, b, h, w, oh, ow):
         need = ctypes.c_size_t()
@@ -281,7 +283,11 @@ class BGTrainer:
                    float(loss_scale), self.depth_mean, self.depth_std)
             ent = self._graphs.get(key)
             if ent is None:
-                # first batch of this configuration: eagerly (the library's one-time kernel-attribute calls are not capturable)
+                # first batch of this configuration: eagerly (the library's one-time kernel-attribute calls are not capturable).
+                # The cache is bounded: a key holds float(loss_scale), so a caller with dynamic loss scaling would otherwise
+                # capture (and keep) one hipGraph + static input copies per distinct scale - the oldest entry goes first
+                while len(self._graphs) >= self.MAX_GRAPHS:
+                    self._graphs.pop(next(iter(self._graphs)))
                 self._graphs[key] = 'seen'
             else:
                 if ent == 'seen':
@@ -298,6 +304,16 @@ class BGTrainer:
         else:
             enqueue(seg, depth, mask, lab)
         return {'loss': (self.out3[0] / self.out3[1]).float(), 'accuracy': (self.out3[2] / self.out3[1]).float()}
+
+    PATH_STATS = ('table_shapes', 'model_shapes', 'autotuned_shapes', 'padded_copy_convs', 'padded_output_layers',
+                  'single_backward_data_convs', 'generic_kernel_launches')
+
+    def path_stats(self):
+        """Which code paths the last ``forward_backward`` took (include/pfhip.h: pf_train_path_stats) - counts of convolutions by
+        where their workgroup shape came from, of odd-width layers on the padded forms, of generic-kernel fallbacks."""
+        buf, n = (ctypes.c_int * 8)(), ctypes.c_int()
+        _lib.check(_lib.load().pf_train_path_stats(self._t, buf, 8, ctypes.byref(n)), 'pf_train_path_stats')
+        return {k: int(buf[i]) for i, k in enumerate(self.PATH_STATS[:n.value])}
 
     def all_reduce_grads(self):
         """Data-parallel exchange: ONE all-reduce of the flat gradient (RCCL over xGMI; DDP-style average)."""

@@ -129,7 +129,8 @@ __device__ __forceinline__ float range_acc(float m, float a, float b, float c, f
 // from before the atomics).  Sampling is conservative for this test: a tensor whose values are ALL below the threshold is
 // below it on every sample, so it is always flagged; a tensor with larger values escapes the flag as soon as one sampled
 // workgroup stored one (8 x 32 pixels x all its output channels each).  A reporting wave ORs 1 into the bit pattern, so a word
-// of 0 means "no report" (an op without a slot), and a launch whose sampled values are all exactly zero counts as low.
+// of 0 means "no report" (an op without a slot) and a word of 1 "every sampled value was exactly zero": neither is low - exact
+// zeros lose nothing in the pair (a dead-ReLU layer, blank frames); the flag needs a NON-ZERO maximum below kRangeLowMax.
 constexpr float kRangeTarget = 8.0f;          // expected magnitude of a stored channel after the plan's scaling
 constexpr float kRangeLowMax = 0.015625f;     // 2^-6: a launch whose reported max |v| is below it raises PF_STATUS_RANGE_LOW
 __device__ __forceinline__ bool range_sampled() {   // uniform per workgroup

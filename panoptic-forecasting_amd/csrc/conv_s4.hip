@@ -987,7 +987,9 @@ __global__ void range_finalize_kernel(unsigned *st, int live_word, int first_slo
     __syncthreads();
     for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
         const unsigned v = st[first_slot + i];
-        if (v != 0 && v < low_bits) low = 1;
+        // v = bits(max |stored value|) | 1; 0 = no report, 1 = every sampled value was exactly zero: zeros lose nothing in the
+        // fp16 pair (a dead-ReLU layer, blank frames, an all-zero dense input), so only a NON-ZERO maximum below 2^-6 is low
+        if ((v & ~1u) != 0 && v < low_bits) low = 1;
         st[first_slot + n_slots + i] = v;
         st[first_slot + i] = 0;
     }

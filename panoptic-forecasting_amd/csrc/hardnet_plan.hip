@@ -76,6 +76,7 @@ int g_opt_range_guard = 1, g_opt_fuse_front = 1;   // fuse_front: conv_front.hip
 int g_opt_normalize = 1;   // normalize_ranges: per-channel power-of-two scaling of the stored activations, fixed at plan creation
 extern int g_opt_use_tuned;
 int g_opt_up_two_pass = 1;  // upsample_bwd_two_pass: the bilinear transposes of large planes as rows-then-columns passes (train_kernels.hip)
+int g_opt_train_table_batch = 0;   // train_table_batch: batch size the rows of train_tuned.inc are looked up with (0 = the call's own)
 int g_opt_train_side = 1;   // train_side_stream: weight gradients on the training plan's own stream (train_plan.hip)
 }
 
@@ -92,6 +93,7 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "normalize_ranges")) g_opt_normalize = value;
     else if (!strcmp(name, "profile_tag_ops")) g_opt_tag_ops = value;
     else if (!strcmp(name, "train_side_stream")) g_opt_train_side = value;
+    else if (!strcmp(name, "train_table_batch")) g_opt_train_table_batch = value < 0 ? 0 : value;
     else if (!strcmp(name, "upsample_bwd_two_pass")) g_opt_up_two_pass = value;
     else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);
     return PF_OK;

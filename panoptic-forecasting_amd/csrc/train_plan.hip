@@ -65,11 +65,14 @@ struct pf_train {
     // the measurements run in a pass of their own in front of the first real pass of a configuration (B, H, W, out_h, out_w):
     // its launches repeat, so what they accumulate is garbage - it goes to a scratch gradient and leaves theta alone
     mutable bool measuring = false;
+    // pf_train_path_stats: which code paths the LAST pf_train_forward_backward took (tests assert that a timed configuration
+    // really ran the table's shapes and the padded odd-width forms, not a fallback)
+    mutable int stats[8] = {};
     mutable std::vector<std::array<int, 5>> measured_configs;
 };
 
 namespace pf {
-extern int g_opt_train_side, g_opt_use_tuned, g_opt_up_two_pass;
+extern int g_opt_train_side, g_opt_use_tuned, g_opt_up_two_pass, g_opt_train_table_batch;
 }
 
 namespace {
@@ -90,9 +93,22 @@ int train_conv_dma(const pf_train *p, const ConvArgs &c, int ks, int stride, int
     const std::array<int, 8> key{ks, stride, c.Cin, c.Cout, c.Hin, c.Win, B, c.accum};
     auto it = p->autotune ? p->tuned.find(key) : p->tuned.end();
     if (it == p->tuned.end() && !p->measuring) {
-        if (g_opt_use_tuned)
+        if (g_opt_use_tuned) {
+            // option "train_table_batch" = n > 0: look the table up as if the batch were n (the rows are keyed on the batch they
+            // were measured at; a parity test of the timed configuration's kernels on a batch the CPU oracle can afford pins n = 8)
+            std::array<int, 8> tkey = key;
+            if (g_opt_train_table_batch > 0) tkey[6] = g_opt_train_table_batch;
             for (const TrainTuned &t : kTrainTuned)
-                if (t.wm && std::equal(key.begin(), key.end(), t.key)) return launch_conv_dma(c, ks, stride, B, s, t.wm, t.nt);
+                if (t.wm && std::equal(tkey.begin(), tkey.end(), t.key)) {
+                    const int rc = launch_conv_dma(c, ks, stride, B, s, t.wm, t.nt);
+                    if (rc != PF_EUNSUPPORTED) {
+                        ++p->stats[0];
+                        return rc;
+                    }
+                    break;      // a row this build has no kernel for: the cost model's shape
+                }
+        }
+        ++p->stats[1];
         return launch_conv_dma(c, ks, stride, B, s);
     }
     if (it == p->tuned.end()) {
@@ -126,6 +142,7 @@ int train_conv_dma(const pf_train *p, const ConvArgs &c, int ks, int stride, int
         if (!(best < 0.97f * model_ms)) pick = {0, 0};
         it = p->tuned.emplace(key, pick).first;
     }
+    ++p->stats[2];
     return it->second.first ? launch_conv_dma(c, ks, stride, B, s, it->second.first, it->second.second) : launch_conv_dma(c, ks, stride, B, s);
 }
 
@@ -470,6 +487,13 @@ extern "C" int pf_train_tuned_shapes(const pf_train *p, int *rows, int cap_rows,
     return PF_OK;
 }
 
+extern "C" int pf_train_path_stats(const pf_train *p, int *stats, int cap, int *n) {
+    if (!p || !n || (cap > 0 && !stats)) return fail(PF_EINVAL, "pf_train_path_stats: null argument");
+    *n = 7;
+    for (int k = 0; k < 7 && k < cap; ++k) stats[k] = p->stats[k];
+    return PF_OK;
+}
+
 extern "C" int pf_train_param_count(const pf_train *p, size_t *n_floats) {
     if (!p || !n_floats) return fail(PF_EINVAL, "pf_train_param_count: null");
     *n_floats = p->n_params;
@@ -527,6 +551,26 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
     const TLayout L = t_layout(p, B, d, out_h, out_w);
     if (ws_bytes < L.total) return fail(PF_EWORKSPACE, "workspace %zu B < required %zu B", ws_bytes, L.total);
     char *wsb = (char *)ws;
+    for (int &v : p->stats) v = 0;
+    // Every exit of this function - an error return in the middle of the backward pass included - leaves the side streams
+    // JOINED to the caller's stream: a fork that is never joined invalidates an enclosing stream capture and lets the caller's
+    // stream run ahead of weight gradients still in flight.
+    struct SideJoin {
+        const pf_train *p;
+        hipStream_t s;
+        int forked = 0;         // number of layers handed to the side streams so far
+        bool done = false;
+        int join() {
+            if (done || !p->side || forked == 0) return PF_OK;
+            done = true;
+            for (int k = 0; k < pf_train::kSideStreams && k < forked; ++k) {   // (a stream that got no layer was never forked)
+                PF_HIP_CHECK(hipEventRecord(p->ev_join[k], p->sides[k]));
+                PF_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join[k], 0));
+            }
+            return PF_OK;
+        }
+        ~SideJoin() { (void)join(); }
+    } side_join{p, s};
     auto act = [&](uint32_t t) { return reinterpret_cast<float *>(wsb + L.act[t]); };
     auto gradt = [&](uint32_t t) { return reinterpret_cast<float *>(wsb + L.grad[t]); };
     const uint32_t input = p->ops[0].src[0].tensor;
@@ -610,6 +654,7 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
             const int Wp = (a.Win + 3) / 4 * 4, pad = ks / 2;
             const int Wop = (Wp + 2 * pad - ks) / stride + 1;
             if ((rc2 = launch_pad_gather(a, B, Wp, gather_to, s))) return rc2;
+            ++p->stats[3];
             ConvArgs c = a;
             c.n_src = 1;
             c.src[0] = gather_to; c.src_ctotal[0] = a.Cin; c.src_choff[0] = 0; c.src_cstart[0] = 0;
@@ -619,11 +664,15 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
             c.dst = keep_padded ? a.dst : pad_out; c.dst_ctotal = a.Cout; c.dst_choff = 0; c.accum = 0;
             const int one = a.Cin;
             rc2 = fast(c, &one, 1);
-            if (rc2 == PF_OK && keep_padded) return PF_OK;
+            if (rc2 == PF_OK && keep_padded) {
+                ++p->stats[4];
+                return PF_OK;
+            }
             if (keep_padded && rc2 == PF_EUNSUPPORTED) return fail(PF_EUNSUPPORTED, "training: no tiled kernel for an odd-width conv + BatchNorm layer");
             if (rc2 == PF_OK) return launch_unpad_scatter(pad_out, B, a.Cout, a.Hout, a.Wout, Wop, a.dst, a.dst_ctotal, a.dst_choff, a.accum, s);
             if (rc2 != PF_EUNSUPPORTED) return rc2;
         }
+        ++p->stats[6];      // the generic register-staged kernel (no tiled kernel took the geometry)
         const ConvTiling t = choose_tiling(ks, stride, tflip ? cout_f : cin_f, tflip ? ch : cout_f, 0);
         if ((rc2 = launch_pack_weights(w, cin_f, cout_f, t, tflip, c0, ch, wpk, s))) return rc2;
         a.wpk = wpk;
@@ -719,6 +768,7 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
                 PF_HIP_CHECK(hipEventRecord(p->ev_dy[slot], s));
                 sw = p->sides[sidx];
                 PF_HIP_CHECK(hipStreamWaitEvent(sw, p->ev_dy[slot], 0));
+                side_join.forked = n_conv;
                 if (sidx) wpart_l = reinterpret_cast<float *>(wsb + L.wpart_more[sidx]);
             }
             ConvArgs a;
@@ -764,6 +814,7 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
                 b.chunk_begin = 0;
                 b.chunk_end = b.nchunks;
                 if ((rc = train_conv_dma(p, b, (int)o.k, 1, B, s))) return rc;
+                ++p->stats[5];
                 float *dsts[kMaxSrc];
                 int ct[kMaxSrc], co[kMaxSrc], chs[kMaxSrc], ow[kMaxSrc];
                 for (uint32_t j = 0; j < o.n_src; ++j) {
@@ -796,13 +847,7 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
             }
         }
     }
-    if (p->side && n_conv) {   // join: the caller's stream carries every gradient when this call's work is done
-        for (int k = 0; k < pf_train::kSideStreams && k < n_conv; ++k) {   // (a stream that got no layer was never forked)
-            PF_HIP_CHECK(hipEventRecord(p->ev_join[k], p->sides[k]));
-            PF_HIP_CHECK(hipStreamWaitEvent(s, p->ev_join[k], 0));
-        }
-    }
-    return PF_OK;
+    return side_join.join();   // the caller's stream carries every gradient when this call's work is done
 }
 
 extern "C" int pf_train_forward_backward(const pf_train *p, float *theta, float *grad, int accumulate_grads, const void *seg, int seg_is_i64,

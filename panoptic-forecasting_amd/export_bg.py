@@ -33,6 +33,7 @@ from . import config as pfconfig   # noqa: E402
 from . import dist as pfdist       # noqa: E402
 from . import hop_io               # noqa: E402
 from . import synth                # noqa: E402
+from .pc_transform_model import add_camera_inverses  # noqa: E402
 from .registry import build_model  # noqa: E402
 
 EXTRA_FLAGS = (
@@ -142,7 +143,10 @@ def export_split(model, dataset, split, params, collate_fn):
         if params.get('dry_run'):
             written += dry_write(batch['meta'], base)
             continue
-        inputs = batch['inputs'] if params.get('no_gpu') else to_device(batch['inputs'])
+        # K^-1 / E^-1 on the HOST tensors, before the move (same LAPACK bits as the reference's torch.inverse inside predict,
+        # pc_transform_model.py:51,71): predict() then never reads a camera back from the device - no stream sync per batch
+        inputs = add_camera_inverses(batch['inputs'])
+        inputs = inputs if params.get('no_gpu') else to_device(inputs)
         with torch.no_grad():
             preds = model.predict(inputs, batch.get('labels'))
         written += hop_io.export_batch(preds, batch['meta'], base, no_convert=bool(params.get('no_convert')),

@@ -47,6 +47,7 @@ SIGNATURES = {
     'pf_train_destroy': (None, [_vp]),
     'pf_train_autotune': (_i, [_vp, _i]),
     'pf_train_tuned_shapes': (_i, [_vp, _c.POINTER(_i), _i, _c.POINTER(_i)]),
+    'pf_train_path_stats': (_i, [_vp, _c.POINTER(_i), _i, _c.POINTER(_i)]),
     'pf_train_param_count': (_i, [_vp, _c.POINTER(_sz)]),
     'pf_train_param_layout': (_i, [_vp, _i, _c.POINTER(_sz), _c.POINTER(_sz), _c.POINTER(_i)]),
     'pf_train_workspace': (_i, [_vp, _i, _i, _i, _i, _i, _c.POINTER(_sz)]),

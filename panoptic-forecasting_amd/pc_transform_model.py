@@ -20,6 +20,25 @@ def host_inverse(m):
     return torch.inverse(m.detach().float().cpu()).to(m.device)
 
 
+def add_camera_inverses(inputs):
+    """HOST side, before the batch moves to the device (the reference's loop: ``batch2gpu`` in training/train_utils.py:45-62,
+    right before ``model.predict``, export_cityscapes_segmentation_results.py:75-85): ``intrinsics_inv`` / ``extrinsics_inv``
+    = ``torch.inverse`` of the host tensors - the same LAPACK call and bits ``PCTransformModel.predict`` would produce
+    (pc_transform_model.py:51,71) - added to a shallow copy of ``inputs``.  ``predict`` then finds the inverses in the batch
+    and never reads a camera tensor back from the device: no stream synchronisation for batches whose camera tensors it has
+    never seen (every batch of a real data loader).  Device-resident or absent cameras are left alone (the model's cache
+    handles them, one device->host copy per distinct tensor)."""
+    K, E = inputs.get('intrinsics'), inputs.get('extrinsics')
+    if not (torch.is_tensor(K) and torch.is_tensor(E)) or K.is_cuda or E.is_cuda:
+        return inputs
+    out = dict(inputs)
+    if out.get('intrinsics_inv') is None:
+        out['intrinsics_inv'] = torch.inverse(K.detach().float())
+    if out.get('extrinsics_inv') is None:
+        out['extrinsics_inv'] = torch.inverse(E.detach().float())
+    return out
+
+
 class InverseCache:
     """K^-1 / E^-1 per distinct camera tensor.  The inverse has to come from host LAPACK (see ``host_inverse``), which
     costs a device->host copy = a stream sync; cameras are per-sequence constants, so ``predict`` pays it once per
@@ -31,7 +50,9 @@ class InverseCache:
     in the environment, or ``pc_transform_model._inverse_cache.verify = True``) adds a content check for such callers: an
     entry keeps a device clone of the matrix it inverted and a hit is honoured only if the tensor still equals it - a
     device comparison read on the host, i.e. one stream synchronisation per camera tensor per predict (skipped under
-    stream capture, where nothing may synchronise)."""
+    stream capture, where nothing may synchronise).  HOST tensors are always content-checked on a hit (``torch.equal`` on 9 /
+    16 floats, no stream involved): numpy-aliased camera matrices edited in place are the likeliest stale-key case.
+    A batch that carries ``intrinsics_inv`` / ``extrinsics_inv`` (``add_camera_inverses``) never comes here."""
 
     def __init__(self, capacity=16, verify=None):
         import os
@@ -42,7 +63,8 @@ class InverseCache:
         key = (m.data_ptr(), m._version, tuple(m.shape), m.dtype, str(m.device))
         hit = self._d.get(key)
         capturing = m.is_cuda and torch.cuda.is_current_stream_capturing()
-        if hit is not None and self.verify and not capturing and not torch.equal(m, hit[2]):
+        check = (self.verify and not capturing) if m.is_cuda else True
+        if hit is not None and check and not torch.equal(m, hit[2]):
             hit = None               # same storage, same version, other numbers
         if hit is None:
             self._d.pop(key, None)

@@ -140,6 +140,30 @@ def test_full_size_timed_configuration_vs_oracle(b, split, term):
         assert agree >= 0.999, (i, agree)
 
 
+def test_second_resolution_heuristic_kernel_choice_vs_oracle():
+    """512x1024, B = 16 - the configuration of bench.py's `other_resolution` leg.  No row of csrc/conv_s4_tuned.inc /
+    conv_tuned.inc matches these shapes, so every layer's kernel comes from the heuristics of conv_select.cpp (the cost model,
+    the reuse-vs-occupancy rule, `conv_split` / `conv_s4` defaults): the untuned choice is held to the same 1e-4 as the tuned
+    one, first and last frame of the batch, warped inputs bit-exact."""
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.registry import build_model
+    h, w, b = 512, 1024, 16
+    sd = _sd()
+    m = build_model(_params(h, w, return_logits='orig', emulate_disk_hop=True, seg_is_label_id=True, per_sample_sentinel=True))
+    m.load_state_dict(sd)
+    parts = [synth.make_inputs(b=1, h=h, w=w, seed=60 + i, gap_len=3) for i in range(b)]
+    inp = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+    out = m.predict({k: v.cuda() for k, v in inp.items()}, None)
+    assert m.bg.range_reruns == 0 and m.bg.range_status() == 0
+    for i in (0, b - 1):
+        ref, seg_w, dep_w = oracle_pipeline(sd, parts[i], h, w)
+        assert torch.equal(torch.from_numpy(synth.ID2TRAINID)[out['warped_seg'][i:i + 1].cpu().long()].long(), seg_w)
+        err = (out['orig_size_logits'][i:i + 1].cpu() - ref['orig_size_logits']).abs().max().item()
+        agree = (out['seg'][i:i + 1].cpu().long() == ref['seg']).float().mean().item()
+        assert err <= 1e-4, (i, err)
+        assert agree >= 0.999, (i, agree)
+
+
 def test_batch_pinned_kernel_table_makes_logits_batch_invariant():
     """conv_table_batch pins the per-layer kernel choice: the same frame alone and inside a batch of 4 gives bit-identical
     logits (without the pin the B=1 and B=4 rows of the tuned table may pick kernels that differ in the last bits)."""
@@ -155,3 +179,36 @@ def test_batch_pinned_kernel_table_makes_logits_batch_invariant():
     one = {k: v[2:3].contiguous() for k, v in inp.items()}
     m1 = m.predict(one, None)['orig_size_logits']
     assert torch.equal(m4[2:3], m1)
+
+
+def test_predict_on_never_seen_camera_tensors_does_not_synchronise():
+    """The reference-shaped loop (export_cityscapes_segmentation_results.py:75-85: batch from the loader -> batch2gpu ->
+    predict) makes FRESH camera tensors every batch, so the model's per-tensor inverse cache never hits.  With
+    `add_camera_inverses` on the host batch (what export_bg.py does) predict() finds K^-1 / E^-1 in the batch: every
+    iteration runs under torch's sync-debug mode 'error' - any device->host read or stream synchronisation inside predict
+    would raise - and the result equals the one the model computes from its own (synchronising) inverses, bit for bit."""
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.pc_transform_model import add_camera_inverses
+    from panoptic_forecasting_amd.registry import build_model
+    h, w = 128, 256
+    m = build_model(_params(h, w, return_logits='orig'))
+    m.load_state_dict(_sd())
+    host = [synth.make_inputs(b=2, h=h, w=w, seed=s_, gap_len=3) for s_ in (31, 32, 33)]
+    host = [{k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in b_.items()} for b_ in host]
+    want = []
+    for b_ in host:                                    # the model's own inverses (cache miss: device -> host -> LAPACK)
+        o = m.predict({k: v.cuda() for k, v in b_.items()}, None)
+        want.append((o['seg'].clone(), o['orig_size_logits'].clone(), o['warped_depth'].clone()))
+    m.bg.settle()
+    torch.cuda.synchronize()
+    outs = []
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        for b_ in host:
+            dev_batch = {k: v.cuda(non_blocking=True) for k, v in add_camera_inverses(b_).items()}   # new tensors every batch
+            outs.append(m.predict(dev_batch, None))    # enqueues only
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    for o, (seg, logit, wd) in zip(outs, want):
+        assert torch.equal(o['seg'], seg) and torch.equal(o['orig_size_logits'], logit)
+        assert torch.equal(o['warped_depth'].view(torch.int32), wd.view(torch.int32))

@@ -104,6 +104,38 @@ def test_scaled_activations_through_a_hardblock_are_right_or_flagged(scale, forc
     net.close()
 
 
+@pytest.mark.parametrize('force', [(5, 2, 0, 0), (4, 2, 0, 0), None], ids=['conv_s4', 'conv_split', 'table'])
+@pytest.mark.parametrize('case', ['zero_input', 'dead_layer'])
+def test_exact_zeros_are_not_a_low_range(case, force, force_conv):
+    """include/pfhip.h: PF_STATUS_RANGE_LOW needs a NON-ZERO maximum below 2^-6.  Exact zeros lose nothing in the fp16 pair, so
+    an all-zero dense input with zero biases (every activation exactly 0) and a layer whose ReLU kills every value (biases of
+    -1e3: the tensor t0 and everything behind its consumers' zero contribution) must leave the status word clear - no fp32
+    re-run, no PfError after graph replays - and the results must still equal float64 torch."""
+    from helpers import MiniNet
+    from test_gpu_conv import _block_net, _block_ref
+    g = torch.Generator().manual_seed(17)
+    b, h, w = 1, 24, 40
+    spec, P = _block_net(g, 12)
+    P = dict(P)
+    if case == 'zero_input':
+        x = torch.zeros(b, 12, h, w)
+        P = {k: (wt, torch.zeros_like(bs)) for k, (wt, bs) in P.items()}
+    else:
+        x = torch.randn(b, 12, h, w, generator=g)
+        P['t0'] = (P['t0'][0], torch.full_like(P['t0'][1], -1e3))
+    if force:
+        force_conv(*force)
+    ref = _block_ref(x, P, h, w)
+    assert ref['t0'].abs().max().item() == 0.0
+    net = MiniNet(spec, P).run(x.cuda())
+    assert net.status() == 0, 'exact zeros raised status %d' % net.status()
+    for name in ('t0', 'L2', 'out', 'c7', 'c8'):
+        r = ref[name].float()
+        err = (net.tensor(name).cpu() - r).abs().max().item()
+        assert err <= 3e-5 * max(r.abs().max().item(), 1e-30) + 0.0, (name, err)
+    net.close()
+
+
 @pytest.mark.parametrize('alpha', [1e-5, 1e-3, 1e3])
 def test_reparameterised_block_runs_on_the_pair_path(alpha, force_conv, normalize_ranges):
     """The same function with other numbers: the first conv's weights and bias times alpha, every consumer's columns of that
@@ -402,3 +434,61 @@ def test_predict_is_asynchronous_and_a_late_check_still_reruns():
         err = (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max().item()
         assert err <= 1e-4 * scale, (err, scale)
     assert m.bg.range_reruns == n0 + 2
+
+
+def test_late_rerun_refuses_inputs_refilled_in_place_and_sync_mode_is_safe():
+    """`task: bg` reads the CALLER's tensors.  A flagged forward is re-run from them when its result is first touched; if the
+    caller refilled them in place in between (a static input buffer), the re-run would put the newer frame's result into the
+    older frame's outputs.  The lazy default detects the refill through the tensors' version counters and raises;
+    model.range_check = 'sync' settles the forward inside predict(), so the same loop returns the ORIGINAL frame's result."""
+    import test_gpu_bg_model as tb
+    from oracle import hardnet_ref
+    from panoptic_forecasting_amd import lib as pflib
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.registry import build_model
+    h, w = 64, 128
+    sd_bad = dict(tb._sd())
+    sd_bad['depth_std'] = torch.tensor([2e-4])          # normalised depths of 1e5+: every forward is flagged
+
+    def model(**kw):
+        p = _bg_params(h, w, 2e-4, **kw)
+        p['task'] = 'bg'
+        p['model']['return_logits'] = False
+        m = build_model(p)
+        m.load_state_dict(sd_bad)
+        return m
+
+    frames = [synth.make_bg_inputs(b=1, h=h, w=w, seed=s_) for s_ in (3, 4)]
+    ref0 = hardnet_ref.bg_predict(sd_bad, frames[0], final_size=(h, w))
+    scale = ref0['orig_size_logits'].abs().max().item()
+
+    lazy = model()
+    static = {k: v.clone().cuda() for k, v in frames[0].items()}
+    lazy.predict(static, None)['seg']                   # warm-up (plan, workspace); re-runs once
+    out = lazy.predict(static, None)
+    for k in static:
+        static[k].copy_(frames[1][k].cuda())            # the next frame lands in the same buffers before `out` was read
+    with pytest.raises(pflib.PfError, match='modified in place'):
+        out['seg']
+
+    sync = model(range_check='sync')
+    static = {k: v.clone().cuda() for k, v in frames[0].items()}
+    n0 = sync.range_reruns
+    out = sync.predict(static, None)
+    assert sync.range_reruns == n0 + 1                  # settled (and re-run on fp32) before predict() returned
+    for k in static:
+        static[k].copy_(frames[1][k].cuda())
+    err = (out['orig_size_logits'].cpu() - ref0['orig_size_logits']).abs().max().item()
+    assert err <= 1e-4 * (1.0 + scale), (err, scale)
+
+    # untouched inputs: the lazy path re-runs as before
+    keep = {k: v.clone().cuda() for k, v in frames[0].items()}
+    out = lazy.predict(keep, None)
+    err = (out['orig_size_logits'].cpu() - ref0['orig_size_logits']).abs().max().item()
+    assert err <= 1e-4 * (1.0 + scale), (err, scale)
+    # dict(out) / {**out} of an unchecked result settle it too (LazyResult is not a dict subclass)
+    out = lazy.predict(keep, None)
+    n1 = lazy.range_reruns
+    plain = dict(out)
+    assert type(plain) is dict and lazy.range_reruns == n1 + 1
+    assert (plain['orig_size_logits'].cpu() - ref0['orig_size_logits']).abs().max().item() <= 1e-4 * (1.0 + scale)

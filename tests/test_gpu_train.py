@@ -141,6 +141,60 @@ def test_forward_backward_vs_oracle(size):
                 assert _rel(got[name[6:]].cpu() * coef, torch.from_numpy(z[name])) <= bars[name[6:]] + 1.5 * _rel(ref['grads'][name[6:]], g64[name[6:]]), name
 
 
+def test_timed_configuration_800x800_vs_oracle():
+    """The configuration tools/bench_train.py and bench.py's `train_step` TIME - 800x800 crops (configs/bg/bg_train.yaml:25,48) -
+    against the oracle, with the kernels of that configuration: csrc/train_tuned.inc is keyed on the timed shapes at batch 8, so
+    the table is consulted as for batch 8 (option train_table_batch) while the batch itself is 2, which the CPU oracle (fp32 and
+    float64 autograd of the 70-layer network) can afford.  At 800x800 the 50- and 25-pixel levels have odd widths (rows padded
+    to 52 / 28 floats): conv + BatchNorm outputs kept in padded rows, one backward-data conv over all input ranges, the padded
+    weight-gradient inputs.  pf_train_path_stats proves those forms and the table's rows ran (and no generic-kernel fallback).
+    Criterion: the one of test_forward_backward_vs_oracle that is independent of this implementation - per tensor at most twice as far
+    from float64 as the reference's own fp32 (ATen) gradient (or ATen's median tensor)."""
+    from panoptic_forecasting_amd import lib as pflib
+    from panoptic_forecasting_amd.bg_train import BGTrainer
+    h = w = 800
+    b = 2
+    sd = _sd()
+    inputs = synth.make_bg_inputs(b=b, h=h, w=w, seed=31)
+    labels = {'seg': _labels(b, h, w, 7)}
+    L = pflib.load()
+    pflib.check(L.pf_set_option(b'train_table_batch', 8), 'pf_set_option')
+    try:
+        tr = BGTrainer(_params())
+        tr.load_state_dict(sd)
+        out = tr.forward_backward(_cuda(inputs), _cuda(labels))
+        torch.cuda.synchronize()
+        stats = tr.path_stats()
+    finally:
+        L.pf_set_option(b'train_table_batch', 0)
+    print('training path at 800x800:', stats)
+    assert stats['table_shapes'] >= 60, stats                 # rows of csrc/train_tuned.inc (73 of the step's 126 geometries have one)
+    assert stats['padded_output_layers'] >= 20, stats         # conv + BatchNorm layers of the 50- / 25-pixel levels, forward
+    assert stats['single_backward_data_convs'] >= 20, stats   # ... and their input gradients, one conv per layer
+    assert stats['generic_kernel_launches'] == 0, stats
+    r32 = hardnet_ref.bg_train_step({k: v.clone() for k, v in sd.items()}, inputs, labels, clip_grad_norm=None, apply_update=False)
+    sd64 = {k: (v.double() if v.dtype == torch.float32 else v.clone()) for k, v in sd.items()}
+    in64 = dict(inputs)
+    in64['depth'] = inputs['depth'].double()
+    r64 = hardnet_ref.bg_train_step(sd64, in64, labels, clip_grad_norm=None, apply_update=False)
+    assert abs(float(out['loss']) - float(r32['loss'])) <= LOSS_REL * abs(float(r32['loss']))
+    assert abs(float(out['accuracy']) - float(r32['accuracy'])) <= 2e-4
+    got = tr.named_grads()
+    g64 = r64['grads']
+    dist = {k: _rel(got[k].cpu(), g) for k, g in g64.items()}
+    aten = {k: _rel(r32['grads'][k], g) for k, g in g64.items()}
+    _record_grad_distances('800x800', dist, aten)
+    aten_med = sorted(aten.values())[len(aten) // 2]
+    for k in g64:
+        assert dist[k] <= max(2.0 * max(aten[k], aten_med), 1e-4), (k, dist[k], aten[k], aten_med)
+    for k in ('model.finalConv.weight', 'model.finalConv.bias', 'model.denseBlocksUp.3.layers.3.norm.weight'):
+        assert dist[k] <= 2e-4, (k, dist[k])
+    post = tr.state_dict()
+    for k in sd64:
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            assert torch.allclose(post[k].double(), sd64[k], rtol=2e-3, atol=1e-4), k
+
+
 def test_two_training_steps_vs_reference_fixture():
     """train_step x2 with the values of configs/bg/bg_train.yaml: parameters, momentum and running statistics after the
     second step against the reference loop's (the clip / weight decay / momentum arithmetic of pf_sgd_step included)."""
@@ -558,6 +612,53 @@ def test_two_rank_train_driver_equals_one_rank_with_accumulation(tmp_path):
     # ... and into the reference's optimizer class unchanged
     dummy = [torch.nn.Parameter(torch.zeros(shape)) for _, _, shape, _ in tr.trainable_layout()]
     torch.optim.SGD(dummy, lr=2e-3, momentum=0.9).load_state_dict(st['optimizer'])
+
+
+def test_bgmodel_under_distributed_data_parallel(tmp_path):
+    """The reference's data-parallel wrapping, unmodified (training/train.py:96-103: ``DistributedDataParallel(DistWrapper(model))``,
+    models/dist_wrapper.py:13-26), around THIS package's registry model: two ranks (gloo, sharing the one GPU) run two steps of the
+    reference loop body (tests/ddp_worker.py).  DDP's reducer hooks fire on the parameter gradients the fused device step hands to
+    autograd, so after ``backward()`` every rank holds the mean gradient - which must equal what the flat exchange of
+    ``train_bg.py`` / ``BGTrainer`` computes for the same micro-batches (the sum of the two half-scaled gradients) to 1e-6, and so
+    must the parameters after two clipped SGD steps.  BatchNorm uses per-rank batch statistics under DDP (no SyncBN in the
+    reference), exactly as per micro-batch here."""
+    import subprocess
+    import sys
+    import ddp_worker
+    from panoptic_forecasting_amd.bg_train import BGTrainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'ddp.pt')
+    port = 29000 + (os.getpid() + 7) % 1000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'ddp_worker.py'), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
+    got = torch.load(out)
+    # every rank ends with the same parameters (same averaged gradients, same update)
+    n0, n1 = got['param_norms_by_rank']
+    assert all(abs(n0[k] - n1[k]) <= 1e-7 * (abs(n0[k]) + 1e-12) for k in n0)
+
+    tr = BGTrainer(ddp_worker.params())
+    tr.load_state_dict(ddp_worker.state_dict())
+    for step in range(2):
+        for r in range(2):
+            inputs, labels = ddp_worker.micro_batches(step, r)
+            tr.forward_backward(_cuda(inputs), _cuda(labels), accumulate=r > 0, loss_scale=0.5)
+        if step == 0:
+            flat = {k: v.cpu().clone() for k, v in tr.named_grads().items()}
+            assert set(got['grads']) == set(flat)
+            worst = max(_rel(got['grads'][k], flat[k]) for k in flat)
+            assert worst <= 1e-6, worst
+        tr.optimizer_step()
+    one = tr.state_dict()
+    worst = 0.0
+    for key, _, _, trainable in tr.layout:
+        if trainable:
+            worst = max(worst, _rel(got['params'][key], one[key]))
+    assert worst <= 1e-6, worst
 
 
 def test_training_mode_loss_under_no_grad_uses_batch_statistics():

@@ -161,37 +161,69 @@ def test_lazy_result_checks_once_on_first_value_access():
         def _resolve(self, token):
             self.resolved.append(token)
 
+    import copy
+    import pickle
+    assert not issubclass(LazyResult, dict)          # CPython's dict fast paths would skip the accessors (dict(r), {**r}, r | x)
     for access in (lambda r: r['seg'], lambda r: r.get('seg'), lambda r: list(r.items()), lambda r: list(r.values()),
-                   lambda r: r.copy(), lambda r: r.pop('seg')):
+                   lambda r: r.copy(), lambda r: r.pop('seg'), lambda r: dict(r), lambda r: {**r}, lambda r: r | {'x': 0},
+                   lambda r: {'x': 0} | r, lambda r: {}.update(r), lambda r: pickle.dumps(r), lambda r: copy.copy(r),
+                   lambda r: r == {'seg': 1}, lambda r: r.setdefault('seg', 5), lambda r: r.popitem(),
+                   lambda r: [v for _, v in r.items()]):
         m = FakeModel()
         r = LazyResult({'seg': 1, 'orig_size_logits': 2}, m, 'token')
-        assert sorted(r.keys()) == ['orig_size_logits', 'seg'] and 'seg' in r and len(r) == 2
+        assert sorted(r.keys()) == ['orig_size_logits', 'seg'] and 'seg' in r and len(r) == 2 and sorted(r) == sorted(r.keys())
         assert m.resolved == []                      # nothing waited for yet
         access(r)
         access(LazyResult({'seg': 1, 'orig_size_logits': 2}, m, None))   # a result without a token (stream capture, policy 'ignore') never resolves
         r.get('orig_size_logits')
         assert m.resolved == ['token'], m.resolved   # exactly once
+    settled = dict(LazyResult({'seg': 1}, FakeModel(), 'token'))
+    assert type(settled) is dict and settled == {'seg': 1}
+    assert type(pickle.loads(pickle.dumps(LazyResult({'seg': 1}, FakeModel(), 't')))) is dict
 
 
-def test_inverse_cache_hits_without_touching_the_tensor_and_verifies_on_request():
-    """pc_transform_model.InverseCache: a hit on (storage, version) returns the cached host inverse without comparing contents
-    (no stream synchronisation per predict); an in-place edit bumps the version and misses; a write that bypasses the version
-    counter is caught only when `verify` is on."""
+def test_inverse_cache_keys_on_storage_and_version_and_checks_host_tensors_by_content():
+    """pc_transform_model.InverseCache: a hit on (storage, version) returns the cached host inverse; an in-place edit bumps the
+    version and misses.  HOST tensors are also compared by content on every hit (no stream is involved), so a write that
+    bypasses the version counter (`K.data.copy_`, numpy-aliased memory) is caught; for DEVICE tensors that comparison would
+    cost a stream synchronisation per predict and stays opt-in (`verify`; exercised on the GPU in test_gpu_warp_splat.py)."""
+    import numpy as np
     from panoptic_forecasting_amd.pc_transform_model import InverseCache
     K = torch.tensor([[[2.0, 0.0, 1.0], [0.0, 4.0, 2.0], [0.0, 0.0, 1.0]]])
+    eye = torch.eye(3).expand(1, 3, 3)
     c = InverseCache(verify=False)
     a = c(K)
-    assert torch.allclose(a @ K, torch.eye(3).expand(1, 3, 3)) and c(K) is a
+    assert torch.allclose(a @ K, eye) and c(K) is a
     K.mul_(2.0)                                       # in-place: _version changes
     b = c(K)
-    assert b is not a and torch.allclose(b @ K, torch.eye(3).expand(1, 3, 3), atol=1e-6)
-    K.data.copy_(K.data * 0.5)                         # bypasses the version counter
-    assert c(K) is b                                   # not seen without verification (documented)
-    v = InverseCache(verify=True)
-    first = v(K)
-    K.data.copy_(K.data * 4.0)
-    again = v(K)
-    assert again is not first and torch.allclose(again @ K, torch.eye(3).expand(1, 3, 3), atol=1e-6)
+    assert b is not a and torch.allclose(b @ K, eye, atol=1e-6)
+    K.data.copy_(K.data * 0.5)                         # bypasses the version counter: caught by the host content check
+    d = c(K)
+    assert d is not b and torch.allclose(d @ K, eye, atol=1e-6)
+    arr = np.array([[[2.0, 0.0, 1.0], [0.0, 4.0, 2.0], [0.0, 0.0, 1.0]]], np.float32)
+    Kn = torch.from_numpy(arr)                         # numpy-aliased camera matrix edited behind torch's back
+    first = c(Kn)
+    arr *= 4.0
+    again = c(Kn)
+    assert again is not first and torch.allclose(again @ Kn, eye, atol=1e-6)
+
+
+def test_add_camera_inverses_gives_the_models_own_bits_and_leaves_device_batches_alone():
+    """pc_transform_model.add_camera_inverses (what export_bg.py calls before the batch moves to the device): K^-1 / E^-1 =
+    torch.inverse of the HOST tensors = bit for bit what predict() would compute for itself (host_inverse: the reference's
+    torch.inverse, pc_transform_model.py:51,71), as new keys of a shallow copy; inverses already in the batch are kept."""
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.pc_transform_model import add_camera_inverses, host_inverse
+    inp = synth.make_inputs(b=2, h=16, w=32, seed=3)
+    out = add_camera_inverses(inp)
+    assert out is not inp and 'intrinsics_inv' not in inp
+    assert torch.equal(out['intrinsics_inv'].view(torch.int32), host_inverse(inp['intrinsics']).view(torch.int32))
+    assert torch.equal(out['extrinsics_inv'].view(torch.int32), host_inverse(inp['extrinsics']).view(torch.int32))
+    assert out['depth'] is inp['depth']
+    marked = dict(inp, intrinsics_inv=torch.zeros(2, 3, 3))
+    assert add_camera_inverses(marked)['intrinsics_inv'] is marked['intrinsics_inv']
+    only_seg = {'seg': inp['seg']}
+    assert add_camera_inverses(only_seg) is only_seg                # no cameras: untouched
 
 
 def test_backend_description_single_process():
