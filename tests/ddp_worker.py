@@ -85,6 +85,8 @@ def main():
         nn.utils.clip_grad_norm_(ddp.parameters(), tp['clip_grad_norm'])
         opt.step()
         opt.zero_grad()
+        if step == 0:
+            saved['params_step1'] = {k: p.detach().cpu().clone() for k, p in ddp.module.model.named_parameters()}
     saved['params'] = {k: p.detach().cpu().clone() for k, p in ddp.module.model.named_parameters()}
     gathered = [None] * world
     dist.all_gather_object(gathered, {k: float(v.double().norm()) for k, v in saved['params'].items()})
