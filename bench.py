@@ -463,6 +463,26 @@ def fresh_cameras_leg(sd, dev, term):
     return res
 
 
+def train_step_in_fresh_process():
+    """`train_step_leg` in a process of its own (python bench.py --train-step-only).  Not for cleanliness: by this point this
+    process has created a dozen HIP streams (the sub-batch streams of every leg, torch's stream pool, capture streams), and
+    the runtime multiplexes streams onto a handful of hardware queues - the training plan's weight-gradient stream then shares
+    a queue with the stream it forks from and joins, every cross-stream edge becomes a barrier packet in that one queue, and
+    the step measures 27-28 ms instead of 14.8 (same kernels, same box; a process that trains has two streams)."""
+    env = dict(os.environ)
+    env.pop('RANK', None)
+    env.pop('WORLD_SIZE', None)
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--train-step-only'], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, timeout=900)
+        lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+        if out.returncode != 0 or not lines:
+            return {'error': 'train-step process failed (rc %d): %s' % (out.returncode, out.stderr[-400:])}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {'error': 'train-step process timed out'}
+
+
 def other_resolution_leg(sd, dev, term, steps):
     """A second resolution, 512x1024 at B = 16 on one stream (hipGraph replay): no row of the measured kernel tables
     (csrc/conv_s4_tuned.inc, conv_tuned.inc: keyed on the 1024x2048 network's exact shapes) matches, so every layer runs the
@@ -652,6 +672,7 @@ def parse_args(argv=None):
                     'own stream, no join between steps, sub-batch i starts i * MS late (streams out of phase)')
     ap.add_argument('--term', choices=['short', 'mid'], default='short',
                     help="short = BASELINE configs[1] (dt=3, the headline); mid = configs[2] (dt=9, predicted odometry)")
+    ap.add_argument('--train-step-only', action='store_true', help='print the train_step object alone (the N=1 line runs this in a fresh process)')
     ap.add_argument('--dry-run', action='store_true', help='rendezvous + the sharded metric exchange only (gloo, no GPU '
                     'work): checks that --gpus N really starts N ranks')
     return ap.parse_args(argv)
@@ -671,6 +692,10 @@ def relaunch_under_torchrun(args):
 
 def main():
     args = parse_args()
+    if args.train_step_only:
+        torch.cuda.set_device(0)
+        print(json.dumps(train_step_leg(calibrated_state_dict())))
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         relaunch_under_torchrun(args)
     rank, world, local = pfdist.init_distributed_mode(backend='gloo' if (args.dry_run or SHARE_GPU) else None)
@@ -828,7 +853,7 @@ def main():
             torch.cuda.empty_cache()
         del shared_batch
         torch.cuda.empty_cache()
-        train_step = train_step_leg(sd)
+        train_step = train_step_in_fresh_process()
 
     if rank == 0:
         line = {'metric': 'forecast frames/sec @1024x2048, 3-in->dt=%d bg' % (3 if args.term == 'short' else 9), 'value': value, 'unit': 'frames/s',
