@@ -43,6 +43,25 @@
 #define S4_PROBE(i) do { } while (0)
 #endif
 
+// A/B knobs of profiles/r05_experiments.md (defaults = the shipped kernels): cache-policy bits of the activation LDS-DMA (2 = nt),
+// non-temporal epilogue stores of the 3x3 kernel's common path, raised wave priority across the matrix phase of a round
+#ifndef S4_ACT_AUX
+#define S4_ACT_AUX 0
+#endif
+#ifndef S4_STORE_NT
+#define S4_STORE_NT 0
+#endif
+#ifndef S4_SETPRIO
+#define S4_SETPRIO 0
+#endif
+// Pixel fragments of the 3x3 kernel: a B operand is 8 fp16 = the 4 channels of TWO group entries of one pixel, which live in two
+// planes of a stage, 2880 B apart - out of reach of one ds_read2_b64 (255 x 8 B).  Left alone, hipcc pairs the reads of two
+// DIFFERENT M-tiles of one plane into a ds_read2_b64 and then moves the halves into place: 72 v_mov_b32 per round next to 54
+// matrix instructions (and a ds_read2_b64 occupies the LDS for 8 cycles where two ds_read_b64 take 4).  1 = volatile 8-B
+// reads: no pairing, no moves
+#ifndef S4_FRAG_B64
+#define S4_FRAG_B64 1
+#endif
 // the DMA parts of the next stage go out after MFMA groups 1, 3, .. of a round (every placement measured within 1 %)
 [[maybe_unused]] constexpr int kS4IssueFirst = 1, kS4IssueStep = 2;
 
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ ==
     auto issue_part = [&](int r, int stage, int j) {
         if ((jb + j) * 64 + lane < C::PIECES)   // the plane holds exactly its pieces: lanes past the last one write nothing
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (s4_lds_ptr_t)(abuf(stage) + w4 * C::PLANE + (jb + j) * 1024), 16,
-                                                     areal ? poff[j] : kS4Oob, asoff, 0, 0);
+                                                     areal ? poff[j] : kS4Oob, asoff, 0, S4_ACT_AUX);
         unsigned char *wdst = wbuf(stage);
         const bool flush = is_flush(r);
 #pragma unroll
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ ==
         for (int j = 0; j < C::NDMA; ++j)
             if (slot == kS4IssueFirst + j * kS4IssueStep) issue_part(round + 1, (round + 1) & 1, j);
     };
-    static_assert(kS4IssueFirst + (C::NDMA - 1) * kS4IssueStep < 6 * HALVES, "every DMA part needs a slot inside the two full instructions");
+    static_assert(kS4IssueFirst + (C::NDMA - 1) * kS4IssueStep < 6 * HALVES, "every DMA part needs a slot inside the two full instructions");   // (batches of 2 M-tiles: 12 slots)
 
     // collected tap: K-slice g of these fragments = entries of round 4q + g
     s4_h8 col_h[C::MP], col_m[C::MP];
@@ -257,53 +276,70 @@ __global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ ==
         if (more) prepare_round(round + 1);
         S4_PROBE(round * 4 + 2);
         const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
+#if S4_SETPRIO
+        __builtin_amdgcn_s_setprio(S4_SETPRIO);
+#endif
         auto frag = [&](const unsigned char *p, s4_h8 &h, s4_h8 &md) {
-            h = s4_join(*reinterpret_cast<const s4_h4 *>(p), *reinterpret_cast<const s4_h4 *>(p + C::PLANE));
-            md = s4_join(*reinterpret_cast<const s4_h4 *>(p + 2 * C::PLANE), *reinterpret_cast<const s4_h4 *>(p + 3 * C::PLANE));
+            if constexpr (S4_FRAG_B64 == 1 || (S4_FRAG_B64 == 2 && NT != 2)) {
+                // four plain ds_read_b64, each straight into its half of an operand tuple (see S4_FRAG_B64 above)
+                typedef const volatile __attribute__((address_space(3))) s4_h4 *lds_h4;
+                const lds_h4 q = (lds_h4)(const __attribute__((address_space(3))) unsigned char *)p;
+                constexpr int PL = C::PLANE / 8;
+                h = s4_join(q[0], q[PL]);
+                md = s4_join(q[2 * PL], q[3 * PL]);
+            } else {
+                h = s4_join(*reinterpret_cast<const s4_h4 *>(p), *reinterpret_cast<const s4_h4 *>(p + C::PLANE));
+                md = s4_join(*reinterpret_cast<const s4_h4 *>(p + 2 * C::PLANE), *reinterpret_cast<const s4_h4 *>(p + 3 * C::PLANE));
+            }
         };
         auto mtile_off = [&](int mm) {
             return ((mm / C::MTR) * C::IW + (mm % C::MTR) * 16) * 8;
         };
-        // the three products of one block of weights with 4 M-tiles; `slot0` numbers the MFMA groups for the DMA parts
-        auto mfmas = [&](const s4_h8 (&wh)[NT], const s4_h8 (&wm)[NT], int m0, const s4_h8 (&fh)[4], const s4_h8 (&fm)[4], int slot0, bool dma) {
+        // the three products of one block of weights with FT M-tiles; `slot0` numbers the MFMA groups for the DMA parts.
+        // FT = 4 M-tiles per batch of fragment reads, or 2 for <2, 32> with the plain 8-B reads: its 126 registers have no
+        // room for 32 fragment registers that are all live at once (the reads are volatile: none may be sunk below a matrix
+        // instruction) - two tiles at a time need 16
+        constexpr bool kB64 = S4_FRAG_B64 == 1 || (S4_FRAG_B64 == 2 && NT != 2);
+        constexpr int FT = (kB64 && NT == 2 && C::MP == 4) ? 2 : 4;
+        auto mfmas = [&](const s4_h8 (&wh)[NT], const s4_h8 (&wm)[NT], int m0, const auto &fh, const auto &fm, int slot0, bool dma) {
+            constexpr int FTn = (int)(sizeof(fh) / sizeof(fh[0]));
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < FTn; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc[m0 + m][n] = PF_MFMA_SPLIT(wh[n], fm[m], acc[m0 + m][n]);
             if (dma) issue_slot(round, more, slot0 + 0);
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < FTn; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc[m0 + m][n] = PF_MFMA_SPLIT(wm[n], fh[m], acc[m0 + m][n]);
             if (dma) issue_slot(round, more, slot0 + 1);
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < FTn; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc[m0 + m][n] = PF_MFMA_SPLIT(wh[n], fh[m], acc[m0 + m][n]);
             if (dma) issue_slot(round, more, slot0 + 2);
         };
-        auto products = [&](int blk, int m0, const s4_h8 (&fh)[4], const s4_h8 (&fm)[4], int slot0, bool dma) {
+        constexpr int NB = C::MP / FT;      // fragment batches per instruction of a round
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
             s4_h8 wh[NT], wm[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                wh[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * C::BPT + blk) * 2 + 0) * 64 + lane) * 16);
-                wm[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * C::BPT + blk) * 2 + 1) * 64 + lane) * 16);
+                wh[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * C::BPT + s) * 2 + 0) * 64 + lane) * 16);
+                wm[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * C::BPT + s) * 2 + 1) * 64 + lane) * 16);
             }
-            mfmas(wh, wm, m0, fh, fm, slot0, dma);
-        };
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int bt = 0; bt < NB; ++bt) {
+                s4_h8 fh[FT], fm[FT];
 #pragma unroll
-            for (int hf = 0; hf < HALVES; ++hf) {
-                s4_h8 fh[4], fm[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) frag(ab + aoff[s] + mtile_off(hf * 4 + m), fh[m], fm[m]);
-                products(s, hf * 4, fh, fm, 3 * (s * HALVES + hf), true);
+                for (int m = 0; m < FT; ++m) frag(ab + aoff[s] + mtile_off(bt * FT + m), fh[m], fm[m]);
+                mfmas(wh, wm, bt * FT, fh, fm, 3 * (s * NB + bt), true);
                 __builtin_amdgcn_sched_barrier(0);   // keep the next unit's fragment reads behind these MFMAs (registers)
             }
+        }
         // the ninth tap of this round's entries: K-slice (round & 3)
         if (g == (round & 3)) {
 #pragma unroll
@@ -340,6 +376,9 @@ __global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ ==
 #pragma unroll
             for (int m = 0; m < C::MP; ++m) col_h[m] = col_m[m] = zero8;
         }
+#if S4_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         S4_PROBE(round * 4 + 3);
     }
     S4_PROBE(58);
@@ -390,8 +429,13 @@ __global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ ==
             char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
             if (!mis) {
                 if (ok1) {
+#if S4_STORE_NT
+                    __builtin_nontemporal_store(hi, reinterpret_cast<s4_h4 *>(p));
+                    __builtin_nontemporal_store(mid, reinterpret_cast<s4_h4 *>(p + term));
+#else
                     *reinterpret_cast<s4_h4 *>(p) = hi;
                     *reinterpret_cast<s4_h4 *>(p + term) = mid;
+#endif
                 } else if (ok0) {
                     *reinterpret_cast<h2 *>(p) = h2{hi[0], hi[1]};
                     *reinterpret_cast<h2 *>(p + term) = h2{mid[0], mid[1]};
