@@ -59,6 +59,9 @@
 // DIFFERENT M-tiles of one plane into a ds_read2_b64 and then moves the halves into place: 72 v_mov_b32 per round next to 54
 // matrix instructions (and a ds_read2_b64 occupies the LDS for 8 cycles where two ds_read_b64 take 4).  1 = volatile 8-B
 // reads: no pairing, no moves
+#ifndef S4_COL_EARLY
+#define S4_COL_EARLY 0
+#endif
 #ifndef S4_FRAG_B64
 #define S4_FRAG_B64 1
 #endif
@@ -323,6 +326,21 @@ __global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ ==
             if (dma) issue_slot(round, more, slot0 + 2);
         };
         constexpr int NB = C::MP / FT;      // fragment batches per instruction of a round
+        // S4_COL_EARLY (<2, 32>): the collected-tap weights of a flush round are requested BEFORE the round's DMA parts: loads return in
+        // order, so waiting for them at the flush then does not wait for the next stage's DMA as well (16 registers across the round:
+        // <3, 32> has no room for its 24)
+        constexpr bool kColEarly = S4_COL_EARLY && C::COLREG && NT == 2;
+        s4_h8 cwh[NT], cwm[NT];
+        if (kColEarly && is_flush(round)) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bool real = tile0 + n < a.ntiles;   // uniform
+                const char *wp = reinterpret_cast<const char *>(a.wpk) +
+                                 ((size_t)(real ? tile0 + n : 0) * nblocks + s4_blocks_before(round) + 2) * C::WBLK + lane * 16;
+                cwh[n] = real ? *reinterpret_cast<const s4_h8 *>(wp) : zero8;
+                cwm[n] = real ? *reinterpret_cast<const s4_h8 *>(wp + 64 * 16) : zero8;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             s4_h8 wh[NT], wm[NT];
@@ -348,9 +366,9 @@ __global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ ==
         if (is_flush(round)) {
             // the collected-tap block of this flush round (third block of the round in the packed stream).  COLREG: global ->
             // registers (L2-resident; the fragment registers of the two full instructions are dead here); else from LDS
-            s4_h8 cwh[NT], cwm[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
+                if (kColEarly) continue;
                 if (C::COLREG) {
                     const bool real = tile0 + n < a.ntiles;   // uniform
                     const char *wp = reinterpret_cast<const char *>(a.wpk) +
