@@ -59,6 +59,9 @@
 // DIFFERENT M-tiles of one plane into a ds_read2_b64 and then moves the halves into place: 72 v_mov_b32 per round next to 54
 // matrix instructions (and a ds_read2_b64 occupies the LDS for 8 cycles where two ds_read_b64 take 4).  1 = volatile 8-B
 // reads: no pairing, no moves
+#ifndef S4_PREFETCH
+#define S4_PREFETCH 0
+#endif
 #ifndef S4_COL_EARLY
 #define S4_COL_EARLY 0
 #endif
@@ -341,6 +344,31 @@ __global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ ==
                 cwm[n] = real ? *reinterpret_cast<const s4_h8 *>(wp + 64 * 16) : zero8;
             }
         }
+        // S4_PREFETCH (experiment, off): the fragments of batch k + 1 are read while the matrix instructions of batch k run
+        constexpr bool kPrefetch = S4_PREFETCH && kB64 && NT <= 2 && KS_ == 1 && TH_ == 8 && TW_ == 32;
+        if constexpr (kPrefetch) {
+            s4_h8 fh[2][FT], fm[2][FT];
+            auto read_batch = [&](int k, s4_h8 (&h)[FT], s4_h8 (&md)[FT]) {
+#pragma unroll
+                for (int m = 0; m < FT; ++m) frag(ab + aoff[k / NB] + mtile_off((k % NB) * FT + m), h[m], md[m]);
+            };
+            read_batch(0, fh[0], fm[0]);
+            s4_h8 wh[NT], wm[NT];
+#pragma unroll
+            for (int k = 0; k < 2 * NB; ++k) {
+                const int sI = k / NB;
+                if (k % NB == 0) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        wh[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * C::BPT + sI) * 2 + 0) * 64 + lane) * 16);
+                        wm[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * C::BPT + sI) * 2 + 1) * 64 + lane) * 16);
+                    }
+                }
+                if (k + 1 < 2 * NB) read_batch(k + 1, fh[(k + 1) & 1], fm[(k + 1) & 1]);
+                mfmas(wh, wm, (k % NB) * FT, fh[k & 1], fm[k & 1], 3 * k, true);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             s4_h8 wh[NT], wm[NT];
@@ -357,6 +385,7 @@ __global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ ==
                 mfmas(wh, wm, bt * FT, fh, fm, 3 * (s * NB + bt), true);
                 __builtin_amdgcn_sched_barrier(0);   // keep the next unit's fragment reads behind these MFMAs (registers)
             }
+        }
         }
         // the ninth tap of this round's entries: K-slice (round & 3)
         if (g == (round & 3)) {

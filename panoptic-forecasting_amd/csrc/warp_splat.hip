@@ -164,20 +164,31 @@ __device__ __forceinline__ void bins(float u, float hi, int &b0, int &b1) {
 // downstream is non-finite too (inf or NaN times any matrix entry, zero included, is inf or NaN, and sums keep it), so
 // "e0, e1, e2 all finite" proves the shortcut was exact; anything else takes the full chain.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_dot2c(const float *m, f32x2 a, f32x2 b) {       // ((0 + m0*a) + m1*b) + m2*1
-    f32x2 acc = f32x2{0.0f, 0.0f} + f32x2{m[0], m[0]} * a;
-    acc = acc + f32x2{m[1], m[1]} * b;
+// Round 5: the leading `0 +` of every dot product is gone, and so are the products with matrix entries that are exactly zero
+// (`Z0` / `Z1`: entry 0 / 1 of the row is 0.0f, checked per launch on the scalar unit - the skew-free K and K^-1 of a pinhole
+// camera: K = [[fx,0,cx],[0,fy,cy]]).  Both change the SIGN OF A ZERO at most: 0 + x == x unless x is -0 (then +0), and
+// acc + 0*b == acc unless acc is a zero of the other sign (b is finite here: pixel coordinates, or checked by the caller).  A zero of
+// either sign cannot reach an output: every sum of this chain that feeds a bin, a validity test or the stored depth either adds a
+// non-zero translation next, or is compared / floored / divided where +0 and -0 behave alike (u >= 0, floor, 0/0 = NaN either
+// way, z > 0), and stored depths of valid points are > 0.  Bit-exactness at full size and on every fixture: tests/test_gpu_warp_splat.py.
+template <bool Z0 = false, bool Z1 = false>
+__device__ __forceinline__ f32x2 pk_dot2c(const float *m, f32x2 a, f32x2 b) {       // (m0*a + m1*b) + m2*1
+    if (Z0) return f32x2{m[1], m[1]} * b + f32x2{m[2], m[2]};
+    f32x2 acc = f32x2{m[0], m[0]} * a;
+    if (!Z1) acc = acc + f32x2{m[1], m[1]} * b;
     return acc + f32x2{m[2], m[2]};
 }
 __device__ __forceinline__ f32x2 pk_dot3c(const float *m, f32x2 a, f32x2 b, f32x2 c) {   // dot4 with a trailing 1
-    f32x2 acc = f32x2{0.0f, 0.0f} + f32x2{m[0], m[0]} * a;
+    f32x2 acc = f32x2{m[0], m[0]} * a;
     acc = acc + f32x2{m[1], m[1]} * b;
     acc = acc + f32x2{m[2], m[2]} * c;
     return acc + f32x2{m[3], m[3]};
 }
+template <bool Z0 = false, bool Z1 = false>
 __device__ __forceinline__ f32x2 pk_dot3(const float *m, f32x2 a, f32x2 b, f32x2 c) {
-    f32x2 acc = f32x2{0.0f, 0.0f} + f32x2{m[0], m[0]} * a;
-    acc = acc + f32x2{m[1], m[1]} * b;
+    if (Z0) return f32x2{m[1], m[1]} * b + f32x2{m[2], m[2]} * c;
+    f32x2 acc = f32x2{m[0], m[0]} * a;
+    if (!Z1) acc = acc + f32x2{m[1], m[1]} * b;
     return acc + f32x2{m[2], m[2]} * c;
 }
 __device__ __forceinline__ bool finite2(f32x2 a) { return __builtin_isfinite(a.x) && __builtin_isfinite(a.y); }
@@ -226,6 +237,12 @@ __device__ __forceinline__ bool camera_affine(GlobalF pKinv, GlobalF pE, GlobalF
     }
     return ok != 0;
 }
+// uniform: the four entries the SKEWFREE chain skips are exactly zero
+__device__ __forceinline__ bool camera_skewfree(GlobalF pKinv, GlobalF pK) {
+    return ((int)(pKinv[1] == 0.0f) & (int)(pKinv[3] == 0.0f) & (int)(pK[1] == 0.0f) & (int)(pK[3] == 0.0f)) != 0;
+}
+// SKEWFREE: K[0][1] == K[1][0] == 0 and the same for K^-1 (uniform, camera_skewfree): those products are skipped
+template <bool SKEWFREE>
 __device__ __forceinline__ bool project4_fast(GlobalF pKinv, GlobalF pE, GlobalF pT, GlobalF pEinv, GlobalF pK, int x, int y,
                                                 const float (&d)[4], const bool (&m)[4], float Wf, float Hf, Proj (&p)[4]) {
     float Kinv[6], E[12];
@@ -234,8 +251,8 @@ __device__ __forceinline__ bool project4_fast(GlobalF pKinv, GlobalF pE, GlobalF
     const f32x2 v = f32x2{(float)y, (float)y};
     const f32x2 ua = f32x2{(float)x, (float)(x + 1)}, ub = f32x2{(float)(x + 2), (float)(x + 3)};
     const f32x2 da = f32x2{d[0], d[1]}, db = f32x2{d[2], d[3]};
-    const f32x2 r0a = pk_dot2c(Kinv + 0, ua, v), r0b = pk_dot2c(Kinv + 0, ub, v);
-    const f32x2 r1a = pk_dot2c(Kinv + 3, ua, v), r1b = pk_dot2c(Kinv + 3, ub, v);
+    const f32x2 r0a = pk_dot2c<false, SKEWFREE>(Kinv + 0, ua, v), r0b = pk_dot2c<false, SKEWFREE>(Kinv + 0, ub, v);
+    const f32x2 r1a = pk_dot2c<SKEWFREE, false>(Kinv + 3, ua, v), r1b = pk_dot2c<SKEWFREE, false>(Kinv + 3, ub, v);
     const f32x2 c0a = r0a * da, c1a = r1a * da, c0b = r0b * db, c1b = r1b * db;                   // r2 == 1: c2 = d
     float Tm[12];
     fetch_rows(pT, Tm);
@@ -252,8 +269,8 @@ __device__ __forceinline__ bool project4_fast(GlobalF pKinv, GlobalF pE, GlobalF
     for (int i = 0; i < 3; ++i) { ea[i] = pk_dot3c(Einv + 4 * i, wa[0], wa[1], wa[2]); eb[i] = pk_dot3c(Einv + 4 * i, wb[0], wb[1], wb[2]); }
     if (!(finite2(ea[0]) && finite2(ea[1]) && finite2(ea[2]) && finite2(eb[0]) && finite2(eb[1]) && finite2(eb[2]))) return false;
     // e3 == 1: px = e0, py = e1, z = e2;  q2 == z
-    const f32x2 q0a = pk_dot3(K + 0, ea[0], ea[1], ea[2]), q0b = pk_dot3(K + 0, eb[0], eb[1], eb[2]);
-    const f32x2 q1a = pk_dot3(K + 3, ea[0], ea[1], ea[2]), q1b = pk_dot3(K + 3, eb[0], eb[1], eb[2]);
+    const f32x2 q0a = pk_dot3<false, SKEWFREE>(K + 0, ea[0], ea[1], ea[2]), q0b = pk_dot3<false, SKEWFREE>(K + 0, eb[0], eb[1], eb[2]);
+    const f32x2 q1a = pk_dot3<SKEWFREE, false>(K + 3, ea[0], ea[1], ea[2]), q1b = pk_dot3<SKEWFREE, false>(K + 3, eb[0], eb[1], eb[2]);
     p[0] = finish(__fdiv_rn(q0a.x, ea[2].x), __fdiv_rn(q1a.x, ea[2].x), ea[2].x, m[0], Wf, Hf);
     p[1] = finish(__fdiv_rn(q0a.y, ea[2].y), __fdiv_rn(q1a.y, ea[2].y), ea[2].y, m[1], Wf, Hf);
     p[2] = finish(__fdiv_rn(q0b.x, eb[2].x), __fdiv_rn(q1b.x, eb[2].x), eb[2].x, m[2], Wf, Hf);
@@ -344,6 +361,7 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
     const GlobalF pKinv = (GlobalF)a.Kinv + b * 9, pK = (GlobalF)a.K + b * 9, pE = (GlobalF)a.E + b * 16, pEinv = (GlobalF)a.Einv + b * 16,
                   pT = (GlobalF)a.Tt + ((long long)b * a.T_total + t) * 16;
     const bool affine = camera_affine(pKinv, pE, pT, pEinv, pK);
+    const bool skewfree = camera_skewfree(pKinv, pK);
     const int g = a.per_frame ? tl : 0, G = a.per_frame ? a.T : 1;
     uint8_t *mark = a.inv_mark + ((long long)b * G + g) * N;
     long long *r2d = a.out_r2d ? a.out_r2d + ((long long)b * a.T + tl) * N * 2 : nullptr;
@@ -355,7 +373,10 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
         uint2 *pj = a.proj + ((long long)b * a.T + tl) * N + (long long)y * a.W + x;
         unsigned pk[8];
         Proj p4[4];
-        if (!(affine && project4_fast(pKinv, pE, pT, pEinv, pK, x, y, d, m, Wf, Hf, p4))) {
+        // (one instantiation of the fast chain: a second one for cameras with skew doubled the spilled scalars; such cameras take
+        //  the full chain below - exact, ~2.5x the instructions)
+        const bool fast_done = affine && skewfree && project4_fast<true>(pKinv, pE, pT, pEinv, pK, x, y, d, m, Wf, Hf, p4);
+        if (!fast_done) {
             // the full chain fetches its own copy of the camera, through pointers the optimiser cannot match with the staged
             // loads of the fast chain (nothing of the camera stays live for this rare branch)
             project4_full(pKinv, pE, pT, pEinv, pK, x, y, d, m, Wf, Hf, p4);

@@ -119,11 +119,16 @@ def test_full_size_properties():
     assert (o['depth'] > 0).float().mean() > 0.99
 
 
-@pytest.mark.parametrize('case', ['non_affine_camera', 'huge_depth', 'list_overflow'])
+@pytest.mark.parametrize('case', ['non_affine_camera', 'skewed_camera', 'first_column_negative_focal', 'huge_depth', 'list_overflow'])
 def test_paths_beside_the_fast_one_match_oracle(case):
     """bin_kernel takes the packed shortcut chain only for affine cameras and finite intermediates, and the raster kernel
     reads per-tile lists unless one overflowed.  The other branches against the C oracle, bit for bit:
       non_affine_camera  last rows of K / E that are not (0,0,1) / (0,0,0,1): every point on the full scalar chain;
+      skewed_camera      K with a skew term (K[0][1] != 0, so K^-1[0][1] != 0 too): the shortcut chain skips the products with
+                         the exactly-zero entries of a pinhole camera and is taken only when they ARE zero - this camera runs the
+                         full chain;
+      first_column_negative_focal  fx < 0 (a mirrored image): K^-1[0][0] * u is -0 in pixel column 0, the one place where the
+                         dropped `0 +` of the dot products changes an intermediate (the sign of a zero) - outputs must not move;
       huge_depth         finite depths around 1e37..3e38 scattered in the maps: intermediates overflow to inf (and inf - inf =
                          NaN in later sums), so those lanes leave the shortcut; both sides clamp the resulting coordinates
                          with fmaxf/fminf before the integer conversion, which is defined for NaN and inf;
@@ -143,6 +148,10 @@ def test_paths_beside_the_fast_one_match_oracle(case):
     if case == 'non_affine_camera':
         inp['intrinsics'][:, 2, 0] = 1e-5
         inp['extrinsics'][:, 3, 2] = 1e-3
+    if case == 'skewed_camera':
+        inp['intrinsics'][:, 0, 1] = 3.5
+    if case == 'first_column_negative_focal':
+        inp['intrinsics'][:, 0, 0] *= -1.0
     if case == 'huge_depth':
         g = torch.Generator().manual_seed(2)
         pick = torch.rand(inp['depth'].shape, generator=g) < 0.02
