@@ -9,9 +9,10 @@ the PQ accumulators.  Prints ONE JSON line on rank 0.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--replays R] [--no-graph] [--no-cpu-baseline] [--no-legs]
 
-A step visits the rank's resident synthetic batch R times (``--replays``, default 2: 2 x 64 = 128 forecast frames per GPU per
-step, one hipGraph), so that the driver's 20 steps time about a second instead of a quarter of one; ``config`` states it.
-The 64 resident frames run as 4 sub-batches of 16 on 4 HIP streams, staggered (``--stagger 1``): the warp/splat of sub-batch
+A step visits the rank's resident synthetic batch R times (``--replays``, default 2: 2 x 128 = 256 forecast frames per GPU per
+step, one hipGraph), so that the driver's 20 steps time about two seconds instead of a quarter of one; ``config`` states it.
+The 128 resident frames run as 4 sub-batches of 32 on 4 HIP streams (round 5: +1.9 % over 64 / 4 in a same-box sweep, 192 and 256
+frames give no more: profiles/r05_experiments.md), staggered (``--stagger 1``): the warp/splat of sub-batch
 i + 1 starts when that of sub-batch i is done, so the vector-ALU-bound front of one sub-batch runs beside the memory-bound
 convolutions of another (+3 % over starting them together: profiles/r03_experiments.md).
 
@@ -58,7 +59,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec (6.3 TB/s achievable)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 (2495 measured; tools/ubench/f16_split.hip: same rate)
 CPU_BUDGET_S = 20.0             # stop starting new baseline frames after this much CPU time
-SUB_BATCH = 16                  # frames per concurrent sub-batch of the headline workload
+SUB_BATCH = 32                  # frames per concurrent sub-batch of the headline workload (the shape tables' nearest row: B = 16)
 # test hook (tests/test_gpu_pipeline.py): PF_BENCH_SHARE_GPU=1 lets the ranks of --gpus N share the GPUs that exist (gloo instead of
 # RCCL, which refuses two ranks per device) so that the N > 1 line - per-rank times, gather, backend - is exercised on a 1-GPU box.
 # Never a measurement: the line says so (config.backend = gloo, identical `devices`)
@@ -652,9 +653,9 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='resident forecast frames per GPU, run as --streams concurrent '
-                    'sub-batches (the reference export loop batches 2; throughput saturates at 48-64 frames in flight as three or '
-                    'four staggered sub-batches of 16)')
+    ap.add_argument('--batch', type=int, default=128, help='resident forecast frames per GPU, run as --streams concurrent '
+                    'sub-batches (the reference export loop batches 2; throughput saturates at 128 frames in flight as four '
+                    'staggered sub-batches of 32)')
     ap.add_argument('--replays', type=int, default=2, help='passes over the resident batch per step (one hipGraph): a step is '
                     '--replays x --batch forecast frames per GPU (20 steps then time about a second)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
