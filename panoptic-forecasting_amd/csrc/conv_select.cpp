@@ -76,8 +76,11 @@ ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout
     // Images of >= 256x512 pixels keep the barrier-synchronised kernel (its big shared tiles move the
     // fewest bytes); below that the wave-autonomous kernel wins everywhere it was measured.  Pick the tile with the
     // most operand reuse (rows x cout tiles) that still puts >= 2 waves on every SIMD of the chip.
+    // (1x1 layers from 32 768 pixels up too - round 5: at 512x1024, B = 16 the wave kernel took the 1x1 layers of the 32x64 level; it
+    //  cannot write the packed-pair layout, so every 3x3 layer of that level fell back to the fp32-source split kernel: 0.56 of
+    //  2.76 ms.  The measured table of the 1024x2048 network makes the same cut: packed pairs down to 32x64 at B = 16.)
     const long px = (long)B * hout * wout;
-    if (px >= 131072) return ConvChoice{1, 0, 0, 0};
+    if (px >= 131072 || (ks == 1 && px >= 32768)) return ConvChoice{1, 0, 0, 0};
     const int ntiles = (cout + 15) / 16;
     ConvChoice best{2, (need & 2) ? 2 : 1, 1, 8};
     long best_reuse = -1, best_waves = -1;

@@ -296,7 +296,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             // eligible convs under pf_debug_force_conv(5, nt, wide)
             const bool forced = g_conv_force.kind == 5;
             const long px = (long)B * a.Hout * a.Wout;
-            bool want = ch.kind == 4 || (o.k == 1 && px >= 131072 && ch.kind == 1) || forced;
+            bool want = ch.kind == 4 || (o.k == 1 && px >= 32768 && ch.kind == 1) || forced;
             r.nt = forced ? g_conv_force.p0 : (o.k == 1 ? 4 : (ch.kind == 4 ? ch.p0 : 2));
             r.wide = forced ? g_conv_force.p1 : (ch.kind == 4 ? ch.p1 : 0);
             ConvChoice s4c;   // measured conv_s4 row of this layer (conv_select.cpp): decides, and names the shape

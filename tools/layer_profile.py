@@ -19,13 +19,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=1)
 ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--force', default='', help='kind,p0,p1,p2 for pf_debug_force_conv')
+ap.add_argument('--size', default='', help='HxW instead of 1024x2048 (the kernel tables have no rows for other sizes: the heuristic choice)')
 args = ap.parse_args()
 for kv in filter(None, os.environ.get('PF_OPTS', '').split(',')):
     k, v = kv.split('=')
     pflib.check(pflib.load().pf_set_option(k.encode(), int(v)), 'pf_set_option')
 if args.force:
     pflib.check(pflib.load().pf_debug_force_conv(*[int(v) for v in args.force.split(',')]), 'pf_debug_force_conv')
-model = build_model(bench.model_params())
+if args.size:
+    bench.H, bench.W = [int(v) for v in args.size.lower().split('x')]
+model = build_model(bench.model_params(final_h=bench.H, final_w=bench.W))
 model.load_state_dict(bench.calibrated_state_dict())
 batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
 for _ in range(3):
