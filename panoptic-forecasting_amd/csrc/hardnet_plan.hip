@@ -295,7 +295,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             // reads S4: the layers the table gives to the split kernels (same tile parameters), big 1x1 convs, or all
             // eligible convs under pf_debug_force_conv(5, nt, wide)
             const bool forced = g_conv_force.kind == 5;
-            const long px = (long)B * a.Hout * a.Wout;
+            const long px = (long)(p->opt_table_batch > 0 ? p->opt_table_batch : B) * a.Hout * a.Wout;   // (the pinned batch decides, like every other choice)
             bool want = ch.kind == 4 || (o.k == 1 && px >= 32768 && ch.kind == 1) || forced;
             r.nt = forced ? g_conv_force.p0 : (o.k == 1 ? 4 : (ch.kind == 4 ? ch.p0 : 2));
             r.wide = forced ? g_conv_force.p1 : (ch.kind == 4 ? ch.p1 : 0);
