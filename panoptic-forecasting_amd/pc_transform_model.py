@@ -16,8 +16,11 @@ PF_SPLAT_PER_FRAME, PF_SPLAT_PER_SAMPLE_SENTINEL = 1, 2      # include/pfhip.h
 
 def host_inverse(m):
     """torch.inverse on the HOST (LAPACK), as the oracle fixes it: the low bits of K^-1 / E^-1 decide
-    which pixel floor() picks for near-integer coordinates (pc_transform_model.py:51,71)."""
-    return torch.inverse(m.detach().float().cpu()).to(m.device)
+    which pixel floor() picks for near-integer coordinates (pc_transform_model.py:51,71).  LAPACK hands back column-major
+    matrices (a strided view); the library wants dense rows, and a ``.contiguous()`` left to every ``predict`` is a copy
+    kernel per matrix per forward - two 4.6 us links in the B = 1 chain of 80 launches (tools/serial_timeline.py) - so the
+    copy is made here, once, on the host."""
+    return torch.inverse(m.detach().float().cpu()).contiguous().to(m.device)
 
 
 def add_camera_inverses(inputs):
@@ -33,9 +36,9 @@ def add_camera_inverses(inputs):
         return inputs
     out = dict(inputs)
     if out.get('intrinsics_inv') is None:
-        out['intrinsics_inv'] = torch.inverse(K.detach().float())
+        out['intrinsics_inv'] = torch.inverse(K.detach().float()).contiguous()
     if out.get('extrinsics_inv') is None:
-        out['extrinsics_inv'] = torch.inverse(E.detach().float())
+        out['extrinsics_inv'] = torch.inverse(E.detach().float()).contiguous()
     return out
 
 

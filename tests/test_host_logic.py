@@ -219,6 +219,10 @@ def test_add_camera_inverses_gives_the_models_own_bits_and_leaves_device_batches
     assert out is not inp and 'intrinsics_inv' not in inp
     assert torch.equal(out['intrinsics_inv'].view(torch.int32), host_inverse(inp['intrinsics']).view(torch.int32))
     assert torch.equal(out['extrinsics_inv'].view(torch.int32), host_inverse(inp['extrinsics']).view(torch.int32))
+    # LAPACK returns column-major views: left like that, every predict() would enqueue one copy kernel per matrix
+    assert not torch.inverse(inp['intrinsics']).is_contiguous()
+    for m in (out['intrinsics_inv'], out['extrinsics_inv'], host_inverse(inp['intrinsics']), host_inverse(inp['extrinsics'])):
+        assert m.is_contiguous()
     assert out['depth'] is inp['depth']
     marked = dict(inp, intrinsics_inv=torch.zeros(2, 3, 3))
     assert add_camera_inverses(marked)['intrinsics_inv'] is marked['intrinsics_inv']
