@@ -50,15 +50,16 @@ bool choose_s4(int ks, int cin, int cout, int hout, int wout, int B, ConvChoice 
 
 ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B, int need, int use_tuned) {
     if (stride != 1) return ConvChoice{1, 0, 0, 0};           // conv_dma, shape by its cost model
-    // The table was measured at B = 1, 2, 4, 8, 16 (a layer without a row at one of those: the heuristics below won
-    // there).  Any other batch size takes the decision of the nearest measured one (in ratio; the larger on a tie): the
-    // choice depends on how many tiles the launch has, which moves slowly with B.
+    // The table was measured at B = 1, 2, 4, 8, 16 and (round 5, the strict-fp32 model at the headline's sub-batch) 32; a layer
+    // without a row at one of those: the heuristics below won there.  Any other batch size takes the decision of the nearest
+    // measured one (in ratio; the larger on a tie; beyond the largest: the largest): the choice depends on how many tiles the
+    // launch has, which moves slowly with B.
     int Bt = B;
-    if (use_tuned && B != 1 && B != 2 && B != 4 && B != 8 && B != 16) {
-        const int measured[5] = {1, 2, 4, 8, 16};
-        Bt = 16;
+    if (use_tuned) {
+        const int measured[6] = {1, 2, 4, 8, 16, 32};
+        Bt = measured[5];
         for (int m : measured)
-            if (m >= B) { Bt = (m > 1 && (long)B * B < (long)m * (m / 2)) ? m / 2 : m; break; }
+            if (m >= B) { Bt = (m > 1 && m != B && (long)B * B < (long)m * (m / 2)) ? m / 2 : m; break; }
     }
     for (const Tuned &t : kTuned)
         if (use_tuned && t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == Bt &&

@@ -22,18 +22,19 @@ ap.add_argument('--json', default=None)
 ap.add_argument('--emit', default=None, help='append the winners as C table rows to this .inc file')
 ap.add_argument('--height', type=int, default=bench.H)
 ap.add_argument('--width', type=int, default=bench.W)
+ap.add_argument('--fp32', action='store_true', help='the strict-fp32 model (split_f16 = 0): only the fp32-MFMA kernel families compete')
 args = ap.parse_args()
 bench.H, bench.W = args.height, args.width
 L = pflib.load()
 pflib.check(L.pf_set_option(b'profile_tag_ops', 1), 'pf_set_option')   # per-op labels in the profile records
 pflib.check(L.pf_set_option(b'use_tuned_table', 0), 'pf_set_option')   # 'auto' = the cost model alone
-model = build_model(bench.model_params())
+model = build_model(bench.model_params(**({'split_f16': 0} if args.fp32 else {})))
 model.load_state_dict(bench.calibrated_state_dict())
 batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
 
 CONFIGS = [(0, 0, 0, 0)] + [(1, wm, nt, 0) for wm in (4, 2, 1) for nt in (1, 2, 3, 4) if not (wm == 1 and nt > 2)] + \
           [(2, mh, nt, wk) for mh in (1, 2, 4) for nt in (1, 2) for wk in (2, 4, 8, 16)] + \
-          ([(4, nt, wd, 0) for nt in (1, 2, 3, 4) for wd in (0, 1)] if os.environ.get('PF_TUNE_SPLIT', '1') != '0' else [])
+          ([(4, nt, wd, 0) for nt in (1, 2, 3, 4) for wd in (0, 1)] if os.environ.get('PF_TUNE_SPLIT', '1') != '0' and not args.fp32 else [])
 
 
 def run(cfg):
