@@ -486,9 +486,9 @@ def train_step_in_fresh_process():
 
 def other_resolution_leg(sd, dev, term, steps):
     """A second resolution, 512x1024 at B = 16 on one stream (hipGraph replay): no row of the measured kernel tables
-    (csrc/conv_s4_tuned.inc, conv_tuned.inc: keyed on the 1024x2048 network's exact shapes) matches, so every layer runs the
-    kernel the heuristics of conv_select.cpp pick - frames/s plus the dominant kernel's roofline fraction of that untuned
-    choice.  Parity at this size: tests/test_gpu_bg_forecast.py::test_second_resolution_heuristic_kernel_choice_vs_oracle."""
+    (csrc/conv_s4_tuned.inc, conv_tuned.inc: keyed on the 1024x2048 network's exact shapes) was measured here, so every layer
+    runs what conv_select.cpp's rule for unmeasured sizes picks (the row of the same layer whose measured launch had as many
+    pixels, else the heuristics) - frames/s plus the dominant kernel's roofline fraction of that choice.  Parity at this size: tests/test_gpu_bg_forecast.py::test_second_resolution_heuristic_kernel_choice_vs_oracle."""
     h, w, b = 512, 1024, 16
     parts = [synth.make_inputs(b=1, t=T, h=h, w=w, seed=i, **TERM[term]) for i in range(b)]
     batch = {k: torch.cat([p[k] for p in parts], 0).to(dev) for k in parts[0]}
@@ -515,7 +515,7 @@ def other_resolution_leg(sd, dev, term, steps):
     m.bg.settle()
     r = roofline_of(recs, 2, b, 'one batch of %d frames at %dx%d, eager, hipEvents' % (b, h, w))
     res = {'value': b * steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'frames_per_step': b,
-           'size': [h, w], 'streams': 1, 'launch': 'hipGraph replay', 'kernel_choice': 'heuristic (no tuned-table row matches)',
+           'size': [h, w], 'streams': 1, 'launch': 'hipGraph replay', 'kernel_choice': 'unmeasured size: rows of the same layer at the batch whose measured launch had as many pixels (here B = 4), else heuristics',
            'range_status_sticky': int(sticky),
            'roofline': {k: r[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'avg_launch_us', 'launches_per_step',
                                           'kernel_ms_per_step')},

@@ -34,13 +34,38 @@ size_t wave_lds_bytes(int ks, int mh, int nt, int wk) {
 }
 }  // namespace
 
+// A layer of the architecture at an image size the tables were not measured at.  Both tables are keyed on the exact shapes of the
+// 1024x2048 network; what a row's choice depends on is how many tiles its launch has, i.e. its pixel count B * hout * wout, not
+// the image size as such (every kernel clips its tiles at the image edge).  So the layer (ks, cin, cout) - each occurs at ONE
+// resolution of the measured network, and the conv_s4 table has a row for every layer at every measured batch - is looked up
+// with the batch size at which the measured launch had the same number of pixels: 512x1024 at B = 16 takes the B = 4 rows.
+// Launches with less than half the pixels of the smallest measured one (B = 1) are outside what the rows know: heuristics.
+// Returns false when the layer is not in the table at all (another architecture) or that small; *exact = its measured size is this one.
+namespace {
+bool measured_geometry(int ks, int cin, int cout, int hout, int wout, int B, int *ht, int *wt, double *b_eq, bool *exact) {
+    for (const Tuned &t : kTunedS4) {
+        if (t.B <= 0 || t.ks != ks || t.cin != cin || t.cout != cout) continue;
+        *ht = t.hout;
+        *wt = t.wout;
+        *exact = t.hout == hout && t.wout == wout;
+        *b_eq = *exact ? (double)B : (double)B * hout * wout / ((double)t.hout * t.wout);
+        return *exact || *b_eq >= 0.5;
+    }
+    return false;
+}
+}  // namespace
+
 // Row of the conv_s4 table for this layer at the measured batch size nearest to B (in ratio); false: no row at all.
 bool choose_s4(int ks, int cin, int cout, int hout, int wout, int B, ConvChoice *out) {
+    int ht, wt;
+    double b_eq;
+    bool exact;
+    if (!measured_geometry(ks, cin, cout, hout, wout, B, &ht, &wt, &b_eq, &exact)) return false;
     const Tuned *best = nullptr;
     double best_d = 0.0;
     for (const Tuned &t : kTunedS4) {
-        if (t.ks != ks || t.cin != cin || t.cout != cout || t.hout != hout || t.wout != wout || t.B <= 0) continue;
-        const double d = t.B > B ? (double)t.B / B : (double)B / t.B;
+        if (t.ks != ks || t.cin != cin || t.cout != cout || t.hout != ht || t.wout != wt || t.B <= 0) continue;
+        const double d = t.B > b_eq ? (double)t.B / b_eq : b_eq / (double)t.B;
         if (!best || d < best_d || (d == best_d && t.B > best->B)) { best = &t; best_d = d; }
     }
     if (!best) return false;
@@ -54,15 +79,19 @@ ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout
     // without a row at one of those: the heuristics below won there.  Any other batch size takes the decision of the nearest
     // measured one (in ratio; the larger on a tie; beyond the largest: the largest): the choice depends on how many tiles the
     // launch has, which moves slowly with B.
-    int Bt = B;
+    int Bt = B, ht = hout, wt = wout;
     if (use_tuned) {
+        // (a layer at another image size than the measured one: the batch at which the measured launch had as many pixels)
+        double b_eq = (double)B;
+        bool exact = true;
+        if (!measured_geometry(ks, cin, cout, hout, wout, B, &ht, &wt, &b_eq, &exact)) { ht = hout; wt = wout; b_eq = (double)B; }
         const int measured[6] = {1, 2, 4, 8, 16, 32};
         Bt = measured[5];
         for (int m : measured)
-            if (m >= B) { Bt = (m > 1 && m != B && (long)B * B < (long)m * (m / 2)) ? m / 2 : m; break; }
+            if ((double)m >= b_eq) { Bt = (m > 1 && (double)m != b_eq && b_eq * b_eq < (double)m * (m / 2)) ? m / 2 : m; break; }
     }
     for (const Tuned &t : kTuned)
-        if (use_tuned && t.ks == ks && t.cin == cin && t.cout == cout && t.hout == hout && t.wout == wout && t.B == Bt &&
+        if (use_tuned && t.ks == ks && t.cin == cin && t.cout == cout && t.hout == ht && t.wout == wt && t.B == Bt &&
             (!(need & 2) || t.c.kind != 2 || t.c.p0 != 1))
             return t.c;
     // Untuned shape.  Large stride-1 3x3 layers go to the split kernel: on every measured shape with >= 64x128

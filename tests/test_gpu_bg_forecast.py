@@ -144,8 +144,9 @@ def test_full_size_timed_configuration_vs_oracle(b, split, term):
 
 def test_second_resolution_heuristic_kernel_choice_vs_oracle():
     """512x1024, B = 16 - the configuration of bench.py's `other_resolution` leg.  No row of csrc/conv_s4_tuned.inc /
-    conv_tuned.inc matches these shapes, so every layer's kernel comes from the heuristics of conv_select.cpp (the cost model,
-    the reuse-vs-occupancy rule, `conv_split` / `conv_s4` defaults): the untuned choice is held to the same 1e-4 as the tuned
+    conv_tuned.inc was measured at these shapes: every layer's kernel comes from conv_select.cpp's rule for unmeasured sizes (the
+    row of the same layer whose measured launch had as many pixels - here the B = 4 rows - else the cost model, the
+    reuse-vs-occupancy rule and the `conv_split` / `conv_s4` defaults): that choice is held to the same 1e-4 as the measured
     one, first and last frame of the batch, warped inputs bit-exact."""
     from panoptic_forecasting_amd import synth
     from panoptic_forecasting_amd.registry import build_model
