@@ -142,15 +142,17 @@ def test_full_size_timed_configuration_vs_oracle(b, split, term):
         assert agree >= 0.999, (i, agree)
 
 
-def test_second_resolution_heuristic_kernel_choice_vs_oracle():
-    """512x1024, B = 16 - the configuration of bench.py's `other_resolution` leg.  No row of csrc/conv_s4_tuned.inc /
-    conv_tuned.inc was measured at these shapes: every layer's kernel comes from conv_select.cpp's rule for unmeasured sizes (the
-    row of the same layer whose measured launch had as many pixels - here the B = 4 rows - else the cost model, the
-    reuse-vs-occupancy rule and the `conv_split` / `conv_s4` defaults): that choice is held to the same 1e-4 as the measured
-    one, first and last frame of the batch, warped inputs bit-exact."""
+@pytest.mark.parametrize('h,w,b', [(512, 1024, 16), (256, 512, 16), (384, 768, 6), (768, 1536, 3)],
+                         ids=['512x1024_B16_rows_of_B4', '256x512_B16_rows_of_B1', '384x768_B6_rows_of_B1', '768x1536_B3_rows_of_B2'])
+def test_second_resolution_heuristic_kernel_choice_vs_oracle(h, w, b):
+    """Image sizes the kernel tables were not measured at; 512x1024, B = 16 is the configuration of bench.py's
+    `other_resolution` leg.  No row of csrc/conv_s4_tuned.inc / conv_tuned.inc has these shapes: every layer's kernel comes from
+    conv_select.cpp's rule for unmeasured sizes (the row of the same layer whose measured launch had as many pixels - the B = 4
+    rows for 512x1024 at B = 16, B = 1 for 256x512 at 16 and 384x768 at 6 (0.84), B = 2 for 768x1536 at 3 (1.7) - else the
+    cost model, the reuse-vs-occupancy rule and the `conv_split` / `conv_s4` defaults): that choice is held to the same 1e-4
+    as the measured one, first and last frame of the batch, warped inputs bit-exact."""
     from panoptic_forecasting_amd import synth
     from panoptic_forecasting_amd.registry import build_model
-    h, w, b = 512, 1024, 16
     sd = _sd()
     m = build_model(_params(h, w, return_logits='orig', emulate_disk_hop=True, seg_is_label_id=True, per_sample_sentinel=True))
     m.load_state_dict(sd)
