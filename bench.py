@@ -22,7 +22,9 @@ RCCL; started by an external launcher it reads RANK/LOCAL_RANK/WORLD_SIZE from t
 when the ranks that joined differ from ``--gpus`` or the node has fewer GPUs than ranks.
 
 At N=1 the same line also carries (driver-timed, same process):
-    by_batch   frames/s of ONE stream at B = 1, 2, 4 frames per step (SURVEY.md 8d Config 2; the reference loop batches 2)
+    by_batch   frames/s of ONE stream at B = 1, 2, 4 frames per step (SURVEY.md 8d Config 2; the reference loop batches 2): latency
+    by_batch_pipelined  the reference-shaped loop double-buffered (export_bg.py --pipeline_depth 2): B = 1, 2 per batch, two model
+               replicas on two streams, eager, fresh host-inverse camera tensors every batch
     fresh_cameras  eager B = 2 / 16 with NEW camera tensors every step: inverses taken on the host batch vs read back by the model
     other_resolution  512x1024 at B = 16, one stream: the heuristic (untuned) kernel choice, frames/s + dominant-kernel fraction
     train_step  one bg training step at batch 8 of 800x800 (configs/bg/bg_train.yaml): ms, dominant kernel + its fraction of the fp32 matrix peak
@@ -35,6 +37,10 @@ At N=1 the same line also carries (driver-timed, same process):
                   words after the timed region); a true here would invalidate the run and bench.py exits non-zero.  Eager
                   forwards (--no-graph) that were flagged have been re-run on fp32 MFMA (`range_reruns`): valid, not an error;
                   `range_status_sticky` carries the raw word either way
+The driver keeps the standard keys plus the scalars of `config`, `roofline` and `cpu_baseline` (strings cut at 120 characters, nested
+objects dropped), so every number a reader needs is ALSO a scalar there: roofline.step_frac, roofline.fp32_only_value / _frac /
+_kernel / _max_abs_dlogit, roofline.train_step_ms, roofline.other_resolution_value / _frac, roofline.parity_max_abs_dlogit,
+config.by_batch, config.by_batch_pipelined.  The line is kept under 6 KB (--verbose adds the per-stage breakdown and the legs' details).
 """
 import argparse
 import glob
@@ -59,7 +65,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec (6.3 TB/s achievable)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 (2495 measured; tools/ubench/f16_split.hip: same rate)
 CPU_BUDGET_S = 20.0             # stop starting new baseline frames after this much CPU time
-SUB_BATCH = 32                  # frames per concurrent sub-batch of the headline workload (the shape tables' nearest row: B = 16)
+SUB_BATCH = 32                  # frames per concurrent sub-batch of the headline workload (the shape tables hold rows measured at B = 32)
 # test hook (tests/test_gpu_pipeline.py): PF_BENCH_SHARE_GPU=1 lets the ranks of --gpus N share the GPUs that exist (gloo instead of
 # RCCL, which refuses two ranks per device) so that the N > 1 line - per-rank times, gather, backend - is exercised on a 1-GPU box.
 # Never a measurement: the line says so (config.backend = gloo, identical `devices`)
@@ -464,6 +470,59 @@ def fresh_cameras_leg(sd, dev, term):
     return res
 
 
+def pipelined_leg(sd, dev, term, steps_by_b=((1, 480), (2, 360))):
+    """the reference-shaped loop (export_cityscapes_segmentation_results.py:75-85: loader -> batch2gpu -> predict
+    -> write) is a STREAM of batches, so it can be double-buffered without touching predict's contract: two model replicas on two
+    HIP streams, batch k + 1 enqueued while batch k runs (what export_bg.py --pipeline_depth 2 does).  Eager launches, the big
+    tensors resident, the camera tensors rebuilt from host memory with host-side inverses every batch (add_camera_inverses) - no
+    graph, no cache hit, no synchronisation inside the loop.  by_batch stays the latency figure of ONE forward at a time."""
+    from panoptic_forecasting_amd.pc_transform_model import add_camera_inverses
+    cam_keys = ('intrinsics', 'extrinsics', 'target_T')
+    res = {}
+    for b, steps in steps_by_b:
+        models = []
+        for _ in range(2):
+            m = build_model(model_params())
+            m.load_state_dict(sd)
+            m.eval()
+            models.append(m)
+        host = {k: torch.cat([synth.make_inputs(b=1, t=T, h=H, w=W, seed=i, **TERM[term])[k] for i in range(b)], 0)
+                for k in ('depth', 'depth_mask', 'seg') + cam_keys}
+        big = {k: host[k].to(dev) for k in ('depth', 'depth_mask', 'seg')}
+        cams_host = {k: host[k].pin_memory() for k in cam_keys}
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [None, None]
+
+        def run(n):
+            cur = torch.cuda.current_stream()
+            for st in streams:
+                st.wait_stream(cur)
+            for k in range(n):
+                i = k & 1
+                fresh = add_camera_inverses({kk: v.clone() for kk, v in cams_host.items()})
+                with torch.cuda.stream(streams[i]):
+                    cams = {kk: v.pin_memory().to(dev, non_blocking=True) for kk, v in fresh.items()}
+                    outs[i] = models[i].predict(dict(big, **cams), None)
+            for st in streams:
+                cur.wait_stream(st)
+        run(10)
+        for m in models:
+            m.bg.settle()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        for m in models:
+            m.bg.settle()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[str(b)] = {'value': b * steps / dt, 'unit': 'frames/s', 'ms_per_batch': 1e3 * dt / steps, 'steps': steps,
+                       'streams': 2, 'launch': 'eager', 'cameras': 'fresh, host inverses',
+                       'reruns': sum(m.bg.range_reruns for m in models)}
+        del models, big, outs
+        torch.cuda.empty_cache()
+    return res
+
+
 def train_step_in_fresh_process():
     """`train_step_leg` in a process of its own (python bench.py --train-step-only).  Not for cleanliness: by this point this
     process has created a dozen HIP streams (the sub-batch streams of every leg, torch's stream pool, capture streams), and
@@ -674,6 +733,7 @@ def parse_args(argv=None):
     ap.add_argument('--term', choices=['short', 'mid'], default='short',
                     help="short = BASELINE configs[1] (dt=3, the headline); mid = configs[2] (dt=9, predicted odometry)")
     ap.add_argument('--train-step-only', action='store_true', help='print the train_step object alone (the N=1 line runs this in a fresh process)')
+    ap.add_argument('--verbose', action='store_true', help='keep the per-stage breakdown and every detail of the legs in the line (> 6 KB)')
     ap.add_argument('--dry-run', action='store_true', help='rendezvous + the sharded metric exchange only (gloo, no GPU '
                     'work): checks that --gpus N really starts N ranks')
     return ap.parse_args(argv)
@@ -783,7 +843,7 @@ def main():
                     r['label'][:70], r['launches'] // args.profile_steps, r['ms'] / args.profile_steps,
                     r['flops'] / max(r['ms'], 1e-9) / 1e9, r['bytes'] / max(r['ms'], 1e-9) / 1e6), file=sys.stderr)
 
-    cpu = parity = by_batch = fp32_only = fresh_cameras = train_step = other_resolution = None
+    cpu = parity = by_batch = by_batch_pipelined = fp32_only = fresh_cameras = train_step = other_resolution = None
     single = rank == 0 and world == 1
     ref = None
     n_done = 0
@@ -829,6 +889,8 @@ def main():
             reruns += sum(m.bg.range_reruns for m in leg.models)
             del leg
             torch.cuda.empty_cache()
+        by_batch_pipelined = pipelined_leg(sd, dev, args.term)
+        reruns += sum(v['reruns'] for v in by_batch_pipelined.values())
         fresh_cameras = fresh_cameras_leg(sd, dev, args.term)
         if not args.fp32_mfma_only:
             other_resolution, st = other_resolution_leg(sd, dev, args.term, max(args.steps, 30) * 4)
@@ -857,39 +919,83 @@ def main():
         train_step = train_step_in_fresh_process()
 
     if rank == 0:
+        r3 = lambda x: None if x is None else round(float(x), 3)
+        launch = (('hipGraph per sub-batch, free-running streams (+%g ms)' % args.free_run) if (args.free_run is not None and use_graph and S > 1)
+                  else (('hipGraph replay' if use_graph else 'eager') + (', sub-batches staggered' if (args.stagger and S > 1) else '')))
+        config = {'workload': 'configs[%d] bg %s-term forecast 3-in dt=%d @1024x2048: 3 warp/splats + HarDNet-70 + upsample/argmax' % (
+                      (1, 'short', 3) if args.term == 'short' else (2, 'mid', 9)),
+                  'frames_per_gpu_per_step': B * R, 'resident_frames_per_gpu': B, 'passes_per_step': R, 'streams': S,
+                  'sub_batch': B // S, 'launch': launch, 'weights': 'random-init, calibrated (tests/golden/calib_seed1234.json)',
+                  'model': "registry.build_model(task 'bg_forecast'), default options (on_range_overflow='rerun', per-sample sentinel)",
+                  'sharding': 'batch over %d rank(s), no data-path collective' % world, 'world': joined,
+                  'device': torch.cuda.get_device_name(local), 'backend': pfdist.backend_description()}
+        if roofline is not None:
+            # scalars the driver's record keeps (nested objects are dropped there): see the module docstring
+            roofline['step_frac'] = roofline['step']['frac']
+            roofline['step_kernel_ms'] = roofline['step']['kernel_ms']
+            for name, st in roofline['step']['stages'].items():
+                roofline['stage_ms_' + name] = r3(st['ms'])
+            if parity is not None:
+                roofline['parity_max_abs_dlogit'] = parity['max_abs_dlogit_vs_oracle']
+                roofline['parity_argmax_agreement'] = parity['argmax_agreement_vs_oracle']
+            if fp32_only is not None:
+                roofline.update({'fp32_only_value': r3(fp32_only['value']), 'fp32_only_frac': fp32_only['roofline']['frac'],
+                                 'fp32_only_bound': fp32_only['roofline']['bound'], 'fp32_only_kernel': fp32_only['roofline']['kernel'][:80],
+                                 'fp32_only_step_frac': fp32_only['roofline_step_frac'],
+                                 'fp32_only_max_abs_dlogit': fp32_only.get('max_abs_dlogit')})
+            if train_step is not None and 'ms_per_step' in train_step:
+                roofline.update({'train_step_ms': r3(train_step['ms_per_step']), 'train_step_dominant_frac': train_step['dominant_kernel']['frac'],
+                                 'train_step_dominant_kernel': train_step['dominant_kernel']['kernel'][:60]})
+            if other_resolution is not None:
+                roofline.update({'other_resolution_value': r3(other_resolution['value']), 'other_resolution_frac': other_resolution['roofline']['frac'],
+                                 'other_resolution_kernel': other_resolution['roofline']['kernel'][:60]})
+            if not args.verbose:
+                for k in ('step', 'peak_note', 'traffic_note', 'measured_on'):
+                    roofline.pop(k, None)
+        if by_batch is not None:
+            config['by_batch'] = ', '.join('B%s %.0f' % (k, v['value']) for k, v in by_batch.items()) + ' frames/s (1 stream, graph)'
+        if by_batch_pipelined is not None:
+            config['by_batch_pipelined'] = ', '.join('B%s %.0f' % (k, v['value']) for k, v in by_batch_pipelined.items()) + \
+                ' frames/s (2 streams, eager, fresh cameras)'
+        if fresh_cameras is not None:
+            config['fresh_cameras'] = '; '.join('B%s ' % k + ' / '.join('%.0f' % v[m_]['value'] for m_ in ('cached', 'host_inverses', 'device_cameras'))
+                                                for k, v in fresh_cameras.items()) + ' (cached / host inverses / device cameras)'
+        if cpu is not None and not args.verbose:
+            cpu = {k: v for k, v in cpu.items() if k != 'network_s_per_frame_by_threads'}
+            cpu['sample'] = cpu['sample'][:118]
+
+        def slim(leg, keep):
+            return None if leg is None else {k: leg[k] for k in keep if k in leg}
+        if not args.verbose:
+            if by_batch is not None:
+                by_batch = {k: r3(v['value']) for k, v in by_batch.items()}
+            if by_batch_pipelined is not None:
+                by_batch_pipelined = {k: r3(v['value']) for k, v in by_batch_pipelined.items()}
+            if fresh_cameras is not None:
+                fresh_cameras = {k: {m_: r3(v[m_]['value']) for m_ in ('cached', 'host_inverses', 'device_cameras')} for k, v in fresh_cameras.items()}
+            if fp32_only is not None:
+                fp32_only = dict(slim(fp32_only, ('value', 'unit', 'ms_per_step', 'dtype', 'max_abs_dlogit', 'argmax_agreement_vs_oracle', 'roofline_step_frac')),
+                                 frac=fp32_only['roofline']['frac'], bound=fp32_only['roofline']['bound'], kernel=fp32_only['roofline']['kernel'][:60])
+            if other_resolution is not None:
+                other_resolution = dict(slim(other_resolution, ('value', 'unit', 'ms_per_step', 'frames_per_step', 'size', 'roofline_step_frac')),
+                                        frac=other_resolution['roofline']['frac'], kernel=other_resolution['roofline']['kernel'][:60])
+            if train_step is not None and 'ms_per_step' in train_step:
+                train_step = dict(slim(train_step, ('ms_per_step', 'samples_per_s', 'batch', 'size', 'dtype', 'loss', 'kernel_ms_sum', 'launches')),
+                                  dominant_kernel=train_step['dominant_kernel']['kernel'][:60], dominant_frac=train_step['dominant_kernel']['frac'],
+                                  dominant_TFLOPs=r3(train_step['dominant_kernel']['TFLOPs']))
         line = {'metric': 'forecast frames/sec @1024x2048, 3-in->dt=%d bg' % (3 if args.term == 'short' else 9), 'value': value, 'unit': 'frames/s',
                 'n_gpus': joined, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                'dtype': 'f32' if args.fp32_mfma_only else
-                         'f32 (accumulation, strided / low-resolution convs: fp32 MFMA; tuned 3x3 and 1x1 layers: every fp32 operand '
-                         'as two round-to-nearest fp16 terms hi + mid, |x - hi - mid| <= 2^-23 |x| + 2^-25 for |x| <= 65504 (fp32 '
-                         'rounding itself: 2^-24; proven in tests/test_host_logic.py::test_split_operand_bound), 3 products on '
-                         'the fp16 MFMA (the dropped mid*mid <= 2^-22 of a product), fp32 accumulate; stored channels are pre-scaled '
-                         'by powers of two chosen from the folded weights; a value beyond 65504 raises PF_STATUS_RANGE, a tensor whose '
-                         'maximum is below 2^-6 raises PF_STATUS_RANGE_LOW, and a flagged forward is re-run on fp32 MFMA: see '
-                         'range_overflow)', 'data': 'synthetic',
+                # (the operand bound and its proof: DESIGN.md 4; the strict-fp32-instruction number: roofline.fp32_only_value)
+                'dtype': 'f32' if args.fp32_mfma_only else 'f32 as 2 fp16 terms/operand, 3 MFMA products, f32 accumulate (strict f32: fp32_only)',
+                'data': 'synthetic',
                 'range_overflow': bool(overflow), 'range_status_sticky': int(sticky), 'range_reruns': int(reruns),
-                'config': {'workload': ('configs[1]: bg short-term forecast, 3 frames in, dt=3' if args.term == 'short' else
-                                        'configs[2]: bg mid-term forecast, 3 frames in, dt=9, predicted-odometry ego chain') +
-                                       ', 1024x2048, random-init calibrated weights; step = 3 warp/splats + HarDNet + upsample/argmax',
-                           'frames_per_gpu_per_step': B * R, 'resident_frames_per_gpu': B, 'passes_per_step': R, 'streams': S, 'launch': ('hipGraph per sub-batch on free-running streams, offset %g ms' % args.free_run) if (args.free_run is not None and use_graph and S > 1)
-                           else (('hipGraph replay' if use_graph else 'eager') + (', sub-batches staggered (software pipeline across the passes of a step)' if (args.stagger and S > 1) else '')),
-                           'model': "registry.build_model(task 'bg_forecast') with default execution options: on_range_overflow = 'rerun' "
-                                    '(asynchronous status check; inside the captured graph every forward ORs its status into the sticky word '
-                                    'read after the timed region), camera inverses computed and cached by the model',
-                           'sentinel': 'per sample (model.per_sample_sentinel = True: outputs independent of batching / sharding; the '
-                                       "reference's batch-global max+1 couples the samples of a predict call)",
-                           'inputs': '%d resident synthetic frames per GPU, the same frames replayed every pass (%.1f GB of inputs, more '
-                                     'than the 256 MB Infinity Cache)' % (B, B * 37.75e6 / 1e9),
-                           'sharding': 'batch over %d rank(s), no data-path collective' % world,
-                           'world': joined, 'device': torch.cuda.get_device_name(local),
-                           'backend': pfdist.backend_description()},
-                'per_rank_ms': [r['ms_per_step'] for r in per_rank],
-                'per_rank_ms_min_max': [min(r['ms_per_step'] for r in per_rank), max(r['ms_per_step'] for r in per_rank)],
+                'config': config,
+                'per_rank_ms': [r3(r['ms_per_step']) for r in per_rank],
                 'devices': [r['device'] for r in per_rank],
-                'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity, 'by_batch': by_batch, 'fresh_cameras': fresh_cameras, 'other_resolution': other_resolution, 'fp32_only': fp32_only, 'train_step': train_step,
-                'pq_gather_check': {'pq_vs_last_input_labels': pq_synth, 'ranks_gathered': int(allacc.shape[0]),
-                                    'note': 'random-init weights: value is meaningless, it exercises the sharded PQ all-gather'}}
+                'roofline': roofline, 'cpu_baseline': cpu, 'parity': parity, 'by_batch': by_batch, 'by_batch_pipelined': by_batch_pipelined,
+                'fresh_cameras': fresh_cameras, 'other_resolution': other_resolution, 'fp32_only': fp32_only, 'train_step': train_step,
+                'pq_gather_check': {'pq_vs_last_input_labels': pq_synth, 'ranks_gathered': int(allacc.shape[0])}}
         print(json.dumps(line))
     if pfdist.is_dist():
         torch.distributed.barrier()

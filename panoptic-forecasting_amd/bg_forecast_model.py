@@ -58,7 +58,8 @@ class BGForecastModel(BaseModel):
             hop |= PF_HOP_TRAINID_LUT
         mask = None if (hop & PF_HOP_DEPTH_U16) else (depth_w > 0)
         (seg, logits, orig), token = self.bg.run_async(seg_w, depth_w, mask, want_logits=self.return_logits is True,
-                                                       want_orig=bool(self.return_logits), hop_flags=hop, seg_dtype=torch.uint8)
+                                                       want_orig=bool(self.return_logits), hop_flags=hop, seg_dtype=torch.uint8,
+                                                       own_inputs=True)
         out = {'seg': seg, 'warped_seg': seg_w, 'warped_depth': depth_w}
         if logits is not None:
             out['logits'] = logits

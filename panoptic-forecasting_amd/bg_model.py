@@ -31,13 +31,21 @@ PF_WS_STATUS_BYTES = 2048
 
 class _Pending:
     """One enqueued forward whose status words are on their way to pinned host memory."""
-    __slots__ = ('slot', 'event', 'stream', 'args', 'outs', 'done', 'stamps')
+    __slots__ = ('slot', 'event', 'stream', 'args', 'outs', 'done', 'stamps', 'error')
 
 
 def _stamp(t):
     """(storage address, in-place version) of a tensor argument at enqueue time: a late fp32 re-run reads the caller's input
-    tensors again, so it must see the numbers the flagged forward saw (see ``BGModel._resolve``)."""
-    return (t.data_ptr(), t._version) if torch.is_tensor(t) else None
+    tensors again, so it must see the numbers the flagged forward saw (see ``BGModel._resolve``).  Inference tensors
+    (``torch.inference_mode()``) carry no version counter - reading ``_version`` raises - and stamp as ``(address, None)``:
+    ``run_async`` settles such a forward before it returns instead of trusting a check it cannot make."""
+    if not torch.is_tensor(t):
+        return None
+    return (t.data_ptr(), None if t.is_inference() else t._version)
+
+
+def _unversioned(stamps):
+    return any(s is not None and s[1] is None for s in stamps)
 
 
 class LazyResult(collections.abc.MutableMapping):
@@ -58,9 +66,11 @@ class LazyResult(collections.abc.MutableMapping):
         self._data, self._model, self._token = dict(data), model, token
 
     def _resolve(self):
+        # the token stays until its forward is settled WITHOUT an error: a failed check (policy 'raise', inputs refilled in
+        # place) raises on every access of this result, not only on the first
         if self._token is not None:
-            token, self._token = self._token, None
-            self._model._resolve(token)
+            self._model._resolve(self._token)
+            self._token = None
 
     def __getitem__(self, k):
         self._resolve()
@@ -315,9 +325,13 @@ class BGModel(BaseModel):
     # ---- device forward ---------------------------------------------------------------------
     _RING = 32
 
-    def _resolve(self, token):
-        """Wait for ONE forward's status words and apply the policy (see LazyResult)."""
+    def _resolve(self, token, owner=True):
+        """Wait for ONE forward's status words and apply the policy (see LazyResult).  A failed check is RECORDED on the token
+        and raised to whoever owns the result, on every access; `owner=False` (the housekeeping of a later predict: ``_poll``,
+        the ring wrapping) never raises - frame i + 1's predict must not die of frame i's flag."""
         if token.done:
+            if token.error is not None and owner:
+                raise token.error
             return
         if not token.event.query():      # (a fired event needs no wait: _poll() settles forwards without any synchronising call)
             token.event.synchronize()
@@ -330,18 +344,22 @@ class BGModel(BaseModel):
         if not (status & PF_STATUS_ANY):
             return
         if self.on_range_overflow == 'raise':
-            raise _lib.PfError('bg forward: status %d on the two-term fp16 operand path (PF_STATUS_RANGE = 1: an activation '
-                               'exceeded 65504; PF_STATUS_RANGE_LOW = 2: a tensor of tiny values, max below 2^-6); run with '
-                               "model.split_f16 = 0 or on_range_overflow = 'rerun'" % status)
+            token.error = _lib.PfError('bg forward: status %d on the two-term fp16 operand path (PF_STATUS_RANGE = 1: an activation '
+                                       'exceeded 65504; PF_STATUS_RANGE_LOW = 2: a tensor of tiny values, max below 2^-6); run with '
+                                       "model.split_f16 = 0 or on_range_overflow = 'rerun'" % status)
         # The re-run reads the caller's input tensors NOW, not when predict() was called.  If they were refilled in place since
         # (a static input buffer with `static.copy_(batch)`, a pinned staging loop), re-running would silently put a newer
         # frame's result into the older frame's outputs: refuse instead.  (Writes that bypass torch's version counter -
         # `x.data.copy_`, a foreign kernel - are not seen: such callers use model.range_check = 'sync'.)
-        if stamps != tuple(_stamp(t) for t in args[:3]):
-            raise _lib.PfError('bg forward: status %d on the two-term fp16 operand path, and the input tensors of that forward were '
-                               'modified in place before its result was first touched - the fp32 re-run cannot see the original '
-                               "frame.  Keep a forward's inputs unchanged until its result has been read (or model.settle()), or "
-                               "build the model with model.range_check = 'sync'" % status)
+        elif stamps is not None and stamps != tuple(_stamp(t) for t in args[:3]):
+            token.error = _lib.PfError('bg forward: status %d on the two-term fp16 operand path, and the input tensors of that forward were '
+                                       'modified in place before its result was first touched - the fp32 re-run cannot see the original '
+                                       "frame.  Keep a forward's inputs unchanged until its result has been read (or model.settle()), or "
+                                       "build the model with model.range_check = 'sync'" % status)
+        if token.error is not None:
+            if owner:
+                raise token.error
+            return
         L, plan = _lib.load(), self._get_plan()
         self.range_reruns += 1
         prior = self.plan_options.get('split_f16', 1)
@@ -360,20 +378,22 @@ class BGModel(BaseModel):
     def _poll(self):
         """Non-blocking: settle every enqueued forward whose status has arrived (predict i checks forward i - 1)."""
         while self._pending and self._pending[0].event.query():
-            self._resolve(self._pending[0])
+            self._resolve(self._pending[0], owner=False)
 
     def _drain(self):
         while self._pending:
-            self._resolve(self._pending[0])
+            self._resolve(self._pending[0], owner=False)
 
     def settle(self):
         """Wait for and check every forward enqueued so far (what the first access of each LazyResult would do)."""
         self._drain()
 
-    def run_async(self, inps, depths, depth_masks, want_logits=True, want_orig=True, hop_flags=0, seg_dtype=torch.int64):
+    def run_async(self, inps, depths, depth_masks, want_logits=True, want_orig=True, hop_flags=0, seg_dtype=torch.int64,
+                  own_inputs=False):
         """Enqueue ``pf_bg_forward`` / ``pf_hardnet_forward_dense`` -> ((seg, logits|None, orig|None), token).  ``token`` is
         None when nothing has to be checked (policy 'ignore', fp32-only plan, stream capture); else pass it to
-        ``_resolve`` (or wrap the outputs in a LazyResult) before using them."""
+        ``_resolve`` (or wrap the outputs in a LazyResult) before using them.  ``own_inputs``: the tensors were made by the caller
+        of this method for this forward alone (``task: bg_forecast``'s warped frames) - no refill check is needed or made."""
         capturing = torch.cuda.is_current_stream_capturing()
         if not capturing:                      # (events cannot be queried while a stream captures)
             self._poll()
@@ -387,15 +407,19 @@ class BGModel(BaseModel):
         self._ring_next = (slot + 1) % self._RING
         for t in list(self._pending):          # the ring wrapped onto a forward nobody has looked at yet
             if t.slot == slot:
-                self._resolve(t)
+                self._resolve(t, owner=False)
         self._pinned[slot].copy_(self._ws[:8].view(torch.int32), non_blocking=True)
         token = _Pending()
-        token.slot, token.args, token.outs, token.done = slot, args, outs, False
-        token.stamps = tuple(_stamp(t) for t in args[:3])
+        token.slot, token.args, token.outs, token.done, token.error = slot, args, outs, False, None
+        token.stamps = None if own_inputs else tuple(_stamp(t) for t in args[:3])
         token.stream = torch.cuda.current_stream()
         token.event = torch.cuda.Event()
         token.event.record(token.stream)
         self._pending.append(token)
+        if token.stamps is not None and _unversioned(token.stamps):
+            # inference tensors: an in-place refill could not be detected later - settle this forward now (one synchronisation)
+            self._resolve(token)
+            return outs, None
         return outs, token
 
     def run(self, inps, depths, depth_masks, want_logits=True, want_orig=True, hop_flags=0, seg_dtype=torch.int64):

@@ -43,15 +43,26 @@ size_t wave_lds_bytes(int ks, int mh, int nt, int wk) {
 // Returns false when the layer is not in the table at all (another architecture) or that small; *exact = its measured size is this one.
 namespace {
 bool measured_geometry(int ks, int cin, int cout, int hout, int wout, int B, int *ht, int *wt, double *b_eq, bool *exact) {
+    // a row measured at exactly this size wins over any other resolution of the same (ks, cin, cout) (today every layer occurs at one
+    // resolution - tests/test_host_logic.py asserts it on both tables - but a table that gains a second size must not remap the first)
+    const Tuned *first = nullptr;
     for (const Tuned &t : kTunedS4) {
         if (t.B <= 0 || t.ks != ks || t.cin != cin || t.cout != cout) continue;
-        *ht = t.hout;
-        *wt = t.wout;
-        *exact = t.hout == hout && t.wout == wout;
-        *b_eq = *exact ? (double)B : (double)B * hout * wout / ((double)t.hout * t.wout);
-        return *exact || *b_eq >= 0.5;
+        if (t.hout == hout && t.wout == wout) {
+            *ht = hout;
+            *wt = wout;
+            *exact = true;
+            *b_eq = (double)B;
+            return true;
+        }
+        if (!first) first = &t;
     }
-    return false;
+    if (!first) return false;
+    *ht = first->hout;
+    *wt = first->wout;
+    *exact = false;
+    *b_eq = (double)B * hout * wout / ((double)first->hout * first->wout);
+    return *b_eq >= 0.5;
 }
 }  // namespace
 
@@ -90,6 +101,8 @@ ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout
         for (int m : measured)
             if ((double)m >= b_eq) { Bt = (m > 1 && (double)m != b_eq && b_eq * b_eq < (double)m * (m / 2)) ? m / 2 : m; break; }
     }
+    // (a layer without a B = 32 row: the cost model / heuristics below measured faster there - rows are kept only where they win by
+    //  > 3 % - so it does NOT fall back to its B = 16 row)
     for (const Tuned &t : kTuned)
         if (use_tuned && t.ks == ks && t.cin == cin && t.cout == cout && t.hout == ht && t.wout == wt && t.B == Bt &&
             (!(need & 2) || t.c.kind != 2 || t.c.p0 != 1))

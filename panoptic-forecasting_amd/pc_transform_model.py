@@ -57,22 +57,49 @@ class InverseCache:
     16 floats, no stream involved): numpy-aliased camera matrices edited in place are the likeliest stale-key case.
     A batch that carries ``intrinsics_inv`` / ``extrinsics_inv`` (``add_camera_inverses``) never comes here."""
 
-    def __init__(self, capacity=16, verify=None):
+    def __init__(self, capacity=16, verify=None, verify_every=64):
         import os
         self.capacity, self._d = capacity, {}
         self.verify = bool(int(os.environ.get('PF_VERIFY_CAMERA_CACHE', '0'))) if verify is None else bool(verify)
+        # round 6: without `verify`, a DEVICE tensor's hit is still content-checked on its first and then every
+        # `verify_every`-th hit (one stream synchronisation per 64 predicts per camera tensor; 0 = never): a write that
+        # bypasses the version counter is found within that many frames instead of never.  The reference inverts every call
+        # (pc_transform_model.py:51,71); callers that cannot tolerate the window use verify = True or add_camera_inverses.
+        self.verify_every = int(os.environ.get('PF_VERIFY_CAMERA_EVERY', verify_every))
+        self._hits = {}
+        self._warned, self._dev_misses = False, 0
 
     def __call__(self, m):
+        if m.is_inference():
+            # no version counter to key on (reading `_version` raises): inverted every call, like the reference
+            return host_inverse(m)
         key = (m.data_ptr(), m._version, tuple(m.shape), m.dtype, str(m.device))
         hit = self._d.get(key)
         capturing = m.is_cuda and torch.cuda.is_current_stream_capturing()
-        check = (self.verify and not capturing) if m.is_cuda else True
+        if m.is_cuda:
+            check = self.verify and not capturing
+            if hit is not None and not check and not capturing and self.verify_every > 0:
+                n = self._hits.get(key, 0)
+                self._hits[key] = n + 1
+                check = n % self.verify_every == 0
+        else:
+            check = True
         if hit is not None and check and not torch.equal(m, hit[2]):
             hit = None               # same storage, same version, other numbers
         if hit is None:
             self._d.pop(key, None)
+            self._hits.pop(key, None)
             if len(self._d) >= self.capacity:
-                self._d.pop(next(iter(self._d)))
+                old = next(iter(self._d))
+                self._d.pop(old)
+                self._hits.pop(old, None)
+            self._dev_misses += int(m.is_cuda)
+            if self._dev_misses == 9 and not self._warned:       # K and E of four batches were cached constants at most
+                import warnings
+                self._warned = True
+                warnings.warn('panoptic_forecasting_amd: camera matrices arrive as new device tensors: every predict() reads them '
+                              'back and inverts on the host (two stream synchronisations).  Take the inverses on the host batch '
+                              'with pc_transform_model.add_camera_inverses(inputs) before moving it to the GPU (INTEGRATION.md A).')
             hit = (m, host_inverse(m), m.detach().clone())
             self._d[key] = hit
         return hit[1]

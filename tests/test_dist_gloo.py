@@ -78,6 +78,17 @@ def test_bench_gpus_2_starts_two_ranks():
     assert line['n_gpus'] == 2 and line['gather_ok'] is True and line['dry_run'] is True
 
 
+def test_bench_gpus_8_dry_run_starts_eight_ranks_and_gathers_eight_ways():
+    """BASELINE configs[4] has 8 ranks; no 8-GPU node has run it yet (SCALE_r0N.json: skipped).  The launcher, the rank
+    bookkeeping and the 8-way metric gather run here on gloo so that hardware is not the first place they run:
+    8 processes, every rank contributes a different accumulator, rank 0 checks count, order and sum."""
+    r, line = _run_bench('--gpus', '8', '--dry-run', env={'OMP_NUM_THREADS': '1'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['n_gpus'] == 8 and line['gather_ok'] is True and line['dry_run'] is True
+    assert len(line['per_rank_ms']) == 8 and len(set(line['devices'])) == 8
+    assert '8 rank(s)' in line['sharding']
+
+
 def test_bench_refuses_a_world_that_differs_from_gpus():
     """Launched with WORLD_SIZE=1 semantics but --gpus 2 in a launcher environment of another size: error, not a silent
     1-rank run."""

@@ -436,6 +436,44 @@ def test_predict_is_asynchronous_and_a_late_check_still_reruns():
     assert m.bg.range_reruns == n0 + 2
 
 
+def test_predict_under_inference_mode():
+    """Inference tensors have no version counter (`t._version` raises): `task: bg` settles such a forward before predict()
+    returns instead of stamping its inputs; `task: bg_forecast` re-runs from tensors it made itself and stays asynchronous.
+    Both give the oracle's result, flagged checkpoints included."""
+    import test_gpu_bg_forecast as t
+    import test_gpu_bg_model as tb
+    from oracle import hardnet_ref
+    from panoptic_forecasting_amd import synth
+    from panoptic_forecasting_amd.registry import build_model
+    h, w = 64, 128
+    for std in (15.0, 2e-4):                    # a normal checkpoint, and one whose every forward is flagged and re-run
+        sd = dict(tb._sd())
+        sd['depth_std'] = torch.tensor([std])
+        p = _bg_params(h, w, std)
+        p['task'] = 'bg'
+        p['model']['return_logits'] = False
+        m = build_model(p)
+        m.load_state_dict(sd)
+        frame = synth.make_bg_inputs(b=1, h=h, w=w, seed=3)
+        ref = hardnet_ref.bg_predict(sd, frame, final_size=(h, w))
+        scale = ref['orig_size_logits'].abs().max().item()
+        with torch.inference_mode():
+            inp = {k: v.clone().cuda() for k, v in frame.items()}
+            assert inp['seg'].is_inference()
+            out = m.predict(inp, None)
+            err = (out['orig_size_logits'].cpu() - ref['orig_size_logits']).abs().max().item()
+        assert err <= 1e-4 * (1.0 + scale), (std, err, scale)
+        assert m.range_reruns == (0 if std > 1 else 1)
+        f = build_model(_bg_params(h, w, std))
+        f.load_state_dict(sd)
+        finp = synth.make_inputs(b=1, h=h, w=w, seed=5, gap_len=3)
+        fref, _, _ = t.oracle_pipeline(sd, finp, h, w)
+        with torch.inference_mode():
+            fout = f.predict({k: v.clone().cuda() for k, v in finp.items()}, None)
+            ferr = (fout['orig_size_logits'].cpu() - fref['orig_size_logits']).abs().max().item()
+        assert ferr <= 1e-4 * (1.0 + fref['orig_size_logits'].abs().max().item()), (std, ferr)
+
+
 def test_late_rerun_refuses_inputs_refilled_in_place_and_sync_mode_is_safe():
     """`task: bg` reads the CALLER's tensors.  A flagged forward is re-run from them when its result is first touched; if the
     caller refilled them in place in between (a static input buffer), the re-run would put the newer frame's result into the
@@ -470,6 +508,14 @@ def test_late_rerun_refuses_inputs_refilled_in_place_and_sync_mode_is_safe():
         static[k].copy_(frames[1][k].cuda())            # the next frame lands in the same buffers before `out` was read
     with pytest.raises(pflib.PfError, match='modified in place'):
         out['seg']
+    # the failure belongs to THAT result: a later predict on the same model is not killed by it (its housekeeping settles older
+    # forwards without raising), and touching the failed result again raises again instead of handing out unchecked tensors
+    nxt = lazy.predict({k: v.clone() for k, v in static.items()}, None)
+    nxt['seg']
+    with pytest.raises(pflib.PfError, match='modified in place'):
+        out['orig_size_logits']
+    with pytest.raises(pflib.PfError, match='modified in place'):
+        dict(out)
 
     sync = model(range_check='sync')
     static = {k: v.clone().cuda() for k, v in frames[0].items()}

@@ -163,3 +163,30 @@ def test_paths_beside_the_fast_one_match_oracle(case):
         assert torch.equal(out['result2d'].cpu(), ref['result2d']), (case, ind)
         assert torch.equal(out['seg'].cpu(), ref['seg']), (case, ind)
         assert torch.equal(out['depth'].cpu().view(torch.int32), ref['depth'].view(torch.int32)), (case, ind)
+
+
+@pytest.mark.gpu
+def test_inverse_cache_finds_a_write_behind_the_version_counter_within_its_window():
+    """Device camera tensors are keyed on (storage, version); a write that bypasses the counter (`K.data`, a foreign kernel) is not
+    seen by the key.  Round 6: the first and then every `verify_every`-th hit compares contents (one synchronisation), so such a
+    write is found within the window instead of never; `verify=True` checks every hit; inference tensors are never cached."""
+    from panoptic_forecasting_amd.pc_transform_model import InverseCache
+    K = torch.tensor([[[2.0, 0.0, 1.0], [0.0, 4.0, 2.0], [0.0, 0.0, 1.0]]], device='cuda')
+    eye = torch.eye(3, device='cuda').expand(1, 3, 3)
+    c = InverseCache(verify=False, verify_every=3)
+    a = c(K)
+    assert c(K) is a                                   # hit 0: checked, equal
+    K.data.mul_(2.0)                                   # version counter untouched
+    assert c(K) is a and c(K) is a                     # hits 1, 2: inside the window (documented)
+    fresh = c(K)                                       # hit 3: compared, found stale, re-inverted
+    assert fresh is not a and torch.allclose(fresh @ K, eye, atol=1e-6)
+    strict = InverseCache(verify=True)
+    s0 = strict(K)
+    K.data.mul_(0.5)
+    s1 = strict(K)
+    assert s1 is not s0 and torch.allclose(s1 @ K, eye, atol=1e-6)
+    with torch.inference_mode():
+        Ki = K.clone()
+        assert Ki.is_inference()
+        i0 = c(Ki)
+        assert torch.allclose(i0 @ Ki, eye, atol=1e-6) and c(Ki) is not i0

@@ -233,3 +233,24 @@ def test_add_camera_inverses_gives_the_models_own_bits_and_leaves_device_batches
 def test_backend_description_single_process():
     from panoptic_forecasting_amd import dist as pfdist
     assert pfdist.backend_description() == 'single process'
+
+
+def test_tuned_tables_key_each_layer_to_one_resolution():
+    """conv_select.cpp::measured_geometry looks a layer (ks, cin, cout) up at the resolution it was MEASURED at: both shape tables
+    must hold every layer at exactly one (hout, wout)."""
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'panoptic-forecasting_amd', 'csrc')
+    row = re.compile(r'^\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), \{')
+    for name in ('conv_s4_tuned.inc', 'conv_tuned.inc'):
+        sizes, n = {}, 0
+        with open(os.path.join(csrc, name)) as f:
+            for line in f:
+                m = row.match(line)
+                if not m:
+                    continue
+                ks, cin, cout, h, w, b = map(int, m.groups())
+                sizes.setdefault((ks, cin, cout), set()).add((h, w))
+                n += 1
+        assert n > 50, name
+        dup = {k: v for k, v in sizes.items() if len(v) != 1}
+        assert not dup, (name, dup)

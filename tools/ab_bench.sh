@@ -11,7 +11,7 @@ OUT=gpurun_out/ab_$(date +%H%M%S).txt
 mkdir -p gpurun_out
 for i in $(seq 1 $RUNS); do
   for L in "${LIBS[@]}"; do
-    PF_LIBPFHIP=$PWD/$L PF_BENCH_KERNELS=1 python bench.py --batch 16 --streams 1 --steps 10 --warmup 3 --replays 1 --no-cpu-baseline --no-legs --profile-steps 3 "$@" \
+    PF_LIBPFHIP=$PWD/$L PF_BENCH_KERNELS=1 python bench.py --batch 16 --streams 1 --steps 10 --warmup 3 --replays 1 --no-cpu-baseline --no-legs --verbose --profile-steps 3 "$@" \
       > /tmp/ab_line.json 2> /tmp/ab_err.txt
     python - "$L" >> $OUT <<'PY'
 import json, sys

@@ -10,7 +10,7 @@ cp /tmp/table_a.inc $d/conv_s4_tuned.inc
 for i in 1 2; do
   for v in a b; do
     if [ $v = a ]; then unset PF_LIBPFHIP; else export PF_LIBPFHIP=/tmp/libpfhip_b.so; fi
-    python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+    python bench.py --verbose --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$v', round(d['value'],1), {k: round(v['value'],1) for k,v in d['by_batch'].items()})"
   done

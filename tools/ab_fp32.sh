@@ -5,7 +5,7 @@ RUNS=${1:-2}; shift
 OUT=gpurun_out/abf_$(date +%H%M%S).txt
 for i in $(seq 1 $RUNS); do
   for L in "$@"; do
-    PF_LIBPFHIP=$PWD/$L python bench.py --fp32-mfma-only --steps 10 --warmup 3 --no-legs --no-cpu-baseline --profile-steps 2 2>/dev/null | python -c "
+    PF_LIBPFHIP=$PWD/$L python bench.py --fp32-mfma-only --steps 10 --warmup 3 --no-legs --no-cpu-baseline --verbose --profile-steps 2 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('%-44s' % '$L'[-44:], round(d['value'],1), 'fps  convs', round(d['roofline']['step']['stages']['convs']['ms'],3), 'kernel sum', round(d['roofline']['kernel_ms_per_step'],3))" >> $OUT
   done

@@ -12,7 +12,7 @@ cp /tmp/table_a.inc $d/conv_s4_tuned.inc
 for i in $(seq $n); do
   for v in a b; do
     if [ $v = a ]; then unset PF_LIBPFHIP; else export PF_LIBPFHIP=/tmp/libpfhip_b.so; fi
-    python bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline --profile-steps 2 2>/dev/null | python -c "
+    python bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline --verbose --profile-steps 2 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$v', round(d['value'],1), 'convs', round(d['roofline']['step']['stages']['convs']['ms'],3), 'sum', round(d['roofline']['kernel_ms_per_step'],3))"
   done

@@ -3,7 +3,7 @@
 RUNS=${1:-3}; A=$2; B=$3; shift 3
 for i in $(seq 1 $RUNS); do
   for O in "$A" "$B"; do
-    PF_OPTS="$O" PF_BENCH_KERNELS=1 python bench.py --batch 16 --streams 1 --steps 10 --warmup 3 --replays 1 --no-cpu-baseline --no-legs --profile-steps 3 "$@" > /tmp/ab_line.json 2> /tmp/ab_err.txt
+    PF_OPTS="$O" PF_BENCH_KERNELS=1 python bench.py --batch 16 --streams 1 --steps 10 --warmup 3 --replays 1 --no-cpu-baseline --no-legs --verbose --profile-steps 3 "$@" > /tmp/ab_line.json 2> /tmp/ab_err.txt
     python - "$O" <<'PY'
 import json, sys
 d = json.load(open('/tmp/ab_line.json'))

@@ -6,7 +6,7 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --batch 32 --streams 1 --steps 4 --warmup 2 --replays 1 --no-cpu-baseline --no-legs --no-graph --profile-steps 1"
+BENCH="python $REPO/bench.py --batch 32 --streams 1 --steps 4 --warmup 2 --replays 1 --no-cpu-baseline --no-legs --no-graph --verbose --profile-steps 1"
 cd /tmp
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_lds" -o p -- $BENCH > "$OUT/bench.log" 2>"$OUT/err.log"
 rocprofv3 --pmc SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_lds2" -o p -- $BENCH > "$OUT/bench2.log" 2>"$OUT/err2.log"

@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 # one sub-batch (32 frames) on one stream: the launches bench.py times for its roofline line; the headline runs 2 of
 # these concurrently on 2 streams inside one hipGraph
-BENCH="python $REPO/bench.py --batch 32 --streams 1 --steps 10 --warmup 3 --replays 1 --no-cpu-baseline --no-legs --no-graph --profile-steps 1 $*"
+BENCH="python $REPO/bench.py --batch 32 --streams 1 --steps 10 --warmup 3 --replays 1 --no-cpu-baseline --no-legs --no-graph --verbose --profile-steps 1 $*"
 # another workload under the same passes (the training step: PF_PROFILE_CMD="python tools/bench_train.py --steps 5")
 if [ -n "${PF_PROFILE_CMD:-}" ]; then BENCH="${PF_PROFILE_CMD/tools\//$REPO/tools/}"; fi
 python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.source_sha())" > "$OUT/source_sha.txt" 2>/dev/null
