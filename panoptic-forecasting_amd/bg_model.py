@@ -23,7 +23,7 @@ from .pc_transform_model import _as_u8
 # params['model'] key -> option name of pf_hardnet_plan_set_option
 PLAN_OPTIONS = {'split_f16': 'split_f16', 'split_bf16': 'split_f16', 'fuse_pool': 'fuse_pool', 'fuse_upsample': 'fuse_upsample',
                 'use_tuned_table': 'use_tuned_table', 'valu_remainder': 'valu_remainder', 'conv_table_batch': 'table_batch',
-                'range_guard': 'range_guard', 'fuse_front': 'fuse_front'}
+                'range_guard': 'range_guard', 'fuse_front': 'fuse_front', 'fuse_pairs': 'fuse_pairs'}
 PF_STATUS_RANGE, PF_STATUS_RANGE_LOW = 1, 2          # include/pfhip.h
 PF_STATUS_ANY = PF_STATUS_RANGE | PF_STATUS_RANGE_LOW
 PF_WS_STATUS_BYTES = 2048

@@ -271,6 +271,33 @@ int s4_rounds(const S4Range *r, int n_src, int ks, int pad_sources);
 size_t s4_packed_floats(const S4Range *r, int n_src, int cout, int ks, int pad_sources);
 void pack_conv_weights_s4(const float *w_oihw, int cin, int cout, int ks, const S4Range *r, int n_src, int pad_sources, float *out);
 int launch_conv_s4(const ConvArgs &a, int ks, int nt, int wide, int B, hipStream_t stream);
+// the same with an explicit start of every range in the conv's input-channel numbering (cstart[j]; nullptr = the ranges are
+// consecutive): ranges may then be packed in ANOTHER order than the one they are concatenated in (conv_pair.hip)
+void pack_conv_weights_s4_ex(const float *w_oihw, int cin, int cout, int ks, const S4Range *r, const int *cstart, int n_src, int pad_sources, float *out);
+
+// conv_pair.hip: an odd HarDBlock layer P = conv3x3(S) computed inside its consumer C = conv3x3(P ++ S ++ others) (hardnet.py:177-194)
+struct PairArgs {
+    ConvArgs c;              // the consumer; sources in the K order [S, other ranges.., P's output] (the last one is never read from
+                             // memory: src_ent0 / nchunks describe it, its src pointer is unused), weights packed in that order with
+                             // pad_sources = 1 and P's range declared as {0, p_cout}
+    const float *p_wpk;      // P: pack_conv_weights_pair_p() of its single range: [tile][round][instr 0, instr 1] blocks ...
+    const float *p_w9;       // ... and the ninth tap [tile][round][term][64 lanes][4 fp16] (lane group 0 / 1 = the round's entries); bias zero padded
+    const float *p_bias;
+    float p_acc_scale;
+    float *p_dst;            // P's destination (packed pairs): its slice of the block's output tensor
+    int p_dst_c4, p_dst_choff, p_dst_limit, p_cout, p_cin, p_ntiles, p_relu;
+    unsigned *p_range_slot;  // max |v| of what P stored (range guard, low side); nullable
+    int rounds_s;            // rounds of S = P's rounds = C's first rounds
+    int round_d;             // C's first round over P's planes
+};
+bool conv_pair_supports(int c_cout, int p_cout);
+// conv_select.cpp: run this pair as one conv_pair launch?  mode = the plan's fuse_pairs option (1: where measured / modelled faster, 2: wherever possible)
+bool pair_wanted(int p_cin, int p_cout, int c_cin, int c_cout, int h, int w, int B, int mode);
+// P's weights (already scaled by 2^k like every split packing): `two` = [tile][round][2 blocks], `nine` = [tile][round][term][lane][4]
+size_t pair_p_two_floats(const S4Range &r, int cout);
+size_t pair_p_nine_floats(const S4Range &r, int cout);
+void pack_conv_weights_pair_p(const float *w_oihw, int cin, int cout, const S4Range &r, float *two, float *nine);
+int launch_conv_pair(const PairArgs &pa, int B, hipStream_t stream);
 // layout conversion (tests, tensor taps): fp32 NCHW <-> S4
 // status (nullable, device): PF_STATUS_RANGE is raised when an element exceeds what the pair represents (|x| > 65504)
 int launch_s4_pack(const float *src, void *dst, int B, int C, int H, int W, unsigned *status, hipStream_t stream);

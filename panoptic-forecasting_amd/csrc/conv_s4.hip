@@ -31,7 +31,7 @@
 #include <cstring>
 #include <vector>
 
-#include "conv_epilogue.h"
+#include "conv_s4.h"
 #include "pf_prof.h"
 
 #ifndef PF_PROBE
@@ -73,38 +73,6 @@
 
 namespace pf {
 
-typedef float s4_f32x4 __attribute__((ext_vector_type(4)));
-typedef split_x8 s4_h8;   // 8 / 4 fp16 terms (conv_mfma.h: split_terms2)
-typedef split_x4 s4_h4;
-typedef __attribute__((address_space(3))) void *s4_lds_ptr_t;
-[[maybe_unused]] constexpr unsigned kS4Oob = 0x80000000u;
-
-__device__ __forceinline__ s4_h8 s4_join(s4_h4 lo, s4_h4 hi) {
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-// group entry e of the conv's K order -> (source tensor frame base, byte offset of the hi plane of its group); all scalar
-__device__ __forceinline__ bool s4_entry(const ConvArgs &a, int e, int b, size_t plane_bytes, const char *&base, unsigned &goff,
-                                         unsigned &term_stride) {
-    const float *sp = a.src[0];
-    int c4 = a.src_c4[0], g0 = a.src_g0[0], gn = a.src_gn[0], e0 = 0;
-#pragma unroll
-    for (int k = 1; k < kConvMaxSrc; ++k) {
-        const bool take = k < a.n_src && e >= a.src_ent0[k];
-        sp = take ? a.src[k] : sp;
-        c4 = take ? a.src_c4[k] : c4;
-        g0 = take ? a.src_g0[k] : g0;
-        gn = take ? a.src_gn[k] : gn;
-        e0 = take ? a.src_ent0[k] : e0;
-    }
-    // entries past the groups of their range (round padding) have zero weights; the caller fetches nothing for them
-    // (out-of-range pieces land as zeros), the address stays inside the tensor anyway
-    base = reinterpret_cast<const char *>(sp) + (size_t)b * 2 * c4 * plane_bytes;
-    goff = (unsigned)(g0 + min(e - e0, gn - 1)) * (unsigned)plane_bytes;
-    term_stride = (unsigned)c4 * (unsigned)plane_bytes;
-    return e - e0 < gn;
-}
-
 // KS_ = 2 / 4 (the small levels, 64x128 and below at B = 16: a few hundred workgroups of 20-50 dependent rounds on 256 CUs):
 // KS_ wave groups per workgroup on the same pixel tile, each with its own stage ring; group k runs the k-th part of the rounds
 // (parts of a multiple of 4 rounds: the collected tap spans groups of 4); groups 1.. hand their sums over through LDS and
@@ -137,10 +105,6 @@ struct S4Cfg {
     static constexpr size_t LDS_BYTES = KS * STAGES_BYTES + NT * 16 * sizeof(float);   // + the bias values of the workgroup's couts
     static_assert(KS == 1 || (size_t)MP * NT * NW * 64 * 16 <= STAGES_BYTES, "the K-split hand-over uses group 1's stage ring");
 };
-
-// weight blocks in front of round r (2 per round + one collected-tap block per started group of 4 rounds before it)
-__host__ __device__ inline int s4_blocks_before(int r) { return 2 * r + r / 4; }
-__host__ __device__ inline int s4_blocks_total(int rounds) { return 2 * rounds + (rounds + 3) / 4; }
 
 template <int NT, int TW_, int TH_, int KS_>
 __global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ == 2) ? 2 : (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT == 3) ? 3 : 2) void conv_s4_kernel(ConvArgs a) {
@@ -970,12 +934,16 @@ size_t s4_packed_floats(const S4Range *r, int n_src, int cout, int ks, int pad_s
 // every 4th (and the last) round the collected-tap block]; instr blocks: g = tap, entries of the round; collected block:
 // g = round 4q + g of its group of four, tap (2,2)
 void pack_conv_weights_s4(const float *w, int cin, int cout, int ks, const S4Range *r, int n_src, int pad_sources, float *out_f) {
+    pack_conv_weights_s4_ex(w, cin, cout, ks, r, nullptr, n_src, pad_sources, out_f);
+}
+void pack_conv_weights_s4_ex(const float *w, int cin, int cout, int ks, const S4Range *r, const int *cstart, int n_src, int pad_sources, float *out_f) {
     unsigned short *out = reinterpret_cast<unsigned short *>(out_f);
     // entry -> (first conv input channel of the group's channel 0, may be negative; valid channel window)
     std::vector<int> ent_c0, ent_lo, ent_hi;
     const int per = ks == 3 ? 2 : 8;
     int c0 = 0;
     for (int j = 0; j < n_src; ++j) {
+        if (cstart) c0 = cstart[j];
         const int g0 = r[j].choff / 4, g1 = (r[j].choff + r[j].ch + 3) / 4;
         for (int g = g0; g < g1; ++g) {
             ent_c0.push_back(c0 + 4 * g - r[j].choff);

@@ -84,6 +84,22 @@ bool choose_s4(int ks, int cin, int cout, int hout, int wout, int B, ConvChoice 
     return true;
 }
 
+// conv_pair.hip (an odd HarDBlock layer inside its consumer) instead of two conv_s4 launches?  mode = plan option fuse_pairs: 0 never,
+// 2 wherever the kernel exists (tests, A/B runs), 1 (default) where it MEASURED faster (MI355X, 1024x2048 network, per pair, same box:
+// profiles/r06_experiments.md).  The fused form does 1.17-1.21x the matrix work of the two launches (the odd layer on 360 + 24 positions
+// per 256 pixels) for 0.68x their bytes, and both forms run at the same ~60 % of the matrix pipe's sustained rate - the pipe and the
+// LDS fragment reads bound them, not the DMA the fusion saves - so a full chip loses exactly the extra matrix work:
+//      pixels of the launch (B * H * W)   524 288+ (B >= 4 at 256x512)    131 072 (B = 1 at 256x512, B = 4 at 128x256)     32 768
+//      <2, 1> pairs (C <= 32, P <= 16)    1.06 - 1.31 x the two launches   0.84 - 0.96 x                                    0.97 - 1.15
+//      <3, 1> / <*, 2> pairs              1.3 - 2.8 x (register spills at 128 registers per lane)
+// It wins where the chip is NOT full: one launch of 512 eight-wave workgroups instead of two launches of 512 four-wave ones.
+bool pair_wanted(int p_cin, int p_cout, int c_cin, int c_cout, int h, int w, int B, int mode) {
+    if (mode >= 2) return true;
+    if (mode <= 0) return false;
+    const long px = (long)B * h * w;
+    return c_cout <= 32 && p_cout <= 16 && px >= 65536 && px <= 196608;
+}
+
 ConvChoice choose_conv(int ks, int stride, int cin, int cout, int hout, int wout, int B, int need, int use_tuned) {
     if (stride != 1) return ConvChoice{1, 0, 0, 0};           // conv_dma, shape by its cost model
     // The table was measured at B = 1, 2, 4, 8, 16 and (round 5, the strict-fp32 model at the headline's sub-batch) 32; a layer

@@ -39,6 +39,11 @@ struct ConvPlan {
     size_t front_off = 0; // conv_s4-style packing of a 3x3 STRIDE-2 conv with one input range (second conv of conv_front.hip), else 0
     bool has_front = false;
     float split_acc_scale = 1.0f;          // 2^-k: the split / S4 packings hold fp16 terms of w * 2^k (conv_mfma.h)
+    // conv_pair.hip, kept on the CONSUMER (op i; its producer is op i - 1): the consumer's weights in the K order [S, others, P] with
+    // every range padded to whole rounds, the producer's two-instruction stream and its ninth-tap stream
+    bool has_pair = false;
+    size_t pair_c_off = 0, pair_two_off = 0, pair_nine_off = 0;
+    int pair_rounds = 0;
 };
 
 struct pf_plan {
@@ -68,11 +73,13 @@ struct pf_plan {
     std::vector<uint8_t> feeds_conv;   // per tensor: a convolution reads it (directly or through pool / upsample ops)
     int opt_normalize = 1;
     int opt_tag_ops = 0;       // pf_profile_* records carry one label per op of the table (tools/)
+    int opt_fuse_pairs = 1;    // conv_pair.hip: an odd HarDBlock layer runs inside its consumer where both read / write packed pairs (0 = two launches)
 };
 
 namespace pf {
 int g_opt_fuse_pool = 1, g_opt_fuse_upsample = 1, g_opt_valu_rem = 1, g_opt_split = 1, g_opt_packed_acts = 1, g_opt_tag_ops = 0;
 int g_opt_range_guard = 1, g_opt_fuse_front = 1;   // fuse_front: conv_front.hip (0: stem -> conv_split -> conv_dma stride 2, three kernels)
+int g_opt_fuse_pairs = 1;  // fuse_pairs: conv_pair.hip (0: every layer a launch of its own)
 int g_opt_normalize = 1;   // normalize_ranges: per-channel power-of-two scaling of the stored activations, fixed at plan creation
 extern int g_opt_use_tuned;
 int g_opt_up_two_pass = 1;  // upsample_bwd_two_pass: the bilinear transposes of large planes as rows-then-columns passes (train_kernels.hip)
@@ -91,6 +98,7 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "range_guard")) g_opt_range_guard = value;
     else if (!strcmp(name, "fuse_front")) g_opt_fuse_front = value;
     else if (!strcmp(name, "normalize_ranges")) g_opt_normalize = value;
+    else if (!strcmp(name, "fuse_pairs")) g_opt_fuse_pairs = value;
     else if (!strcmp(name, "profile_tag_ops")) g_opt_tag_ops = value;
     else if (!strcmp(name, "train_side_stream")) g_opt_train_side = value;
     else if (!strcmp(name, "train_table_batch")) g_opt_train_table_batch = value < 0 ? 0 : value;
@@ -110,6 +118,7 @@ extern "C" int pf_hardnet_plan_set_option(pf_plan *p, const char *name, int valu
     else if (!strcmp(name, "range_guard")) p->opt_range_guard = value;
     else if (!strcmp(name, "fuse_front")) p->opt_fuse_front = value;
     else if (!strcmp(name, "table_batch")) p->opt_table_batch = value < 0 ? 0 : value;
+    else if (!strcmp(name, "fuse_pairs")) p->opt_fuse_pairs = value;
     else if (!strcmp(name, "profile_tag_ops")) p->opt_tag_ops = value;
     else return fail(PF_EINVAL, "pf_hardnet_plan_set_option: unknown option '%s'", name);
     return PF_OK;
@@ -120,6 +129,21 @@ namespace {
 struct Dims {
     int h = 0, w = 0;
 };
+
+// ops i (P) and i + 1 (C) form a pair conv_pair.hip can run as one launch: P = 3x3 conv of ONE range S, C = 3x3 conv whose first range
+// is exactly P's output and whose second range is exactly S (hardnet.py:177-194: the links of an even layer start with the odd layer
+// in front of it and contain that layer's input)
+bool is_conv_pair(const pf_plan *p, size_t i) {
+    if (i + 1 >= p->ops.size()) return false;
+    const BlobOp &P = p->ops[i], &C = p->ops[i + 1];
+    if (P.kind != OP_CONV || C.kind != OP_CONV || P.k != 3 || C.k != 3 || P.stride != 1 || C.stride != 1) return false;
+    if (P.n_src != 1 || C.n_src < 2 || (P.dst_choff & 1) || (C.dst_choff & 1)) return false;
+    if (C.src[0].tensor != P.dst || C.src[0].choff != P.dst_choff || C.src[0].ch != P.cout) return false;
+    if (C.src[1].tensor != P.src[0].tensor || C.src[1].choff != P.src[0].choff || C.src[1].ch != P.src[0].ch) return false;
+    for (uint32_t j = 0; j < C.n_src; ++j)
+        if (C.src[j].choff & 1) return false;
+    return conv_pair_supports((int)C.cout, (int)P.cout);
+}
 
 // Cityscapes id -> trainId (public label table; ids outside 0..33 -> 0, like the zeros_like init of
 // export_cityscapes_segmentation_results.py:34-38)
@@ -517,6 +541,73 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
             i += 2;
             continue;
         }
+        // ---- an odd HarDBlock layer inside its consumer (conv_pair.hip): decided in the REAL pass only - the dry pass recorded the two
+        //      launches as they would run alone, so the formats are what the unfused plan has, and any pair whose tensors did not all
+        //      end up as packed pairs simply runs as two launches
+        if (!dry && p->opt_fuse_pairs && is_conv_pair(p, i) && p->conv[i + 1].has_pair && (in.w & 3) == 0 && (g_conv_force.kind == 0 || g_conv_force.kind == 5) &&
+            rec_i + 1 < recs.size()) {
+            const BlobOp &C = p->ops[i + 1];
+            const ConvRec &rp = recs[rec_i], &rc_ = recs[rec_i + 1];
+            bool ok = rp.can_read && rc_.can_read && fmt[o.dst] && fmt[C.dst] && fmt[o.src[0].tensor];
+            for (uint32_t j = 1; j < C.n_src; ++j) ok = ok && fmt[C.src[j].tensor];
+            const int Bt = p->opt_table_batch > 0 ? p->opt_table_batch : B;
+            ok = ok && pair_wanted((int)o.cin, (int)o.cout, (int)C.cin, (int)C.cout, out.h, out.w, Bt, p->opt_fuse_pairs);
+            if (ok) {
+                PairArgs pa;
+                memset(&pa, 0, sizeof(pa));
+                ConvMeta mt;
+                fill_conv_args(C, i + 1, in, out, pa.c, mt);
+                ConvArgs &a = pa.c;
+                // K order [S, others.., P]: source j of the launch = source (j + 1) % n of the op
+                const int n = (int)C.n_src;
+                int e = 0;
+                for (int j = 0; j < n; ++j) {
+                    const BlobSrc &sj = C.src[(j + 1) % n];
+                    const bool isP = j == n - 1;
+                    a.src[j] = tptr(sj.tensor);
+                    a.src_ctotal[j] = (int)p->tensors[sj.tensor].channels;
+                    a.src_choff[j] = (int)sj.choff;
+                    a.src_c4[j] = (a.src_ctotal[j] + 3) / 4;
+                    a.src_g0[j] = isP ? 0 : (int)sj.choff / 4;
+                    a.src_gn[j] = isP ? ((int)sj.ch + 3) / 4 : ((int)sj.choff + (int)sj.ch + 3) / 4 - (int)sj.choff / 4;
+                    a.src_ent0[j] = e;
+                    e += (a.src_gn[j] + 1) / 2 * 2;
+                }
+                for (int j = n; j <= kConvMaxSrc; ++j) a.src_ent0[j] = e;
+                a.src_fmt = 1;
+                a.dst_fmt = 1;
+                a.dst_c4 = (a.dst_ctotal + 3) / 4;
+                a.dst_limit = rc_.dst_limit;
+                a.acc_scale = p->conv[i + 1].split_acc_scale;
+                a.wpk = p->dev_weights + p->conv[i + 1].pair_c_off;
+                a.nchunks = p->conv[i + 1].pair_rounds;
+                pa.p_wpk = p->dev_weights + p->conv[i + 1].pair_two_off;
+                pa.p_w9 = p->dev_weights + p->conv[i + 1].pair_nine_off;
+                pa.p_bias = p->dev_weights + p->conv[i].bias_off;
+                pa.p_acc_scale = p->conv[i].split_acc_scale;
+                pa.p_dst = tptr(o.dst);
+                pa.p_dst_c4 = ((int)p->tensors[o.dst].channels + 3) / 4;
+                pa.p_dst_choff = (int)o.dst_choff;
+                pa.p_dst_limit = rp.dst_limit;
+                pa.p_cout = (int)o.cout;
+                pa.p_cin = (int)o.cin;
+                pa.p_ntiles = ((int)o.cout + 15) / 16;
+                pa.p_relu = (int)o.relu;
+                pa.p_range_slot = slot_of(i, o.dst);
+                pa.rounds_s = a.src_ent0[1] / 2;
+                pa.round_d = a.src_ent0[n - 1] / 2;
+                if (tag_ops && prof_enabled()) {
+                    char tag[96];
+                    snprintf(tag, sizeof(tag), "%02zu+%02zu %s+%s %u->%u->%u %dx%d", i, i + 1, p->tensors[o.dst].name, p->tensors[C.dst].name, o.cin,
+                             o.cout, C.cout, out.h, out.w);
+                    prof_set_tag(tag);
+                }
+                if ((rc = launch_conv_pair(pa, B, s))) return rc;
+                rec_i += 2;
+                ++i;
+                continue;
+            }
+        }
         if (o.kind == OP_STEM && stem) {
             if (dry) { pin_fp32(o); continue; }
             StemArgs a = *stem;
@@ -777,6 +868,7 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
     p->opt_range_guard = g_opt_range_guard;
     p->opt_fuse_front = g_opt_fuse_front;
     p->opt_normalize = g_opt_normalize;
+    p->opt_fuse_pairs = g_opt_fuse_pairs;
     p->opt_tag_ops = g_opt_tag_ops;
     p->hdr = h;
     p->tensors.resize(h.n_tensors);
@@ -900,6 +992,39 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
                 host.resize(host.size() + s4_packed_floats(rg, (int)o.n_src, (int)o.cout, (int)o.k, c.s4_pad));
                 pack_conv_weights_s4(wsplit, (int)o.cin, (int)o.cout, (int)o.k, rg, (int)o.n_src, c.s4_pad, host.data() + c.s4_off);
             }
+        }
+        if (i > 0 && is_conv_pair(p, i - 1)) {
+            // conv_pair.hip: this op is the consumer C of the pair (P = op i - 1).  C's weights in the K order [S, others.., P], every
+            // range padded to whole rounds, P's range declared at channel 0 of its own planes; P's weights as two-instruction rounds + a
+            // ninth-tap stream (scaled by P's own 2^k)
+            const BlobOp &P = p->ops[i - 1];
+            const int n = (int)o.n_src;
+            S4Range rg[kMaxSrc];
+            int cstart[kMaxSrc], c0s[kMaxSrc], acc0 = 0;
+            for (int j = 0; j < n; ++j) { c0s[j] = acc0; acc0 += (int)o.src[j].ch; }
+            for (int j = 0; j < n; ++j) {
+                const int sj = (j + 1) % n;
+                rg[j] = sj == 0 ? S4Range{0, (int)o.src[0].ch} : S4Range{(int)o.src[sj].choff, (int)o.src[sj].ch};
+                cstart[j] = c0s[sj];
+            }
+            host.resize(align_up(host.size(), 16), 0.f);
+            c.pair_c_off = host.size();
+            c.pair_rounds = s4_rounds(rg, n, 3, 1);
+            host.resize(host.size() + s4_packed_floats(rg, n, (int)o.cout, 3, 1));
+            pack_conv_weights_s4_ex(wsplit, (int)o.cin, (int)o.cout, 3, rg, cstart, n, 1, host.data() + c.pair_c_off);
+            const size_t nwp = (size_t)P.cout * P.cin * 9;
+            const float scp = split_weight_scale(wts + P.w_off, nwp);
+            std::vector<float> wp(nwp);
+            for (size_t q = 0; q < nwp; ++q) wp[q] = wts[P.w_off + q] * scp;
+            const S4Range rs{(int)P.src[0].choff, (int)P.src[0].ch};
+            host.resize(align_up(host.size(), 16), 0.f);
+            c.pair_two_off = host.size();
+            host.resize(host.size() + pair_p_two_floats(rs, (int)P.cout));
+            host.resize(align_up(host.size(), 16), 0.f);
+            c.pair_nine_off = host.size();
+            host.resize(host.size() + pair_p_nine_floats(rs, (int)P.cout));
+            pack_conv_weights_pair_p(wp.data(), (int)P.cin, (int)P.cout, rs, host.data() + c.pair_two_off, host.data() + c.pair_nine_off);
+            c.has_pair = true;
         }
         if (o.k == 3 && o.stride == 2 && o.kind == OP_CONV && o.n_src == 1 && (o.src[0].choff & 3) == 0 && o.cout <= 32) {
             const S4Range rg{(int)o.src[0].choff, (int)o.src[0].ch};

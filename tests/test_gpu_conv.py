@@ -545,3 +545,97 @@ def test_packed_activations_off_is_fp32_layout(force_conv):
         r = ref[name].float()
         assert (net.tensor(name).cpu() - r).abs().max().item() <= 3 * _tol_split(r)
     net.close()
+
+
+def _pair_net(g, cin0, c_odd, c_even, deep):
+    """HarDBlock wiring (hardnet.py:177-194) with free channel counts: L1 = f(x0), L2 = f(L1 ++ x0), L3 = f(L2), L4 = f(L3 ++ L2 ++ x0)
+    and, `deep`, L5 = f(L4), L6 = f(L5 ++ L4), L7 = f(L6), L8 = f(L7 ++ L6 ++ L4 ++ x0); odd layers are slots of the block's
+    output tensor (offsets that are not multiples of 4), even layers tensors of their own, then a 3x3 conv over the output."""
+    from helpers import MiniSpec
+    from panoptic_forecasting_amd import hardnet_arch as arch
+    S = arch.Src
+    spec = MiniSpec(cin0)
+    c0 = 24
+    t0 = spec.conv('t0', [S(0, 0, cin0)], c0, 3)
+    n_odd = 4 if deep else 2
+    out_ch = n_odd * c_odd + c_even
+    out = spec.tensor('out', out_ch)
+    shapes = [('t0', cin0, c0)]
+    spec.conv('L1', [S(t0, 0, c0)], c_odd, 3, dst=out, dst_choff=0)
+    l2 = spec.conv('L2', [S(out, 0, c_odd), S(t0, 0, c0)], c_even, 3)
+    spec.conv('L3', [S(l2, 0, c_even)], c_odd, 3, dst=out, dst_choff=c_odd)
+    shapes += [('L1', c0, c_odd), ('L2', c_odd + c0, c_even), ('L3', c_even, c_odd)]
+    if not deep:
+        spec.conv('L4', [S(out, c_odd, c_odd), S(l2, 0, c_even), S(t0, 0, c0)], c_even, 3, dst=out, dst_choff=2 * c_odd)
+        shapes += [('L4', c_odd + c_even + c0, c_even)]
+    else:
+        l4 = spec.conv('L4', [S(out, c_odd, c_odd), S(l2, 0, c_even), S(t0, 0, c0)], c_even, 3)
+        spec.conv('L5', [S(l4, 0, c_even)], c_odd, 3, dst=out, dst_choff=2 * c_odd)
+        l6 = spec.conv('L6', [S(out, 2 * c_odd, c_odd), S(l4, 0, c_even)], c_even, 3)
+        spec.conv('L7', [S(l6, 0, c_even)], c_odd, 3, dst=out, dst_choff=3 * c_odd)
+        spec.conv('L8', [S(out, 3 * c_odd, c_odd), S(l6, 0, c_even), S(l4, 0, c_even), S(t0, 0, c0)], c_even, 3, dst=out, dst_choff=4 * c_odd)
+        shapes += [('L4', c_odd + c_even + c0, c_even), ('L5', c_even, c_odd), ('L6', c_odd + c_even, c_even), ('L7', c_even, c_odd),
+                   ('L8', c_odd + 2 * c_even + c0, c_even)]
+    spec.conv('fin', [S(out, 0, out_ch)], 9, 3, relu=False)
+    shapes += [('fin', out_ch, 9)]
+    P = {n: (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5, torch.randn(co, generator=g) * 0.5) for n, ci, co in shapes}
+    return spec, P
+
+
+def _pair_ref(x, P, deep):
+    D = {k: (v[0].double(), v[1].double()) for k, v in P.items()}
+    cv = lambda n, t: F.relu(F.conv2d(t, *D[n], padding=1))
+    t0 = cv('t0', x.double())
+    l1 = cv('L1', t0)
+    l2 = cv('L2', torch.cat([l1, t0], 1))
+    l3 = cv('L3', l2)
+    l4 = cv('L4', torch.cat([l3, l2, t0], 1))
+    if not deep:
+        out = torch.cat([l1, l3, l4], 1)
+        return {'L2': l2, 'out': out, 'fin': F.conv2d(out, *D['fin'], padding=1)}
+    l5 = cv('L5', l4)
+    l6 = cv('L6', torch.cat([l5, l4], 1))
+    l7 = cv('L7', l6)
+    l8 = cv('L8', torch.cat([l7, l6, l4, t0], 1))
+    out = torch.cat([l1, l3, l5, l7, l8], 1)
+    return {'L2': l2, 'L4': l4, 'L6': l6, 'out': out, 'fin': F.conv2d(out, *D['fin'], padding=1)}
+
+
+@pytest.mark.parametrize('c_odd,c_even,deep', [(10, 18, False), (10, 28, False), (16, 46, False), (18, 30, True), (24, 40, True), (6, 14, False), (32, 48, False)])
+@pytest.mark.parametrize('h,w,b', [(16, 64, 2), (21, 44, 1), (40, 100, 3)])
+def test_conv_pair_vs_float64_and_two_launches(c_odd, c_even, deep, h, w, b, force_conv):
+    """conv_pair.hip: an odd HarDBlock layer computed inside its consumer (one launch per pair: S staged once with a two-pixel halo,
+    P on the tile plus one halo pixel into LDS planes, zero outside the image, P's own pixels to its slot of the block output).  Every
+    cout-tile combination the kernel is built for (C: 1-3 tiles, P: 1-2), 4- and 8-layer blocks (2-4 source ranges), image sizes
+    with partial tiles and widths that are multiples of 4 only, batches: against float64 torch at the tolerance of the two-launch
+    path, and within 1e-5 (1 + max) of what that path (fuse_pairs = 0) stores."""
+    from helpers import MiniNet
+    from panoptic_forecasting_amd import lib as pflib
+    g = torch.Generator().manual_seed(h * 7 + w + c_even)
+    x = torch.randn(b, 12, h, w, generator=g) * torch.exp(0.5 * torch.randn(b, 12, 1, 1, generator=g))
+    spec, P = _pair_net(g, 12, c_odd, c_even, deep)
+    ref = _pair_ref(x, P, deep)
+    force_conv(5, 2, 0, 0)
+    got = {}
+    for fuse in (0, 2):
+        net = MiniNet(spec, P).set_option('fuse_pairs', fuse)
+        pflib.profile(True)
+        net.run(x.cuda())
+        labels = [r['label'] for r in pflib.profile_results()]
+        pflib.profile(False)
+        n_pair = sum('conv_pair_kernel' in l for l in labels)
+        assert n_pair == (0 if fuse == 0 else 1), labels      # (one label per kernel shape: the pairs of a block share theirs)
+        if fuse:
+            nt, ntp = (c_even + 15) // 16, (c_odd + 15) // 16
+            assert any('conv_pair_kernel<%d, %d>' % (nt, ntp) in l for l in labels), labels
+        got[fuse] = {k: net.tensor(k).cpu() for k in ref}
+        assert net.status() == 0
+        net.close()
+    for name, r in ref.items():
+        r = r.float()
+        scale = 3 if name in ('out', 'fin') else 2
+        for fuse in (0, 2):
+            err = (got[fuse][name] - r).abs().max().item()
+            assert err <= scale * _tol_split(r), (name, fuse, err, _tol_split(r))
+        d = (got[0][name] - got[2][name]).abs().max().item()
+        assert d <= 1e-5 * (1.0 + r.abs().max().item()), (name, d)
