@@ -76,7 +76,11 @@ typedef __attribute__((address_space(3))) void *dma_lds_ptr_t;
 // the s_nop's are the VALU-write -> permlane-swap-read wait states the compiler would insert.)
 #define PF_FMAC_QUAD(acc, w, x, C) \
     asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #C "," #C "," #C "," #C "] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(x))
-template <int KS, int STRIDE, int WM, int WK, int NT, int EPI, int RV>
+// KACC (training forward, ConvArgs::kacc): the sums of every round (8 input channels x the taps: 72 terms for a 3x3 conv) are
+// added into a second set of accumulators instead of running ONE fp32 chain over all 9 * Cin terms of an output - the blocked
+// summation ATen's CPU convolution does; round-off grows with sqrt(terms per block + blocks) instead of sqrt(terms)
+// (at 800x800 the unsplit chain was 1.2-1.5x as far from float64 as torch-CPU fp32; tools/train_fwd_error.py)
+template <int KS, int STRIDE, int WM, int WK, int NT, int EPI, int RV, int KACC = 0>
 __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtin types in the body; the host pass only needs the stub
     using C = DmaCfg<KS, STRIDE, WM, WK, NT, RV>;
@@ -100,6 +104,11 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
     for (int m = 0; m < C::MP; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 tot[KACC ? C::MP : 1][KACC ? NT : 1];
+#pragma unroll
+    for (int m = 0; m < (KACC ? C::MP : 1); ++m)
+#pragma unroll
+        for (int n = 0; n < (KACC ? NT : 1); ++n) tot[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int abase[C::MP];
 #pragma unroll
@@ -271,8 +280,23 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
                 }
             }
         }
+        if (KACC) {
+#pragma unroll
+            for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    tot[KACC ? m : 0][KACC ? n : 0] += acc[m][n];
+                    acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next round landed
         __syncthreads();                                    // ... and everyone is done with `cur`
+    }
+    if (KACC) {
+#pragma unroll
+        for (int m = 0; m < C::MP; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = tot[KACC ? m : 0][KACC ? n : 0];
     }
 
     DPROBE(1);
@@ -385,8 +409,11 @@ __global__ __launch_bounds__(64 * WM * WK) void conv_dma_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int KS, int STRIDE, int WM, int WK, int NT, int EPI, int RV = 0>
+template <int KS, int STRIDE, int WM, int WK, int NT, int EPI, int RV = 0, int KACC = 0>
 static int launch_dma_epi(const ConvArgs &a0, int B, hipStream_t s) {
+    if constexpr (KACC == 0 && EPI == 0 && RV == 0 && KS == 3) {
+        if (a0.kacc) return launch_dma_epi<KS, STRIDE, WM, WK, NT, EPI, RV, 1>(a0, B, s);
+    }
     using C = DmaCfg<KS, STRIDE, WM, WK, NT, RV>;
     ConvArgs a = a0;
     a.tilesX = (a.Wout + C::TW - 1) / C::TW;
@@ -401,19 +428,19 @@ static int launch_dma_epi(const ConvArgs &a0, int B, hipStream_t s) {
     }
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI, RV>),
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI, RV, KACC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
     char label[96];
-    snprintf(label, sizeof(label), "void pf::conv_dma_kernel<%d, %d, %d, %d, %d, %d, %d>(pf::ConvArgs)", KS, STRIDE, WM, WK, NT, EPI, RV);
+    snprintf(label, sizeof(label), KACC ? "void pf::conv_dma_kernel<%d, %d, %d, %d, %d, %d, %d, 1>(pf::ConvArgs)" : "void pf::conv_dma_kernel<%d, %d, %d, %d, %d, %d, %d>(pf::ConvArgs)", KS, STRIDE, WM, WK, NT, EPI, RV);
     if (a.res) strncat(label, " +res", sizeof(label) - strlen(label) - 1);
     if (a.pool) strncat(label, " +pool", sizeof(label) - strlen(label) - 1);
     if (a.no_bias) strncat(label, " lowres-half", sizeof(label) - strlen(label) - 1);
     const double px = (double)B * a.Hout * a.Wout;
     ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * KS * KS,
                  4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * KS * KS));
-    hipLaunchKernelGGL((conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI, RV>),
+    hipLaunchKernelGGL((conv_dma_kernel<KS, STRIDE, WM, WK, NT, EPI, RV, KACC>),
                        dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(64 * WM * WK), lds, s, a);
     PF_LAUNCH_CHECK("conv_dma_kernel");
     return PF_OK;

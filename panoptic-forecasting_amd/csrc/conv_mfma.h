@@ -45,6 +45,7 @@ struct ConvArgs {
     unsigned *status;        // range guard of the two-term operand split (below): word 0 of the forward's workspace, or
                              // nullptr (fp32-only plans, training): epilogues OR PF_STATUS_RANGE into it when they store |v| > 65504
     unsigned *range_slot;    // ... and keep max |v| of what this launch stored here (low side of the guard, below); nullable
+    int kacc;                // conv_dma 3x3 (training forward): per-round partial sums added into a second accumulator set (blocked summation)
     int accum;               // fp32 NCHW stores of conv_mfma.hip and of epi_store (conv_dma / conv_wave): dst += result (gradient
                              // accumulation of the training path); not combined with rem / pool / S4 destinations
     float acc_scale;         // split kernels (conv_split.hip, conv_s4.hip) only: their weights are packed as fp16 terms of

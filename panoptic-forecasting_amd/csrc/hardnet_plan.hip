@@ -84,6 +84,7 @@ int g_opt_normalize = 1;   // normalize_ranges: per-channel power-of-two scaling
 extern int g_opt_use_tuned;
 int g_opt_up_two_pass = 1;  // upsample_bwd_two_pass: the bilinear transposes of large planes as rows-then-columns passes (train_kernels.hip)
 int g_opt_train_table_batch = 0;   // train_table_batch: batch size the rows of train_tuned.inc are looked up with (0 = the call's own)
+int g_opt_train_kacc = 1;   // train_blocked_sum: per-round partial sums in the 3x3 convolutions of a training step (conv_dma.hip: KACC)
 int g_opt_train_side = 1;   // train_side_stream: weight gradients on the training plan's own stream (train_plan.hip)
 }
 
@@ -101,6 +102,7 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "fuse_pairs")) g_opt_fuse_pairs = value;
     else if (!strcmp(name, "profile_tag_ops")) g_opt_tag_ops = value;
     else if (!strcmp(name, "train_side_stream")) g_opt_train_side = value;
+    else if (!strcmp(name, "train_blocked_sum")) g_opt_train_kacc = value;
     else if (!strcmp(name, "train_table_batch")) g_opt_train_table_batch = value < 0 ? 0 : value;
     else if (!strcmp(name, "upsample_bwd_two_pass")) g_opt_up_two_pass = value;
     else return fail(PF_EINVAL, "pf_set_option: unknown option '%s'", name);

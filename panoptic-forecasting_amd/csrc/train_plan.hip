@@ -72,6 +72,7 @@ struct pf_train {
 };
 
 namespace pf {
+extern int g_opt_train_kacc;
 extern int g_opt_train_side, g_opt_use_tuned, g_opt_up_two_pass, g_opt_train_table_batch;
 }
 
@@ -89,7 +90,10 @@ const TrainTuned kTrainTuned[] = {
 
 // conv_dma with the measured shape for the geometry: this plan's own measurement (pf_train::autotune, measuring first if need
 // be), else the table's, else the cost model's
-int train_conv_dma(const pf_train *p, const ConvArgs &c, int ks, int stride, int B, hipStream_t s) {
+int train_conv_dma(const pf_train *p, const ConvArgs &c0, int ks, int stride, int B, hipStream_t s) {
+    // blocked summation in the 3x3 convolutions of a training step (conv_dma.hip: KACC; option train_blocked_sum, on)
+    ConvArgs c = c0;
+    c.kacc = (g_opt_train_kacc && ks == 3) ? 1 : 0;
     const std::array<int, 8> key{ks, stride, c.Cin, c.Cout, c.Hin, c.Win, B, c.accum};
     auto it = p->autotune ? p->tuned.find(key) : p->tuned.end();
     if (it == p->tuned.end() && !p->measuring) {

@@ -108,13 +108,14 @@ def test_fp32_mfma_only_option():
                          ids=['B1_split', 'B1_fp32', 'B2_split', 'B4_split', 'B8_split', 'B16_split', 'B16_fp32', 'B3_nearest_row',
                               'B16_mid_term', 'B2_mid_term', 'B32_headline_sub_batch', 'B32_fp32'])
 def test_full_size_timed_configuration_vs_oracle(b, split, term):
-    """Every configuration bench.py times (1024x2048; the B = 1, 2, 4, 8, 16 rows of csrc/conv_tuned.inc and
-    conv_s4_tuned.inc - headline sub-batches of 16 and the by_batch legs - split kernels on and off; `mid` = BASELINE
+    """Every configuration bench.py times (1024x2048; the B = 1, 2, 4, 8, 16, 32 rows of csrc/conv_tuned.inc and
+    conv_s4_tuned.inc - headline sub-batches of 32 and the by_batch legs, incl. the conv_pair launches B = 1 selects - split
+    kernels on and off; `mid` = BASELINE
     configs[2]: gap_len 9 with the predicted-odometry ego chain, pc_transform_dataset.py:156-186) against the oracle
     pipeline at its own size: logits of the first and the last frame of the batch, argmax agreement and bit-exact warped
     inputs.  The per-layer kernel choice is keyed on (shape, B), so the small-size tests above never execute these table
-    rows.  B=3 is not a measured batch size: it takes the rows of the nearest one (4); B=32 - the sub-batch of the round-5
-    headline (128 resident frames on 4 streams) - takes the B=16 rows."""
+    rows.  B=3 is not a measured batch size: it takes the rows of the nearest one (4); B=32 - the sub-batch of the
+    headline (128 resident frames on 4 streams) - has rows of its own (measured at 32)."""
     from panoptic_forecasting_amd import lib as pflib
     from panoptic_forecasting_amd import synth
     from panoptic_forecasting_amd.registry import build_model

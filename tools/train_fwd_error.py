@@ -26,6 +26,7 @@ ap.add_argument('--width', type=int, default=0)
 ap.add_argument('--batch', type=int, default=2)
 ap.add_argument('--table-batch', type=int, default=8)
 ap.add_argument('--use-table', type=int, default=1)
+ap.add_argument('--blocked', type=int, default=1, help='option train_blocked_sum: per-round partial sums in the 3x3 convolutions (round 6)')
 a = ap.parse_args()
 h, w, b = a.size, a.width or a.size, a.batch
 with open(os.path.join(ROOT, 'tests', 'golden', 'calib_seed1234.json')) as f:
@@ -55,6 +56,7 @@ t64, t32 = cpu_taps(torch.float64), cpu_taps(torch.float32)
 L = pflib.load()
 pflib.check(L.pf_set_option(b'train_table_batch', a.table_batch), 'opt')
 pflib.check(L.pf_set_option(b'use_tuned_table', a.use_table), 'opt')
+pflib.check(L.pf_set_option(b'train_blocked_sum', a.blocked), 'opt')
 params = {'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])]},
           'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True},
           'training': {'lr': 2e-3, 'mom': 0.9, 'wd': 1e-4, 'clip_grad_norm': 5.0}}
