@@ -150,12 +150,13 @@ def test_timed_configuration_800x800_vs_oracle():
     weight-gradient inputs.  pf_train_path_stats proves those forms and the table's rows ran (and no generic-kernel fallback).
     Criterion: the one of test_forward_backward_vs_oracle that is independent of this implementation - the distance to float64 of
     every gradient tensor RELATIVE to the distance of the reference's own fp32 (ATen) gradient of that tensor (or of ATen's median
-    tensor) - with the factor this size needs, 3 instead of 2, and why: the gradient error of this ReLU network follows the forward
-    pass's round-off (masks flip), and at 800x800 the HIP forward is 1.3-1.5x as far from float64 as torch-CPU fp32 is (base.4
-    8.8e-7 vs 7.1e-7, logits 2.5e-5 vs 1.7e-5 relative L2; 0.93x at 128x256 - tools/train_fwd_error.py, gpurun_out/r5c_fwd_err.txt):
-    large grids run the unsplit workgroup shapes, one fp32 FMA chain over all 9 * Cin terms per output, where small grids (and
-    ATen's blocked GEMM) add shorter partial chains.  Measured here: median tensor 1.7x ATen's distance, worst 2.95x
-    (8.9e-3 / 1.8e-2 against ATen's 5.2e-3 / 1.2e-2).  Loss 1e-4, head-level tensors 2e-4, running statistics as at the small sizes."""
+    tensor) - with the SAME factor as at the small sizes, 2.  Round 5 needed 3 here (worst tensor 2.95x): the gradient error of this
+    ReLU network follows the forward pass's round-off (masks flip), and at 800x800 the HIP forward was 1.2-1.5x as far from float64
+    as torch-CPU fp32 - large grids run the unsplit workgroup shapes, ONE fp32 FMA chain over all 9 * Cin terms per output, where
+    ATen's blocked GEMM adds shorter partial chains.  Round 6: the 3x3 convolutions of a training step add every round of 8 input
+    channels into a second accumulator set (conv_dma.hip KACC, option train_blocked_sum): the forward is now 0.79-0.95x ATen's
+    distance at every block output (tools/train_fwd_error.py, profiles/r06_experiments.md; +0.17 ms per step).
+    Loss 1e-4, head-level tensors 2e-4, running statistics as at the small sizes."""
     from panoptic_forecasting_amd import lib as pflib
     from panoptic_forecasting_amd.bg_train import BGTrainer
     h = w = 800
@@ -192,9 +193,11 @@ def test_timed_configuration_800x800_vs_oracle():
     _record_grad_distances('800x800', dist, aten)
     aten_med = sorted(aten.values())[len(aten) // 2]
     for k in g64:
-        assert dist[k] <= max(3.0 * max(aten[k], aten_med), 1e-4), (k, dist[k], aten[k], aten_med)
+        assert dist[k] <= max(2.0 * max(aten[k], aten_med), 1e-4), (k, dist[k], aten[k], aten_med)
     med = sorted(dist.values())[len(dist) // 2]
-    assert med <= 2.0 * aten_med, (med, aten_med)
+    assert med <= 1.5 * aten_med, (med, aten_med)
+    worst = max(dist[k] / max(aten[k], aten_med) for k in g64)
+    print('800x800 gradient distances: median %.2f x ATen median, worst tensor %.2f x' % (med / aten_med, worst))
     for k in ('model.finalConv.weight', 'model.finalConv.bias', 'model.denseBlocksUp.3.layers.3.norm.weight'):
         assert dist[k] <= 2e-4, (k, dist[k])
     post = tr.state_dict()

@@ -31,6 +31,9 @@ def main():
     a = ap.parse_args()
     if a.lib:
         pflib.LIB_PATH = os.path.abspath(a.lib)
+    for kv in filter(None, os.environ.get('PF_OPTS', '').split(',')):    # A/B runs: PF_OPTS=train_blocked_sum=0,...
+        k, v = kv.split('=')
+        pflib.check(pflib.load().pf_set_option(k.encode(), int(v)), 'pf_set_option')
     params = {'data': {'num_classes': 11, 'depth_norm_params': [torch.tensor([20.]), torch.tensor([15.])]},
               'model': {'num_inputs': 3, 'use_depth_inps': True, 'convert2onehot': True},
               'training': {'lr': 2e-3, 'mom': 0.9, 'wd': 1e-4, 'clip_grad_norm': 5.0, 'use_hip_graph': a.graph, 'weight_gradient_stream': not (a.graph or a.no_side_stream), 'autotune': a.autotune}}
