@@ -204,6 +204,17 @@ int pf_panoptic_encode(const void *seg, int seg_is_i64, int convert_to_ids, int 
 int pf_panoptic_max_ids(void);
 
 /* ------------------------------------------------------------------------------------------
+ * pf_bg_dense_input - the network input of BGModel.forward (models/bg/bg_model.py:61-69) for the configurations the fused stem
+ * of pf_bg_forward does not cover (convert2onehot = False, or no depth channels): writes x [B, T*C (+T), H, W] f32 for
+ * pf_hardnet_forward_dense.
+ *   frames   kind 0: labels u8 [B,T,H,W], kind 1: labels i64 [B,T,H,W] (one-hot over `channels` classes, labels >= channels ->
+ *            zero vector, :53-59), kind 2: f32 [B,T,channels,H,W] (copied: the reshape of :63-64)
+ *   depth    f32 [B,T,H,W] or NULL (use_depth_inps false); depth_mask u8 [B,T,H,W]: channel T*C + t = (depth - mean) / std * mask (:66-69)
+ */
+int pf_bg_dense_input(const void *frames, int kind, int channels, const float *depth, const uint8_t *depth_mask, float depth_mean,
+                      float depth_std, int B, int T, int H, int W, float *x, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Validation loss of the bg model (forward part) - replaces BGModel.loss (bg_model.py:73-89):
  * nn.CrossEntropyLoss(ignore_index) of the bilinearly upsampled (align_corners, hardnet.py:372-384) logits and the
  * accuracy counters, fused: the full-resolution logits are never materialised.

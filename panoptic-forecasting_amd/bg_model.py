@@ -476,17 +476,28 @@ class BGModel(BaseModel):
         return seg, logits, orig
 
     def _dense_input(self, inps, depths, depth_masks):
-        """bg_model.py:61-69 as device-side torch glue for the non-default configurations
-        (convert2onehot False, or no depth channels): builds [B, in_ch, H, W] f32."""
+        """bg_model.py:61-69 for the non-default configurations (convert2onehot False, or no depth channels): builds
+        [B, in_ch, H, W] f32 with ONE device call (``pf_bg_dense_input``; ATen glue until round 6)."""
+        L = _lib.load()
         if self.convert2onehot:
-            m = inps < self.num_classes
-            oh = F.one_hot(torch.where(m, inps, torch.zeros_like(inps)).long(), self.num_classes) * m.unsqueeze(-1)
-            inps = oh.permute(0, 1, 4, 2, 3).float()
-        b, t, c, h, w = inps.shape
-        x = inps.reshape(b, t * c, h, w).float()
+            b, t, h, w = inps.shape
+            if inps.dtype not in (torch.uint8, torch.int64):
+                inps = inps.long()
+            frames, kind, c = _lib.require_cuda(inps.contiguous(), 'seg'), int(inps.dtype == torch.int64), self.num_classes
+        else:
+            b, t, c, h, w = inps.shape
+            frames, kind = _lib.require_cuda(inps.float().contiguous(), 'seg'), 2
+        dptr = mptr = None
+        mean = std = 0.0
         if self.use_depth_inps:
-            d = (depths - self.depth_mean) / self.depth_std
-            x = torch.cat([x, d * depth_masks], dim=1)
+            depths = _lib.require_cuda(depths.float().contiguous(), 'depth')
+            mask = _lib.require_cuda(_as_u8(depth_masks), 'depth_mask')
+            dptr, mptr = depths.data_ptr(), mask.data_ptr()
+            self._get_plan()
+            mean, std = self._norm
+        x = torch.empty((b, t * c + (t if self.use_depth_inps else 0), h, w), dtype=torch.float32, device=inps.device)
+        _lib.check(L.pf_bg_dense_input(frames.data_ptr(), kind, c, dptr, mptr, mean, std, b, t, h, w, x.data_ptr(), _lib.stream_ptr()),
+                   'pf_bg_dense_input')
         return x
 
     # ---- reference surface ------------------------------------------------------------------

@@ -996,3 +996,45 @@ extern "C" int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, 
     return PF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ dense network input
+// bg_model.py:61-69 for the configurations the fused stem does not cover (convert2onehot = False: frames that are images or
+// already one-hot; or no depth channels): x[b, t * C + c] = frame channel c (labels: (label == c), labels >= n_cls -> zero
+// vector, :53-59), then - with depth - x[b, T * C + t] = (depth - mean) / std * mask (IEEE division, like ATen).  Round 6: was ATen glue.
+namespace pf {
+template <int KIND>   // 0: u8 labels, 1: i64 labels, 2: f32 frames [B][T][C][H][W]
+__global__ __launch_bounds__(256) void dense_input_kernel(const void *frames, int C, const float *depth, const uint8_t *mask, float mean,
+                                                          float stdv, int T, long long HW, float *x) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int bt = blockIdx.y, b = bt / T, t = bt - b * T;
+    if (i >= HW) return;
+    const int Cx = T * C + (depth ? T : 0);
+    float *xb = x + (long long)b * Cx * HW + i;
+    if (KIND == 2) {
+        const float *f = reinterpret_cast<const float *>(frames) + (long long)bt * C * HW + i;
+        for (int c = 0; c < C; ++c) xb[(long long)(t * C + c) * HW] = f[(long long)c * HW];
+    } else {
+        const long long in = (long long)bt * HW + i;
+        const long long lab = KIND == 1 ? reinterpret_cast<const long long *>(frames)[in] : (long long)reinterpret_cast<const uint8_t *>(frames)[in];
+        for (int c = 0; c < C; ++c) xb[(long long)(t * C + c) * HW] = (lab == c) ? 1.f : 0.f;
+    }
+    if (depth) {
+        const long long in = (long long)bt * HW + i;
+        xb[(long long)(T * C + t) * HW] = ((depth[in] - mean) / stdv) * (mask[in] ? 1.f : 0.f);
+    }
+}
+}  // namespace pf
+
+extern "C" int pf_bg_dense_input(const void *frames, int kind, int channels, const float *depth, const uint8_t *depth_mask, float depth_mean,
+                                 float depth_std, int B, int T, int H, int W, float *x, void *stream) {
+    if (!frames || !x || B <= 0 || T <= 0 || H <= 0 || W <= 0 || channels <= 0 || kind < 0 || kind > 2 || (depth && !depth_mask))
+        return pf::fail(PF_EINVAL, "pf_bg_dense_input: bad argument (kind %d, channels %d, B %d T %d %dx%d)", kind, channels, B, T, H, W);
+    const long long HW = (long long)H * W;
+    const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(B * T));
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == 0) hipLaunchKernelGGL(pf::dense_input_kernel<0>, grid, dim3(256), 0, s, frames, channels, depth, depth_mask, depth_mean, depth_std, T, HW, x);
+    else if (kind == 1) hipLaunchKernelGGL(pf::dense_input_kernel<1>, grid, dim3(256), 0, s, frames, channels, depth, depth_mask, depth_mean, depth_std, T, HW, x);
+    else hipLaunchKernelGGL(pf::dense_input_kernel<2>, grid, dim3(256), 0, s, frames, channels, depth, depth_mask, depth_mean, depth_std, T, HW, x);
+    PF_LAUNCH_CHECK("dense_input_kernel");
+    return PF_OK;
+}
+

@@ -41,6 +41,7 @@ SIGNATURES = {
                                _vp, _i, _vp, _sz, _vp]),
     'pf_panoptic_encode': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'pf_panoptic_max_ids': (_i, []),
+    'pf_bg_dense_input': (_i, [_vp, _i, _i, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp]),
     'pf_seg_loss_workspace': (_i, [_i, _i, _i, _c.POINTER(_sz)]),
     'pf_seg_loss': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'pf_train_create': (_i, [_vp, _sz, _i, _i, _c.POINTER(_vp)]),

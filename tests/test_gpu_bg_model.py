@@ -162,6 +162,38 @@ def test_dense_path_equals_fused_path():
     assert (d['seg'] == fused['seg']).float().mean() >= AGREE
 
 
+def test_dense_input_kernel_equals_the_references_arithmetic():
+    """pf_bg_dense_input = bg_model.py:53-69 (one-hot with labels >= n_cls -> zero vector, the reshape of dense frames, the
+    normalised + masked depth channels with an IEEE division): bit-exact against the oracle's torch restatement for u8 and i64
+    labels, for dense float frames, and without depth channels."""
+    import ctypes
+    from oracle import hardnet_ref
+    from panoptic_forecasting_amd import lib as pflib, synth
+    L = pflib.load()
+    h, w, b, t, n = 24, 40, 2, 3, 11
+    sd = _sd()
+    inp = synth.make_bg_inputs(b=b, h=h, w=w, seed=9)
+    seg = inp['seg'].clone()
+    seg[0, 1, :3, :5] = 255                                  # ignore labels -> zero vectors
+    want = hardnet_ref.bg_inputs_to_tensor(sd, seg, inp['depth'], inp['depth_mask'])      # [B, T * (n + 1), H, W]
+    mean, std = float(sd['depth_mean']), float(sd['depth_std'])
+    dep, msk = inp['depth'].cuda().contiguous(), inp['depth_mask'].cuda().view(torch.uint8).contiguous()
+
+    def run(frames, kind, c, with_depth):
+        x = torch.full((b, t * c + (t if with_depth else 0), h, w), float('nan'), device='cuda')
+        pflib.check(L.pf_bg_dense_input(frames.data_ptr(), kind, c, dep.data_ptr() if with_depth else None,
+                                        msk.data_ptr() if with_depth else None, mean, std, b, t, h, w, x.data_ptr(), pflib.stream_ptr()),
+                    'pf_bg_dense_input')
+        return x.cpu()
+    for frames, kind in ((seg.to(torch.uint8).cuda(), 0), (seg.long().cuda(), 1)):
+        assert torch.equal(run(frames, kind, n, True).view(torch.int32), want.view(torch.int32))
+        assert torch.equal(run(frames, kind, n, False), want[:, :t * n])
+    dense = want[:, :t * n].reshape(b, t, n, h, w).cuda().contiguous()
+    assert torch.equal(run(dense, 2, n, True).view(torch.int32), want.view(torch.int32))
+    x = torch.empty(1, device='cuda')
+    assert L.pf_bg_dense_input(dense.data_ptr(), 3, n, None, None, 0.0, 1.0, b, t, h, w, x.data_ptr(), pflib.stream_ptr()) == -1   # PF_EINVAL
+
+
 def test_cpu_inputs_fail_loudly():
     from panoptic_forecasting_amd import synth
     from panoptic_forecasting_amd.lib import PfError

@@ -19,11 +19,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=16)
 ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--margin', type=float, default=0.03, help='a challenger shape replaces the shape the current table runs only if it is this much faster (run-to-run noise is 1-3 %%)')
+ap.add_argument('--size', default='', help='HxW instead of 1024x2048: rows for a second image size (conv_select.cpp prefers rows measured at exactly the size asked for)')
 ap.add_argument('--emit', default=None, help='append the conv_s4 winners as C table rows to this .inc file')
 args = ap.parse_args()
 L = pflib.load()
 pflib.check(L.pf_set_option(b'profile_tag_ops', 1), 'pf_set_option')   # per-op labels in the profile records
-model = build_model(bench.model_params())
+if args.size:
+    bench.H, bench.W = [int(v) for v in args.size.lower().split('x')]
+model = build_model(bench.model_params(final_h=bench.H, final_w=bench.W))
 model.load_state_dict(bench.calibrated_state_dict())
 batch = bench.make_batch(args.batch, 0, torch.device('cuda'))
 CONFIGS = [(0, 0, 0, 0)] + [(5, nt, wd, 0) for nt in (1, 2, 3, 4) for wd in (0, 1)] + [(5, 1, 2, 0), (5, 2, 2, 0), (5, 1, 3, 0), (5, 2, 3, 0), (5, 1, 4, 0), (5, 2, 4, 0)]   # wd 2: 16x32 tiles, 8 waves; wd 3 / 4: 8x32 tiles, K split over two / four wave groups
@@ -78,8 +81,8 @@ print('conv total: auto %.1f us -> best of auto / s4 per layer %.1f us  (B=%d)' 
 
 if args.emit:
     with open(args.emit, 'a') as f:
-        f.write('    // B=%d: tools/tune_s4.py on MI355X, every eligible layer on conv_s4 (auto %.0f us -> best shapes %.0f us)\n'
-                % (args.batch, tot_auto, tot_best))
+        f.write('    // B=%d%s: tools/tune_s4.py on MI355X, every eligible layer on conv_s4 (auto %.0f us -> best shapes %.0f us)\n'
+                % (args.batch, (' at %dx%d' % (bench.H, bench.W)) if args.size else '', tot_auto, tot_best))
         seen = set()
         for tag, auto, kern, us in emit_rows:
             m = re.match(r'\d+[ab]? (\S+) (\d+)->(\d+) (\d+)x(\d+)', tag)
