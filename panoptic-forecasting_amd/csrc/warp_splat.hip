@@ -53,6 +53,12 @@ constexpr int kThreads = 256;
 // that its 32 KB z-buffer fixes at 4: waves hide that better than loads in flight per wave.  Same box, 16 frames:
 // 256 threads x 8 tiles in flight (4 waves per SIMD, 109 registers) 557 us; 512 x 4 at 4 waves 652; 512 x 4 at 5 waves (66
 // registers) 517; 512 x 2 at 8 waves (64 registers) 460-478; 512 x 3 at 8 waves 470; 512 x 1 at 8 waves 485.
+// invalid-point mark stores of bin_kernel (same-box A/B, 32 frames, profiles/r06_experiments.md): 0 = four unconditional byte stores
+// (rounds 1-5): 1138 / 1119 / 1138 us; 1 = only the distinct bins: 1088 / 1093 / 1095; 2 (shipped) = distinct bins, the two bins of a
+// row as one two-byte store: 1064 / 1071 / 1067 (-6 %).  Bit-exact either way (tests/test_gpu_warp_splat.py, test_gpu_pipeline.py)
+#ifndef PF_MARK_VARIANT
+#define PF_MARK_VARIANT 2
+#endif
 #ifndef PF_RASTER_THREADS
 #define PF_RASTER_THREADS 512
 #endif
@@ -403,10 +409,31 @@ __global__ __launch_bounds__(kThreads) void bin_kernel(SplatArgs a) {
                 // the uniform base: N < 2^30 is checked at launch)
                 const unsigned o00 = (unsigned)p.y0 * (unsigned)a.W + (unsigned)p.x0, dxo = (unsigned)(p.x1 - p.x0);
                 const unsigned o10 = (unsigned)p.y1 * (unsigned)a.W + (unsigned)p.x0;
+#if PF_MARK_VARIANT == 1
+                // A/B (profiles/r06_experiments.md): only the DISTINCT bins are marked - a point clamped to the image edge has
+                // x1 == x0 and / or y1 == y0 and stores once or twice instead of four times
+                mark[o00] = 1;
+                if (dxo) mark[o00 + 1] = 1;
+                if (o10 != o00) {
+                    mark[o10] = 1;
+                    if (dxo) mark[o10 + 1] = 1;
+                }
+#elif PF_MARK_VARIANT == 2
+                // the two bins of a row as ONE two-byte store where they differ (x1 = x0 + 1 <= W - 1: inside the row; the store may be
+                // unaligned - global memory takes that), a byte store where they do not; the second row only if it is another row
+                if (dxo) {
+                    __builtin_memcpy(mark + o00, "\1\1", 2);
+                    if (o10 != o00) __builtin_memcpy(mark + o10, "\1\1", 2);
+                } else {
+                    mark[o00] = 1;
+                    if (o10 != o00) mark[o10] = 1;
+                }
+#else
                 mark[o00] = 1;
                 mark[o10] = 1;
                 mark[o00 + dxo] = 1;
                 mark[o10 + dxo] = 1;
+#endif
             }
         }
         if ((a.W & 3) == 0) {   // the raster pass re-reads these instead of re-projecting (coalesced 32 B per thread)

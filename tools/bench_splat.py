@@ -28,7 +28,7 @@ def main():
     inp = bench.make_batch(a.batch, 100, dev, a.term)
     sp = WarpSplat()
     run = lambda: sp(inp['depth'], inp['depth_mask'], inp['seg'], inp['intrinsics'], inp['extrinsics'], inp['target_T'],
-                     Kinv=inp['intrinsics_inv'], Einv=inp['extrinsics_inv'], per_frame=True, want_result2d=False)
+                     Kinv=inp.get('intrinsics_inv'), Einv=inp.get('extrinsics_inv'), per_frame=True, want_result2d=False)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
