@@ -23,8 +23,8 @@ when the ranks that joined differ from ``--gpus`` or the node has fewer GPUs tha
 
 At N=1 the same line also carries (driver-timed, same process):
     by_batch   frames/s of ONE stream at B = 1, 2, 4 frames per step (SURVEY.md 8d Config 2; the reference loop batches 2): latency
-    by_batch_pipelined  the reference-shaped loop double-buffered (export_bg.py --pipeline_depth 2): B = 1, 2 per batch, two model
-               replicas on two streams, eager, fresh host-inverse camera tensors every batch
+    by_batch_pipelined  the reference-shaped loop with batches in flight (export_bg.py --pipeline_depth N): B = 1, 2 per batch, N = 2
+               and 3 model replicas on as many streams, eager, fresh host-inverse camera tensors every batch
     fresh_cameras  eager B = 2 / 16 with NEW camera tensors every step: inverses taken on the host batch vs read back by the model
     other_resolution  512x1024 at B = 16, one stream: the heuristic (untuned) kernel choice, frames/s + dominant-kernel fraction
     train_step  one bg training step at batch 8 of 800x800 (configs/bg/bg_train.yaml): ms, dominant kernel + its fraction of the fp32 matrix peak
@@ -470,7 +470,7 @@ def fresh_cameras_leg(sd, dev, term):
     return res
 
 
-def pipelined_leg(sd, dev, term, steps_by_b=((1, 480), (2, 360))):
+def pipelined_leg(sd, dev, term, steps_by_b=((1, 480), (2, 360)), depth=2):
     """the reference-shaped loop (export_cityscapes_segmentation_results.py:75-85: loader -> batch2gpu -> predict
     -> write) is a STREAM of batches, so it can be double-buffered without touching predict's contract: two model replicas on two
     HIP streams, batch k + 1 enqueued while batch k runs (what export_bg.py --pipeline_depth 2 does).  Eager launches, the big
@@ -481,7 +481,7 @@ def pipelined_leg(sd, dev, term, steps_by_b=((1, 480), (2, 360))):
     res = {}
     for b, steps in steps_by_b:
         models = []
-        for _ in range(2):
+        for _ in range(depth):
             m = build_model(model_params())
             m.load_state_dict(sd)
             m.eval()
@@ -490,15 +490,15 @@ def pipelined_leg(sd, dev, term, steps_by_b=((1, 480), (2, 360))):
                 for k in ('depth', 'depth_mask', 'seg') + cam_keys}
         big = {k: host[k].to(dev) for k in ('depth', 'depth_mask', 'seg')}
         cams_host = {k: host[k].pin_memory() for k in cam_keys}
-        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-        outs = [None, None]
+        streams = [torch.cuda.Stream() for _ in range(depth)]
+        outs = [None] * depth
 
         def run(n):
             cur = torch.cuda.current_stream()
             for st in streams:
                 st.wait_stream(cur)
             for k in range(n):
-                i = k & 1
+                i = k % depth
                 fresh = add_camera_inverses({kk: v.clone() for kk, v in cams_host.items()})
                 with torch.cuda.stream(streams[i]):
                     cams = {kk: v.pin_memory().to(dev, non_blocking=True) for kk, v in fresh.items()}
@@ -516,7 +516,7 @@ def pipelined_leg(sd, dev, term, steps_by_b=((1, 480), (2, 360))):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         res[str(b)] = {'value': b * steps / dt, 'unit': 'frames/s', 'ms_per_batch': 1e3 * dt / steps, 'steps': steps,
-                       'streams': 2, 'launch': 'eager', 'cameras': 'fresh, host inverses',
+                       'streams': depth, 'launch': 'eager', 'cameras': 'fresh, host inverses',
                        'reruns': sum(m.bg.range_reruns for m in models)}
         del models, big, outs
         torch.cuda.empty_cache()
@@ -890,6 +890,9 @@ def main():
             del leg
             torch.cuda.empty_cache()
         by_batch_pipelined = pipelined_leg(sd, dev, args.term)
+        deeper = pipelined_leg(sd, dev, args.term, depth=3)          # export_bg.py --pipeline_depth 3 (its default)
+        for k, v in deeper.items():
+            by_batch_pipelined[k + '_depth3'] = v
         reruns += sum(v['reruns'] for v in by_batch_pipelined.values())
         fresh_cameras = fresh_cameras_leg(sd, dev, args.term)
         if not args.fp32_mfma_only:
@@ -955,8 +958,8 @@ def main():
         if by_batch is not None:
             config['by_batch'] = ', '.join('B%s %.0f' % (k, v['value']) for k, v in by_batch.items()) + ' frames/s (1 stream, graph)'
         if by_batch_pipelined is not None:
-            config['by_batch_pipelined'] = ', '.join('B%s %.0f' % (k, v['value']) for k, v in by_batch_pipelined.items()) + \
-                ' frames/s (2 streams, eager, fresh cameras)'
+            config['by_batch_pipelined'] = ', '.join('B%s %.0f' % (k.replace('_depth3', ' (3 streams)'), v['value']) for k, v in by_batch_pipelined.items()) + \
+                ' frames/s (2 streams unless said, eager, fresh cameras)'
         if fresh_cameras is not None:
             config['fresh_cameras'] = '; '.join('B%s ' % k + ' / '.join('%.0f' % v[m_]['value'] for m_ in ('cached', 'host_inverses', 'device_cameras'))
                                                 for k, v in fresh_cameras.items()) + ' (cached / host inverses / device cameras)'

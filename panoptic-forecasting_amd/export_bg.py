@@ -50,7 +50,7 @@ EXTRA_FLAGS = (
     # not reference flags:
     ('--synthetic', dict(type=int, default=0, help='export N synthetic samples instead of a dataset')),
     ('--dataset', dict(default='reference', choices=['reference'])),
-    ('--pipeline_depth', dict(type=int, default=2, help='batches in flight: N model replicas on N HIP streams, batch k + 1 is enqueued '
+    ('--pipeline_depth', dict(type=int, default=3, help='batches in flight: N model replicas on N HIP streams, batch k + 1 is enqueued '
                                                         'before the files of batch k are written (1 = the plain serial loop)')),
     ('--dry_run', dict(action='store_true', help='with --synthetic: no model and no GPU - every rank writes a constant placeholder map '
                                                  'per sample of its shard (gloo rendezvous), then the barrier and the fill of missing frames '
@@ -142,7 +142,8 @@ def export_split(model, dataset, split, params, collate_fn):
     loader = torch.utils.data.DataLoader(dataset, batch_size=tr.get('batch_size', 2), collate_fn=collate_fn,
                                          num_workers=tr.get('num_data_workers', 0), pin_memory=False)
     written = []
-    # Round 6: the loop is a STREAM of batches, so it is double-buffered (--pipeline_depth N, default 2): replica k % N of the
+    # Round 6: the loop is a STREAM of batches, so several are kept in flight (--pipeline_depth N, default 3; measured at B = 1 / 2:
+    # one 970 / 1380, two 1300 / 1820, three 1495 / 2030, four 1575 / 2090 frames/s - tools/pipeline_depth.py): replica k % N of the
     # model enqueues batch k on its own HIP stream, and only then are the files of batch k - N + 1 written.  At the reference's
     # batch size (2) one forward leaves most of the chip idle (78 dependent launches of 5-30 us); the warp/splat + stem of the
     # next batch now run beside the network of the current one, and the host-side PNG encoding overlaps both.  predict()'s
