@@ -144,9 +144,9 @@ def test_full_size_timed_configuration_vs_oracle(b, split, term):
 
 
 @pytest.mark.parametrize('h,w,b,kw', [(512, 1024, 16, {}), (256, 512, 16, {}), (384, 768, 6, {}), (768, 1536, 3, {}),
-                                      (512, 1024, 16, {'split_f16': 0}), (384, 768, 6, {'split_f16': 0})],
+                                      (512, 1024, 16, {'split_f16': 0}), (384, 768, 6, {'split_f16': 0}), (520, 1040, 2, {})],
                          ids=['512x1024_B16_rows_of_B4', '256x512_B16_rows_of_B1', '384x768_B6_rows_of_B1', '768x1536_B3_rows_of_B2',
-                              '512x1024_B16_strict_fp32', '384x768_B6_strict_fp32'])
+                              '512x1024_B16_strict_fp32', '384x768_B6_strict_fp32', '520x1040_B2_widths_not_multiples_of_32'])
 def test_second_resolution_heuristic_kernel_choice_vs_oracle(h, w, b, kw):
     """Image sizes the kernel tables were not measured at; 512x1024, B = 16 is the configuration of bench.py's
     `other_resolution` leg.  No row of csrc/conv_s4_tuned.inc / conv_tuned.inc has these shapes: every layer's kernel comes from
@@ -154,7 +154,8 @@ def test_second_resolution_heuristic_kernel_choice_vs_oracle(h, w, b, kw):
     rows for 512x1024 at B = 16, B = 1 for 256x512 at 16 and 384x768 at 6 (0.84), B = 2 for 768x1536 at 3 (1.7) - else the
     cost model, the reuse-vs-occupancy rule and the `conv_split` / `conv_s4` defaults): that choice is held to the same 1e-4
     as the measured one, first and last frame of the batch, warped inputs bit-exact.  `strict_fp32`: the same with split_f16 = 0
-    (the fp32-MFMA families, i.e. the path a flagged forward is re-run on, under the same rule)."""
+    (the fp32-MFMA families, i.e. the path a flagged forward is re-run on, under the same rule).  520x1040: level widths 520 /
+    260 (multiples of 4, not of 32: partial 32-pixel tiles on the reused shapes) and 130 / 65 / 32 (the generic kernels)."""
     from panoptic_forecasting_amd import synth
     from panoptic_forecasting_amd.registry import build_model
     sd = _sd()
