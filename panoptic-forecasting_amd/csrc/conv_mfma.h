@@ -290,9 +290,14 @@ struct PairArgs {
     unsigned *p_range_slot;  // max |v| of what P stored (range guard, low side); nullable
     int rounds_s;            // rounds of S = P's rounds = C's first rounds
     int round_d;             // C's first round over P's planes
+    int merged;              // 1: c.wpk was packed from C's weights WITH P's weights in rows 4 .. 4 + p_cout - 1 of C's last cout tile
+                             // (columns of S only; each conv's own 2^k): P's values at the tile's own pixels come out of C's matrix
+                             // instructions, conv_pair computes P only on the halo ring.  Needs roundup4(C cout) + P cout <= 16 * tiles
 };
 bool conv_pair_supports(int c_cout, int p_cout);
-// conv_select.cpp: run this pair as one conv_pair launch?  mode = the plan's fuse_pairs option (1: where measured / modelled faster, 2: wherever possible)
+bool conv_pair_merged_supports(int c_cout, int p_cout);     // PairArgs::merged possible for these channel counts?
+// conv_select.cpp: run this pair as one conv_pair launch?  mode = the plan's fuse_pairs option (1: where measured / modelled faster, 2: wherever possible,
+// 3: wherever possible and never merged, 4: the merged pairs only)
 bool pair_wanted(int p_cin, int p_cout, int c_cin, int c_cout, int h, int w, int B, int mode);
 // P's weights (already scaled by 2^k like every split packing): `two` = [tile][round][2 blocks], `nine` = [tile][round][term][lane][4]
 size_t pair_p_two_floats(const S4Range &r, int cout);

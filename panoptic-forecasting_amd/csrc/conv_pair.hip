@@ -34,7 +34,7 @@
 
 namespace pf {
 
-template <int NT, int NTP>
+template <int NT, int NTP, int MERGED = 0>
 struct PairCfg {
     static constexpr int TW = 32, TH = 8, NW = 8, NTHR = 512, MP = 2;   // wave w: row w of the tile (2 M-tiles) + 3 of P's 23 M-tiles
     static constexpr int IW = TW + 4;                               // pixels per plane row (2-pixel apron: 16-B pieces)
@@ -51,7 +51,11 @@ struct PairCfg {
     static constexpr int NDENT = 4 * NTP;                           // derived entries (every one is written: couts past P's are zeros)
     static constexpr int DBUF = 2 * NDENT * DPLANE;                 // [term][entry]
     static constexpr int NPOS = IH_C * IW;                          // P positions of a tile
-    static constexpr int PM = ((NPOS + 15) / 16 + NW - 1) / NW;     // P's M-tiles per wave (6; the 24th covers positions past the plane)
+    // P's M-tiles per wave.  Plain: 23 linear M-tiles over all 360 positions, 3 per wave.  MERGED: the tile's OWN 256 positions come
+    // out of C's matrix instructions (P's couts ride in the zero-padded rows of C's last cout tile: see the kernel), only the halo
+    // ring - row 0, row 9 and columns 1 / 34 of rows 1..8: 84 positions = 6 M-tiles with per-lane positions - is computed here
+    static constexpr int PM = MERGED ? 1 : ((NPOS + 15) / 16 + NW - 1) / NW;
+    static constexpr int PWAVES = MERGED ? 6 : NW, NHALO = 84;
     static constexpr int PADF = 64, TAIL = 512;                     // the linear taps reach 8 B in front of / ~200 B behind the ring
     static constexpr int MAXR = 64;                                 // rounds that read memory (S + other ranges): the round table below
     static constexpr int OFF_A = PADF, OFF_W = OFF_A + 2 * ABUF + TAIL, OFF_D = OFF_W + 2 * WBUF, OFF_B = OFF_D + DBUF;
@@ -121,10 +125,10 @@ __device__ __forceinline__ void pair_store_px(const PairDst &d, int co, size_t p
 #endif
 }
 
-template <int NT, int NTP>
+template <int NT, int NTP, int MERGED>
 __global__ __launch_bounds__(512, 4) void conv_pair_kernel(PairArgs pa) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using C = PairCfg<NT, NTP>;
+    using C = PairCfg<NT, NTP, MERGED>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ConvArgs &a = pa.c;
     const int lane = threadIdx.x & 63, tid = threadIdx.x;
@@ -185,16 +189,25 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(PairArgs pa) {
     // the staged planes start one row higher (+ IW * 8).  P: linear positions, wave w owns positions [48 w, 48 w + 48)
     const int g = lane >> 4;
     int aoff[2], aoff_col, paoff[2], paoff9;
+    // P position of this lane's pixel in M-tile 0 of its wave (M-tile m of the plain form: + 16 m)
+    int q0 = wave * C::PM * 16 + (lane & 15);
+    bool phalo = true;          // MERGED: the lane's halo position exists (84 of 6 x 16)
+    if (MERGED) {
+        const int k = wave * 16 + (lane & 15);
+        phalo = k < C::NHALO;
+        const int s8 = k - 68;
+        q0 = k < 34 ? 1 + k : (k < 68 ? 9 * C::IW + 1 + (k - 34) : (phalo ? C::IW * (1 + (s8 >> 1)) + ((s8 & 1) ? C::TW + 2 : 1) : 0));
+    }
     {
         const int ky[2] = {g >> 1, g < 2 ? 2 : g - 2};
         const int kx[2] = {g & 1, g < 2 ? g : 2};
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             aoff[s] = ((wave + ky[s]) * C::IW + (lane & 15) + kx[s] + 1) * 8;
-            paoff[s] = (wave * C::PM * 16 + (lane & 15) + ky[s] * C::IW + kx[s] - 1) * 8;
+            paoff[s] = (q0 + ky[s] * C::IW + kx[s] - 1) * 8;
         }
         aoff_col = ((wave + 2) * C::IW + (lane & 15) + 2 + 1) * 8;
-        paoff9 = (wave * C::PM * 16 + (lane & 15) + 2 * C::IW + 2 - 1) * 8 + (g == 1 ? C::PLANE : 0);   // (groups 2, 3: any finite values, their weights are zero)
+        paoff9 = (q0 + 2 * C::IW + 2 - 1) * 8 + (g == 1 ? C::PLANE : 0);   // (groups 2, 3: any finite values, their weights are zero)
     }
 
     if (wave == 0) {   // bias values of both convs -> LDS (conv_s4.hip: kept in registers they cost spills and a wait on the stores)
@@ -305,7 +318,11 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(PairArgs pa) {
             if constexpr (slot == 3) { if (more) issue_part(R + 1, std::integral_constant<int, 1>()); }
         };
         auto no_tick = [](auto) {};
-        const bool flushC = (R & 3) == 3 || R == nrounds - 1;
+        // C's collected ninth tap is retired every fourth round and at the end - and, MERGED, after the last round of S: P's own
+        // pixels are read out of C's accumulators then, and need the (2,2) products of rounds 4q .. RS - 1 too.  The block used is the
+        // one of the group's regular flush round rf (its weights for rounds that have not been collected yet meet zeroed fragments)
+        const bool flushC = (R & 3) == 3 || R == nrounds - 1 || (MERGED && R == RS - 1);
+        const int rf = min(R | 3, nrounds - 1);
 
         // ---- C over this round's two entries: from the stage, or from P's planes in LDS
         {
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(PairArgs pa) {
             for (int n = 0; n < NT; ++n) {
                 // (buffer loads: scalar base + one lane offset; 64-bit lane pointers per block were spilled)
                 const bool real = n < a.ntiles;   // uniform
-                const unsigned so = (unsigned)((real ? n : 0) * nblocksC + s4_blocks_before(R) + 2) * C::WBLK;
+                const unsigned so = (unsigned)((real ? n : 0) * nblocksC + s4_blocks_before(rf) + 2) * C::WBLK;
                 cwh[n] = real ? __builtin_bit_cast(s4_h8, __builtin_amdgcn_raw_buffer_load_b128(wrsC, lane * 16, so, 0)) : zero8;
                 cwm[n] = real ? __builtin_bit_cast(s4_h8, __builtin_amdgcn_raw_buffer_load_b128(wrsC, lane * 16, so + 64 * 16, 0)) : zero8;
             }
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(PairArgs pa) {
         //      four rounds like C's (that costs 8 registers per M-tile across the whole phase; at 16 waves per CU there are 128): it is
         //      one K = 16 instruction per product and round - lane group 0 / 1 = the (2,2) tap of the round's first / second entry,
         //      groups 2 and 3 zero weights - with its weights straight from memory (L2) into 4 registers per cout tile
-        if constexpr (PH == 0) {
+        if (PH == 0 && wave < C::PWAVES) {      // (MERGED: six halo M-tiles, waves 6 and 7 have none)
             constexpr int ES = C::PLANE / 8, TS = 2 * C::PLANE / 8;
             s4_h4 w9h[NTP], w9m[NTP];
 #pragma unroll
@@ -429,15 +446,17 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(PairArgs pa) {
         pd.limit = pa.p_dst_limit;
         const float relu_lo = pa.p_relu ? 0.f : -__builtin_inff();
         float vmax = 0.f;
+        if (wave < C::PWAVES) {
 #pragma unroll
         for (int m = 0; m < C::PM; ++m) {
-            const int q = (wave * C::PM + m) * 16 + px;
+            const int q = q0 + m * 16;
             const int i = (q * 1821) >> 16, j = q - i * C::IW;       // q / 36 for q < 1024
             const int y = Y0 - 1 + i, x = X0 - 2 + j;
             // (columns 0 and 35 of a row were computed on the neighbouring rows' pixels: never read by C, kept out of the planes'
             //  numbers and of the range guard)
-            const bool inimg = q < C::NPOS && j >= 1 && j <= C::TW + 2 && y >= 0 && y < a.Hout && x >= 0 && x < a.Wout;
-            const bool own = inimg && i >= 1 && i <= C::TH && j >= 2 && j < 2 + C::TW;
+            const bool inplane = MERGED ? phalo : q < C::NPOS;
+            const bool inimg = inplane && j >= 1 && j <= C::TW + 2 && y >= 0 && y < a.Hout && x >= 0 && x < a.Wout;
+            const bool own = !MERGED && inimg && i >= 1 && i <= C::TH && j >= 2 && j < 2 + C::TW;
 #pragma unroll
             for (int n = 0; n < NTP; ++n) {
                 s4_f32x4 v = pacc[m][n] + pacc9[m][n];
@@ -445,7 +464,7 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(PairArgs pa) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = inimg ? fmaxf(v[r] * pa.p_acc_scale + b4[r], relu_lo) : 0.f;
                 vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
-                if (q < C::NPOS) {
+                if (inplane) {
                     s4_h4 hi, mid;
                     split_terms4(v, hi, mid);
                     unsigned char *dp = dbuf + (n * 4 + g) * C::DPLANE + q * 8;
@@ -454,6 +473,31 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(PairArgs pa) {
                 }
                 const int co = n * 16 + 4 * g;
                 if (own && co < pa.p_cout + 2) pair_store_px(pd, co, (size_t)y * a.Wout + x, v);
+            }
+        }
+        }
+        if (MERGED) {
+            // the tile's own pixels: P's couts were rows 4 .. 4 + p_cout - 1 of C's LAST cout tile during the rounds of S (their
+            // weights sit in the rows C pads with zeros, conv_mfma.h: PairArgs::merged), so lane group g >= 1 of that tile's
+            // accumulators holds P's couts 4 (g - 1) .. of the wave's two M-tiles; lane group 0 (C's own couts) zero-fills the
+            // plane entry no cout of P reaches (its consumer weights are zero, but 0 x stale LDS bits may be NaN)
+#pragma unroll
+            for (int m = 0; m < C::MP; ++m) {
+                const int oy = Y0 + wave, ox = X0 + m * 16 + px;
+                const int q = (wave + 1) * C::IW + m * 16 + px + 2;
+                const bool inimg = oy < a.Hout && ox < a.Wout;
+                s4_f32x4 v = acc[m][NT - 1];
+                const int pg = g > 0 ? g - 1 : 3;             // plane entry this lane writes
+                const s4_f32x4 b4 = *reinterpret_cast<const s4_f32x4 *>(bias_lds + NT * 16 + 4 * pg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (inimg && g > 0) ? fmaxf(v[r] * pa.p_acc_scale + b4[r], relu_lo) : 0.f;
+                vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
+                s4_h4 hi, mid;
+                split_terms4(v, hi, mid);
+                unsigned char *dp = dbuf + pg * C::DPLANE + q * 8;
+                *reinterpret_cast<s4_h4 *>(dp) = hi;
+                *reinterpret_cast<s4_h4 *>(dp + C::NDENT * C::DPLANE) = mid;
+                if (inimg && g > 0 && 4 * pg < pa.p_cout + 2) pair_store_px(pd, 4 * pg, (size_t)oy * a.Wout + ox, v);
             }
         }
 #if !(PAIR_DBG & 4)
@@ -498,31 +542,35 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(PairArgs pa) {
 #endif
 }
 
-template <int NT, int NTP>
+template <int NT, int NTP, int MERGED = 0>
 static int launch_pair_cfg(const PairArgs &pa0, int B, hipStream_t s) {
-    using C = PairCfg<NT, NTP>;
+    using C = PairCfg<NT, NTP, MERGED>;
     PairArgs pa = pa0;
     ConvArgs &a = pa.c;
     a.tilesX = (a.Wout + C::TW - 1) / C::TW;
     a.tilesY = (a.Hout + C::TH - 1) / C::TH;
     static bool attr_set = false;
     if (!attr_set) {
-        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pair_kernel<NT, NTP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pair_kernel<NT, NTP, MERGED>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::LDS_BYTES));
         attr_set = true;
     }
     char label[96];
-    snprintf(label, sizeof(label), "void pf::conv_pair_kernel<%d, %d>(pf::PairArgs)", NT, NTP);
+    snprintf(label, sizeof(label), "void pf::conv_pair_kernel<%d, %d, %d>(pf::PairArgs)", NT, NTP, MERGED);
     const double px = (double)B * a.Hout * a.Wout;
     const int cin_mem = a.Cin - pa.p_cout;                          // C's input channels that come from memory
     ProfScope ps(s, label, 2.0 * px * 9 * ((double)a.Cout * a.Cin + (double)pa.p_cout * pa.p_cin),
                  4.0 * (px * (cin_mem + a.Cout + pa.p_cout) + 9.0 * ((double)a.Cout * a.Cin + (double)pa.p_cout * pa.p_cin)));
-    hipLaunchKernelGGL((conv_pair_kernel<NT, NTP>), dim3(a.tilesX * a.tilesY, 1, B), dim3(C::NTHR), C::LDS_BYTES, s, pa);
+    hipLaunchKernelGGL((conv_pair_kernel<NT, NTP, MERGED>), dim3(a.tilesX * a.tilesY, 1, B), dim3(C::NTHR), C::LDS_BYTES, s, pa);
     PF_LAUNCH_CHECK("conv_pair_kernel");
     return PF_OK;
 }
 
 bool conv_pair_supports(int c_cout, int p_cout) { return c_cout <= 48 && p_cout <= 32; }
+// merged: built for two cout tiles of C, P in at most three lane groups of the second (the fourth plane entry is zero-filled by C's lanes)
+bool conv_pair_merged_supports(int c_cout, int p_cout) {
+    return c_cout > 16 && c_cout <= 32 && p_cout <= 12 && (c_cout + 3) / 4 * 4 - 16 == 4 && p_cout + 20 <= 32;
+}
 
 // ---- host side: P's weights.  `two`: blocks of [term 2][lane 64][8 fp16] as in pack_conv_weights_s4 (lane = cout n = lane & 15,
 // lane group g = tap of instr 0 / 1, the lane's 8 values = 4 channels of the round's two entries), two per round and tile, no
@@ -566,6 +614,10 @@ int launch_conv_pair(const PairArgs &pa, int B, hipStream_t s) {
     if (!conv_pair_supports(a.Cout, pa.p_cout)) return fail(PF_EUNSUPPORTED, "conv_pair: %d / %d output channels", a.Cout, pa.p_cout);
     if (pa.rounds_s < 1 || pa.round_d < pa.rounds_s || pa.round_d >= a.nchunks) return fail(PF_EINVAL, "conv_pair: round layout");
     const int nt = a.ntiles, ntp = pa.p_ntiles;
+    if (pa.merged) {
+        if (conv_pair_merged_supports(a.Cout, pa.p_cout)) return launch_pair_cfg<2, 1, 1>(pa, B, s);
+        return fail(PF_EUNSUPPORTED, "conv_pair (merged): built for C of 17..20 and P of <= 12 output channels");
+    }
 #define PF_PAIR(NT_, NTP_) \
     if (nt == NT_ && ntp == NTP_) return launch_pair_cfg<NT_, NTP_>(pa, B, s);
     PF_PAIR(1, 1) PF_PAIR(2, 1) PF_PAIR(3, 1) PF_PAIR(2, 2) PF_PAIR(3, 2)

@@ -94,6 +94,7 @@ bool choose_s4(int ks, int cin, int cout, int hout, int wout, int B, ConvChoice 
 //      <3, 1> / <*, 2> pairs              1.3 - 2.8 x (register spills at 128 registers per lane)
 // It wins where the chip is NOT full: one launch of 512 eight-wave workgroups instead of two launches of 512 four-wave ones.
 bool pair_wanted(int p_cin, int p_cout, int c_cin, int c_cout, int h, int w, int B, int mode) {
+    if (mode == 4) return conv_pair_merged_supports(c_cout, p_cout);
     if (mode >= 2) return true;
     if (mode <= 0) return false;
     const long px = (long)B * h * w;

@@ -44,6 +44,7 @@ struct ConvPlan {
     bool has_pair = false;
     size_t pair_c_off = 0, pair_two_off = 0, pair_nine_off = 0;
     int pair_rounds = 0;
+    bool pair_merged = false;              // pair_c_off carries P's weights in C's padding rows (conv_mfma.h: PairArgs::merged)
 };
 
 struct pf_plan {
@@ -85,6 +86,7 @@ extern int g_opt_use_tuned;
 int g_opt_up_two_pass = 1;  // upsample_bwd_two_pass: the bilinear transposes of large planes as rows-then-columns passes (train_kernels.hip)
 int g_opt_train_table_batch = 0;   // train_table_batch: batch size the rows of train_tuned.inc are looked up with (0 = the call's own)
 int g_opt_train_kacc = 1;   // train_blocked_sum: per-round partial sums in the 3x3 convolutions of a training step (conv_dma.hip: KACC)
+extern int g_opt_wgrad_taps;   // wgrad_taps (train_kernels.hip)
 int g_opt_train_side = 1;   // train_side_stream: weight gradients on the training plan's own stream (train_plan.hip)
 }
 
@@ -102,6 +104,7 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "fuse_pairs")) g_opt_fuse_pairs = value;
     else if (!strcmp(name, "profile_tag_ops")) g_opt_tag_ops = value;
     else if (!strcmp(name, "train_side_stream")) g_opt_train_side = value;
+    else if (!strcmp(name, "wgrad_taps")) g_opt_wgrad_taps = value;
     else if (!strcmp(name, "train_blocked_sum")) g_opt_train_kacc = value;
     else if (!strcmp(name, "train_table_batch")) g_opt_train_table_batch = value < 0 ? 0 : value;
     else if (!strcmp(name, "upsample_bwd_two_pass")) g_opt_up_two_pass = value;
@@ -598,6 +601,7 @@ int run_net(const pf_plan *p, const StemArgs *stem, const float *dense_x, int B,
                 pa.p_range_slot = slot_of(i, o.dst);
                 pa.rounds_s = a.src_ent0[1] / 2;
                 pa.round_d = a.src_ent0[n - 1] / 2;
+                pa.merged = p->conv[i + 1].pair_merged && p->opt_fuse_pairs != 3;
                 if (tag_ops && prof_enabled()) {
                     char tag[96];
                     snprintf(tag, sizeof(tag), "%02zu+%02zu %s+%s %u->%u->%u %dx%d", i, i + 1, p->tensors[o.dst].name, p->tensors[C.dst].name, o.cin,
@@ -1013,11 +1017,25 @@ extern "C" int pf_hardnet_plan_create(const void *blob, size_t bytes, int in_ch,
             c.pair_c_off = host.size();
             c.pair_rounds = s4_rounds(rg, n, 3, 1);
             host.resize(host.size() + s4_packed_floats(rg, n, (int)o.cout, 3, 1));
-            pack_conv_weights_s4_ex(wsplit, (int)o.cin, (int)o.cout, 3, rg, cstart, n, 1, host.data() + c.pair_c_off);
             const size_t nwp = (size_t)P.cout * P.cin * 9;
             const float scp = split_weight_scale(wts + P.w_off, nwp);
             std::vector<float> wp(nwp);
             for (size_t q = 0; q < nwp; ++q) wp[q] = wts[P.w_off + q] * scp;
+            c.pair_merged = conv_pair_merged_supports((int)o.cout, (int)P.cout);
+            if (c.pair_merged) {
+                // P's couts ride in the rows C's last cout tile pads with zeros (from the next multiple of four on), over the columns of
+                // S: C's matrix instructions over S then produce P at the tile's own pixels for nothing.  Harmless for the plain kernel
+                // (its epilogue never looks at those rows)
+                const int nt = ((int)o.cout + 15) / 16, row0 = ((int)o.cout + 3) / 4 * 4, cS = c0s[1 % n];
+                std::vector<float> waug((size_t)nt * 16 * o.cin * 9, 0.f);
+                std::copy(wsplit, wsplit + (size_t)o.cout * o.cin * 9, waug.begin());
+                for (int pc = 0; pc < (int)P.cout; ++pc)
+                    for (int ci = 0; ci < (int)P.cin; ++ci)
+                        for (int t = 0; t < 9; ++t) waug[((size_t)(row0 + pc) * o.cin + cS + ci) * 9 + t] = wp[((size_t)pc * P.cin + ci) * 9 + t];
+                pack_conv_weights_s4_ex(waug.data(), (int)o.cin, nt * 16, 3, rg, cstart, n, 1, host.data() + c.pair_c_off);
+            } else {
+                pack_conv_weights_s4_ex(wsplit, (int)o.cin, (int)o.cout, 3, rg, cstart, n, 1, host.data() + c.pair_c_off);
+            }
             const S4Range rs{(int)P.src[0].choff, (int)P.src[0].ch};
             host.resize(align_up(host.size(), 16), 0.f);
             c.pair_two_off = host.size();

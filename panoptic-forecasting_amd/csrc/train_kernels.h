@@ -44,6 +44,11 @@ int wgrad_slabs(int cout, int cin, int ks, int B, int Hout, int Win, int Wout);
 size_t wgrad_partial_floats(int cout, int cin, int ks, int B, int Hout, int Win, int Wout);
 // a: the forward conv's arguments (sources, Cin/Cout, Hin/Win/Hout/Wout); dw (OIHW) accumulates
 int launch_wgrad(const ConvArgs &a, int ks, int stride, const float *dy, int B, float *partial, float *dw, hipStream_t s);
+// wgrad_taps.hip: 3x3 stride-1 layers, the taps folded into the matrix rows; partial[slab][co_pad][ci_pad][9], *slabs_used <= max_slabs
+bool wgrad_taps_ok(int ks, int stride, int Hin, int Win, int Hout, int Wout);
+// mode = option wgrad_taps: 0 never, 2 wherever the kernel exists, 1 where it measured faster than wgrad_tiled_kernel
+bool wgrad_taps_wanted(int mode, int ks, int stride, int Cin, int Cout, int Hin, int Win, int Hout, int Wout);
+int launch_wgrad_taps(const ConvArgs &a, const float *dy, int B, int max_slabs, int co_pad, int ci_pad, float *partial, int *slabs_used, hipStream_t s);
 // odd-width convs on copies with a row pitch rounded up to 4 (train_kernels.hip): all input ranges of `a` -> [B][Cin][Hin][Wp];
 // [B][C][H][Wp] -> channels [dst_choff, dst_choff + C) of a [B][dst_ctotal][H][W] tensor
 int launch_pad_gather(const ConvArgs &a, int B, int Wp, float *dst, hipStream_t s);

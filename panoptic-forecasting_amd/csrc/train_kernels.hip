@@ -812,9 +812,24 @@ size_t wgrad_partial_floats(int cout, int cin, int ks, int B, int Hout, int Win,
     return (size_t)wgrad_slabs(cout, cin, ks, B, Hout, Win, Wout) * ((cout + 31) / 32 * 32) * ((cin + 15) / 16 * 16) * ks * ks;
 }
 
+int g_opt_wgrad_taps = 1;   // wgrad_taps: 3x3 stride-1 weight gradients with the taps folded into the matrix rows (wgrad_taps.hip)
+
 int launch_wgrad(const ConvArgs &a, int ks, int stride, const float *dy, int B, float *partial, float *dw, hipStream_t s) {
     int slabs = wgrad_slabs(a.Cout, a.Cin, ks, B, a.Hout, a.Win, a.Wout);
     const bool tiled = wgrad_tiled_ok(a.Win, a.Wout);
+    if (wgrad_taps_wanted(g_opt_wgrad_taps, ks, stride, a.Cin, a.Cout, a.Hin, a.Win, a.Hout, a.Wout)) {
+        const int co_pad = (a.Cout + 31) / 32 * 32, ci_pad = (a.Cin + 15) / 16 * 16;      // (what wgrad_partial_floats sized the buffer for)
+        const double flops = 2.0 * B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks;
+        {
+            ProfScope ps(s, "wgrad_taps_kernel", flops, 4.0 * B * ((double)a.Cout * a.Hout * a.Wout + (double)a.Cin * a.Hin * a.Win));
+            int rc = launch_wgrad_taps(a, dy, B, slabs, co_pad, ci_pad, partial, &slabs, s);
+            if (rc) return rc;
+        }
+        const long long total = (long long)a.Cout * a.Cin * ks * ks;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, partial, slabs, co_pad, ci_pad, ks * ks, a.Cout, a.Cin, dw);
+        PF_LAUNCH_CHECK("wgrad_reduce_kernel");
+        return PF_OK;
+    }
     const bool two_rows = tiled && ks == 3 && stride == 1;      // R = 2: half as many work items (the partial buffer is sized for R = 1)
     if (two_rows) {
         const long long items2 = (long long)B * ((a.Hout + 1) / 2) * ((a.Wout + 63) / 64);

@@ -777,6 +777,11 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
             }
             ConvArgs a;
             conv_args(o, in, out, a);
+            if (prof_enabled()) {      // per-layer rows of tools/bench_train.py --layers
+                char tag[64];
+                snprintf(tag, sizeof(tag), "%02d %u->%u k%u s%u %dx%d", (int)ii, o.cin, o.cout, o.k, o.stride, out.h, out.w);
+                prof_set_tag(tag);
+            }
             if (odd) {
                 // odd width: the tiled kernel on the padded copy of x the forward pass gathered (all ranges) and the padded dy; zero
                 // pad columns add nothing
@@ -789,6 +794,7 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
             } else if ((rc = launch_wgrad(a, (int)o.k, (int)o.stride, dy, B, wpart_l, grad + p->w_off[ii], sw))) {
                 return rc;
             }
+            if (prof_enabled()) prof_set_tag(nullptr);
             if (p->side) PF_HIP_CHECK(hipEventRecord(p->ev_wg[slot], sw));
             // dX per input range (the network input needs none)
             const float *dsrc = dy;

@@ -601,14 +601,17 @@ def _pair_ref(x, P, deep):
     return {'L2': l2, 'L4': l4, 'L6': l6, 'out': out, 'fin': F.conv2d(out, *D['fin'], padding=1)}
 
 
-@pytest.mark.parametrize('c_odd,c_even,deep', [(10, 18, False), (10, 28, False), (16, 46, False), (18, 30, True), (24, 40, True), (6, 14, False), (32, 48, False)])
+@pytest.mark.parametrize('c_odd,c_even,deep', [(10, 18, False), (10, 28, False), (16, 46, False), (18, 30, True), (24, 40, True), (6, 14, False), (32, 48, False),
+                                               (12, 20, True), (10, 17, False)])
 @pytest.mark.parametrize('h,w,b', [(16, 64, 2), (21, 44, 1), (40, 100, 3)])
 def test_conv_pair_vs_float64_and_two_launches(c_odd, c_even, deep, h, w, b, force_conv):
     """conv_pair.hip: an odd HarDBlock layer computed inside its consumer (one launch per pair: S staged once with a two-pixel halo,
     P on the tile plus one halo pixel into LDS planes, zero outside the image, P's own pixels to its slot of the block output).  Every
     cout-tile combination the kernel is built for (C: 1-3 tiles, P: 1-2), 4- and 8-layer blocks (2-4 source ranges), image sizes
     with partial tiles and widths that are multiples of 4 only, batches: against float64 torch at the tolerance of the two-launch
-    path, and within 1e-5 (1 + max) of what that path (fuse_pairs = 0) stores."""
+    path, and within 1e-5 (1 + max) of what that path (fuse_pairs = 0) stores.  Pairs of (<= 12) -> (17 .. 20) channels also run
+    MERGED (fuse_pairs = 2; 3 = never merged): P's weights ride in the rows C's second cout tile pads with zeros, so P at the
+    tile's own pixels comes out of C's matrix instructions and only the 84 halo positions are computed separately."""
     from helpers import MiniNet
     from panoptic_forecasting_amd import lib as pflib
     g = torch.Generator().manual_seed(h * 7 + w + c_even)
@@ -617,7 +620,9 @@ def test_conv_pair_vs_float64_and_two_launches(c_odd, c_even, deep, h, w, b, for
     ref = _pair_ref(x, P, deep)
     force_conv(5, 2, 0, 0)
     got = {}
-    for fuse in (0, 2):
+    merged = 16 < c_even <= 20 and c_odd <= 12
+    modes = (0, 2, 3) if merged else (0, 2)
+    for fuse in modes:
         net = MiniNet(spec, P).set_option('fuse_pairs', fuse)
         pflib.profile(True)
         net.run(x.cuda())
@@ -627,15 +632,16 @@ def test_conv_pair_vs_float64_and_two_launches(c_odd, c_even, deep, h, w, b, for
         assert n_pair == (0 if fuse == 0 else 1), labels      # (one label per kernel shape: the pairs of a block share theirs)
         if fuse:
             nt, ntp = (c_even + 15) // 16, (c_odd + 15) // 16
-            assert any('conv_pair_kernel<%d, %d>' % (nt, ntp) in l for l in labels), labels
+            assert any('conv_pair_kernel<%d, %d, %d>' % (nt, ntp, merged and fuse == 2) in l for l in labels), labels
         got[fuse] = {k: net.tensor(k).cpu() for k in ref}
         assert net.status() == 0
         net.close()
     for name, r in ref.items():
         r = r.float()
         scale = 3 if name in ('out', 'fin') else 2
-        for fuse in (0, 2):
+        for fuse in modes:
             err = (got[fuse][name] - r).abs().max().item()
             assert err <= scale * _tol_split(r), (name, fuse, err, _tol_split(r))
-        d = (got[0][name] - got[2][name]).abs().max().item()
-        assert d <= 1e-5 * (1.0 + r.abs().max().item()), (name, d)
+        for fuse in modes[1:]:
+            d = (got[0][name] - got[fuse][name]).abs().max().item()
+            assert d <= 1e-5 * (1.0 + r.abs().max().item()), (name, fuse, d)

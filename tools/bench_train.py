@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--autotune', action='store_true', help='training.autotune: measured conv shapes')
     ap.add_argument('--lib', default='', help='another build of libpfhip.so (A/B runs)')
     ap.add_argument('--out', default='', help='also write the JSON line here')
+    ap.add_argument('--layers', action='store_true', help='one row per weight-gradient launch (use with --no-side-stream: alone on the chip)')
     a = ap.parse_args()
     if a.lib:
         pflib.LIB_PATH = os.path.abspath(a.lib)
@@ -58,6 +59,20 @@ def main():
     recs = pflib.profile_results()
     pflib.profile(False)
     tr.use_graph = graph
+    if a.layers:
+        tot = 0.0
+        for r in recs:
+            if '@' in r['label'] and 'wgrad' in r['label'] and 'reduce' not in r['label']:
+                tot += r['ms']
+                print('%-60s %8.1f us %7.1f TF/s %7.0f GB/s' % (r['label'][-60:], r['ms'] * 1e3, r['flops'] / max(r['ms'], 1e-9) / 1e9, r['bytes'] / max(r['ms'], 1e-9) / 1e6))
+        print('weight-gradient kernels: %.3f ms' % tot)
+        recs = [dict(r, label=r['label'].split(' @')[0]) for r in recs]
+        agg = {}
+        for r in recs:
+            g = agg.setdefault(r['label'], dict(r, ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            for k in ('ms', 'launches', 'flops', 'bytes'):
+                g[k] += r[k]
+        recs = list(agg.values())
     top = sorted(recs, key=lambda r: -r['ms'])
     line = {'ms_per_step': ms, 'samples_per_s': a.batch / ms * 1e3, 'batch': a.batch, 'size': a.size, 'loss': float(out['loss']),
             'launch': 'hipGraph replay of forward + loss + backward, eager SGD step' if graph else ('eager, weight gradients on their own stream' if tr.side_stream else 'eager, one stream'), 'steps': a.steps,
