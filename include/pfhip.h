@@ -263,6 +263,19 @@ int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void 
  *   "train_table_batch" (default 0; process-wide only, read by pf_train_forward_backward) n > 0: the measured shape table of the
  *                   training step's convolutions (csrc/train_tuned.inc, keyed on the batch it was measured at) is consulted as if
  *                   the batch were n - the kernels of the timed configuration (n = 8) on a batch a CPU checker can afford;
+ *   "fuse_pairs"    (default 1) an odd HarDBlock layer computed INSIDE its consumer where both read / write packed pairs
+ *                   (csrc/conv_pair.hip: one launch per pair, the shared input staged once, the odd layer kept in LDS planes; the
+ *                   (<= 12) -> (17..20)-channel pairs in the MERGED form, the odd layer's weights in the rows the consumer's second
+ *                   cout tile pads with zeros): 1 = where it measured faster (launches of 65k-196k pixels), 0 = never, 2 = wherever
+ *                   the kernel exists, 3 = everywhere and never merged, 4 = the merged pairs only (A/B runs, tests); results agree
+ *                   with the two launches within 1e-5 (1 + max) (tests/test_gpu_conv.py);
+ *   "train_blocked_sum" (default 1; process-wide only) the 3x3 convolutions of a training step add every round of 8 input channels
+ *                   into a second accumulator set (blocked summation, like ATen's): forward activations 0.79-0.95 x as far from
+ *                   float64 as torch-CPU fp32; 0 = one fp32 chain over all 9 Cin terms;
+ *   "wgrad_taps"    (default 1; process-wide only) weight gradients of 3x3 stride-1 layers with the taps folded into the matrix rows
+ *                   (csrc/wgrad_taps.hip: rows = (cout, tap) pairs, 10 outputs fill 90 of 96 rows instead of 10 of 16): 1 = per layer
+ *                   where it measured faster, 0 = never (wgrad_tiled_kernel), 2 = wherever the kernel exists; same fixed-order
+ *                   partial sums either way (a step stays bit-reproducible), other rounding than the tiled kernel's;
  *   "valu_remainder" (default 1) trailing cout % 16 <= 8 channels of a conv_dma layer on the vector ALU. */
 int pf_set_option(const char *name, int value);
 /* The same options per plan: a plan copies the process-wide values when it is created; this call changes them for
