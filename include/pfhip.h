@@ -272,6 +272,12 @@ int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void 
  *   "train_blocked_sum" (default 1; process-wide only) the 3x3 convolutions of a training step add every round of 8 input channels
  *                   into a second accumulator set (blocked summation, like ATen's): forward activations 0.79-0.95 x as far from
  *                   float64 as torch-CPU fp32; 0 = one fp32 chain over all 9 Cin terms;
+ *   "train_forward_s4" (default 0; process-wide only, read by pf_train_create) 1 = the forward 3x3 stride-1 and 1x1 conv +
+ *                   BatchNorm layers of a training step run on the packed-pair kernels of the inference path (csrc/train_s4.hip:
+ *                   weights packed on the device every step with the fixed scale 2^12 - a weight of magnitude >= 16 becomes NaN,
+ *                   loudly - activations shadowed as fp16 pairs slice by slice, fp32 outputs): the step 14.45 -> 13.97 ms at batch 8
+ *                   of 800x800, the forward pass 1.0-1.2 x as far from float64 as torch-CPU fp32 instead of 0.9 x (one fp32 chain
+ *                   per output instead of blocked sums) - which is why it is off; 0 = conv_dma on the fp32 matrix instruction;
  *   "wgrad_taps"    (default 1; process-wide only) weight gradients of 3x3 stride-1 layers with the taps folded into the matrix rows
  *                   (csrc/wgrad_taps.hip: rows = (cout, tap) pairs, 10 outputs fill 90 of 96 rows instead of 10 of 16): 1 = per layer
  *                   where it measured faster, 0 = never (wgrad_tiled_kernel), 2 = wherever the kernel exists; same fixed-order
@@ -327,7 +333,8 @@ int pf_train_tuned_shapes(const pf_train *t, int *rows, int cap_rows, int *n_row
  * csrc/train_tuned.inc, [1] with the cost model's shape, [2] with a shape pf_train_autotune measured, [3] odd-width convolutions
  * run on row-padded copies (gather), [4] of those, forward conv + BatchNorm layers whose output stayed in padded rows, [5]
  * odd-width layers whose input gradients came from ONE backward-data conv over all ranges, [6] launches of the generic
- * (register-staged) kernel.  *n = 7 values available, at most cap are written.  (Tests: the timed configuration's kernels ran.) */
+ * (register-staged) kernel, [7] forward convolutions run on the packed-pair kernels (option "train_forward_s4").  *n = 8 values
+ * available, at most cap are written.  (Tests: the timed configuration's kernels ran.) */
 int pf_train_path_stats(const pf_train *t, int *stats, int cap, int *n);
 int pf_train_param_count(const pf_train *t, size_t *n_floats);
 int pf_train_param_layout(const pf_train *t, int op_index, size_t *w_off, size_t *aux_off, int *has_bn);

@@ -87,6 +87,7 @@ int g_opt_up_two_pass = 1;  // upsample_bwd_two_pass: the bilinear transposes of
 int g_opt_train_table_batch = 0;   // train_table_batch: batch size the rows of train_tuned.inc are looked up with (0 = the call's own)
 int g_opt_train_kacc = 1;   // train_blocked_sum: per-round partial sums in the 3x3 convolutions of a training step (conv_dma.hip: KACC)
 extern int g_opt_wgrad_taps;   // wgrad_taps (train_kernels.hip)
+int g_opt_train_s4 = 0;         // train_forward_s4: the forward convolutions of a training step on conv_s4 (train_s4.hip); off: 1.2x instead of 0.9x ATen's distance to float64
 int g_opt_train_side = 1;   // train_side_stream: weight gradients on the training plan's own stream (train_plan.hip)
 }
 
@@ -105,6 +106,7 @@ extern "C" int pf_set_option(const char *name, int value) {
     else if (!strcmp(name, "profile_tag_ops")) g_opt_tag_ops = value;
     else if (!strcmp(name, "train_side_stream")) g_opt_train_side = value;
     else if (!strcmp(name, "wgrad_taps")) g_opt_wgrad_taps = value;
+    else if (!strcmp(name, "train_forward_s4")) g_opt_train_s4 = value;
     else if (!strcmp(name, "train_blocked_sum")) g_opt_train_kacc = value;
     else if (!strcmp(name, "train_table_batch")) g_opt_train_table_batch = value < 0 ? 0 : value;
     else if (!strcmp(name, "upsample_bwd_two_pass")) g_opt_up_two_pass = value;

@@ -60,6 +60,7 @@ struct pf_train {
     // hipEvents) instead of taken from the inference path's cost model, which was calibrated on 1024x2048 batches.  Off by default:
     // the choice (and with it the summation order of K-split shapes) then depends on timing, i.e. may differ from run to run.
     int autotune = 0;
+    int fwd_s4 = 0;                       // option "train_forward_s4" when the plan was created: forward convolutions on conv_s4 (train_s4.hip)
     mutable std::map<std::array<int, 8>, std::pair<int, int>> tuned;   // (ks, stride, Cin, Cout, Hin, Win, B, accum) -> (wm, nt)
     mutable hipEvent_t tune_ev[2] = {nullptr, nullptr};
     // the measurements run in a pass of their own in front of the first real pass of a configuration (B, H, W, out_h, out_w):
@@ -74,6 +75,7 @@ struct pf_train {
 namespace pf {
 extern int g_opt_train_kacc;
 extern int g_opt_train_side, g_opt_use_tuned, g_opt_up_two_pass, g_opt_train_table_batch;
+extern int g_opt_train_s4;      // train_forward_s4: the forward convolutions of a step on the packed-pair kernels (train_s4.hip)
 }
 
 namespace {
@@ -246,7 +248,23 @@ struct TLayout {
     std::vector<std::vector<int>> bwd_job;     // per op, per input range: its backward-data job, or -1 (the network input needs none)
     std::vector<int> bwd_all_job;              // per op of an odd-width level: ONE backward-data conv over all input ranges, or -1
     size_t wpk_arena = 0;
+    // forward pass on the packed-pair kernels (train_s4.hip): per tensor its shadow, per op its device-side weight packing
+    std::vector<size_t> s4act;
+    std::vector<int> s4_job;
+    std::vector<S4WJob> s4jobs;
+    size_t s4w_arena = 0;
 };
+
+// may op i's forward convolution run on conv_s4?  conv + BatchNorm, 3x3 / 1x1, stride 1, every input range at an even channel of a
+// tensor some op produced (the network input stays dense fp32: the stem reads it)
+bool s4_fwd_ok(const pf_train *p, size_t i) {
+    const BlobOp &o = p->ops[i];
+    if (!p->fwd_s4 || o.kind != OP_CONV || !p->bn[i] || o.stride != 1 || (o.k != 1 && o.k != 3) || o.n_src > (uint32_t)kConvMaxSrc) return false;
+    const uint32_t input = p->ops[0].src[0].tensor;
+    for (uint32_t j = 0; j < o.n_src; ++j)
+        if ((o.src[j].choff & 1) || o.src[j].tensor == input) return false;
+    return true;
+}
 
 TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_h, int out_w) {
     TLayout L;
@@ -352,6 +370,31 @@ TLayout t_layout(const pf_train *p, int B, const std::vector<TDims> &d, int out_
         }
         L.wpk_arena = take(arena * sizeof(float) + 256);
     }
+    // the forward convolutions that run on the packed-pair kernels: their device-side weight packings, and the shadows of the tensors they read
+    {
+        L.s4act.assign(nt, (size_t)-1);
+        L.s4_job.assign(p->ops.size(), -1);
+        std::vector<char> need(nt, 0);
+        size_t arena = 0;
+        for (size_t i = 0; i < p->ops.size(); ++i) {
+            if (!s4_fwd_ok(p, i)) continue;
+            const BlobOp &o = p->ops[i];
+            S4Range rg[kConvMaxSrc];
+            for (uint32_t j = 0; j < o.n_src; ++j) {
+                rg[j] = S4Range{(int)o.src[j].choff, (int)o.src[j].ch};
+                need[o.src[j].tensor] = 1;
+            }
+            S4WJob jb;
+            const size_t fl = s4_wjob_init(jb, p->w_off[i], (int)o.cin, (int)o.cout, (int)o.k, rg, (int)o.n_src, o.k == 1 && o.n_src == 2);
+            jb.out_off = (unsigned)arena;
+            arena += align_up(fl, 64);
+            L.s4_job[i] = (int)L.s4jobs.size();
+            L.s4jobs.push_back(jb);
+        }
+        for (size_t t = 0; t < nt; ++t)
+            if (need[t] && d[t].h) L.s4act[t] = take((size_t)B * 2 * ((p->tensors[t].channels + 3) / 4) * d[t].h * ((d[t].w + 3) / 4 * 4) * 8);
+        L.s4w_arena = take(arena * sizeof(float) + 256);
+    }
     if (p->autotune) L.tune_grad = take(p->n_params * sizeof(float));
     L.dy = take(max_dy + 256);
     if (p->side) {
@@ -434,6 +477,7 @@ extern "C" int pf_train_create(const void *blob, size_t bytes, int in_ch, int n_
         delete p;
         return fail(PF_EHIP, "pf_train_create: device allocation failed");
     }
+    p->fwd_s4 = g_opt_train_s4;
     if (g_opt_train_side) {
         int lo = 0, hi = 0;
         bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
@@ -493,8 +537,8 @@ extern "C" int pf_train_tuned_shapes(const pf_train *p, int *rows, int cap_rows,
 
 extern "C" int pf_train_path_stats(const pf_train *p, int *stats, int cap, int *n) {
     if (!p || !n || (cap > 0 && !stats)) return fail(PF_EINVAL, "pf_train_path_stats: null argument");
-    *n = 7;
-    for (int k = 0; k < 7 && k < cap; ++k) stats[k] = p->stats[k];
+    *n = 8;
+    for (int k = 0; k < 8 && k < cap; ++k) stats[k] = p->stats[k];
     return PF_OK;
 }
 
@@ -602,6 +646,21 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
     }
     float *wpk_arena = reinterpret_cast<float *>(wsb + L.wpk_arena);
     if ((rc = launch_pack_weights_batch(theta, wpk_arena, L.jobs.data(), (int)L.jobs.size(), s))) return rc;   // theta does not move inside this call
+    float *s4w_arena = reinterpret_cast<float *>(wsb + L.s4w_arena);
+    if (!L.s4jobs.empty() && (rc = launch_s4_pack_weights_dev(theta, s4w_arena, L.s4jobs.data(), (int)L.s4jobs.size(), kS4TrainWeightScale, s))) return rc;
+    // the packed-pair shadow of channels [c0, c1) of tensor t, for the convolutions that read it through conv_s4
+    // (a slice that starts or ends in the middle of a 4-channel group also zero-fills the group's other half while no producer has
+    //  written it in this pass: a reader of this slice multiplies those channels by zero weights, and 0 x a stale NaN pattern is NaN)
+    std::vector<std::vector<char>> s4_written(p->tensors.size());
+    auto shadow = [&](uint32_t t, int c0, int c1) -> int {
+        if (L.s4act[t] == (size_t)-1) return PF_OK;
+        const int ct = (int)p->tensors[t].channels;
+        std::vector<char> &wr = s4_written[t];
+        if (wr.empty()) wr.assign((size_t)ct + 4, 0);
+        const int fill_lo = (c0 & 2) && !wr[c0 - 2], fill_up = (c1 & 3) == 2 && c1 < ct && !wr[c1];
+        for (int c = c0; c < c1; ++c) wr[c] = 1;
+        return launch_s4_pack_act(act(t), B, ct, c0, c1, fill_lo, fill_up, d[t].h, d[t].w, (d[t].w + 3) / 4 * 4, wsb + L.s4act[t], s);
+    };
     const GradFirst gfirst = grad_first_writers(p, d);      // (no cleared gradient arena: first writers store)
     for (const auto &c : gfirst.clear)
         if ((rc = launch_zero_channels(gradt((uint32_t)c[0]), B, (int)p->tensors[c[0]].channels, c[1], c[2], (long long)d[c[0]].h * d[c[0]].w, s))) return rc;
@@ -699,10 +758,49 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
                 float *y = reinterpret_cast<float *>(wsb + L.ypre[i]);
                 a.dst = y; a.dst_ctotal = (int)o.cout; a.dst_choff = 0; a.relu = 0;
                 const bool odd_f = (in.w & 3) != 0 && o.stride == 1;
+                if (L.s4_job[i] >= 0) {
+                    // train_s4.hip: conv_s4 on the shadows of the input ranges; y in fp32 (rows padded to 4 on an odd-width level,
+                    // as the tiled fp32 path leaves them).  The weight gradient of an odd-width layer still reads the gathered,
+                    // row-padded fp32 copy of x
+                    const S4WJob &jb = L.s4jobs[L.s4_job[i]];
+                    const int Wp = (in.w + 3) / 4 * 4, per = o.k == 3 ? 2 : 8;
+                    if (odd_f) {
+                        if ((rc = launch_pad_gather(a, B, Wp, gather_to, s))) return rc;
+                        ++p->stats[3];
+                        ++p->stats[4];
+                    }
+                    ConvArgs c = a;
+                    int e = 0;
+                    for (int j = 0; j < c.n_src; ++j) {
+                        const int ch0 = (int)o.src[j].choff, chn = (int)o.src[j].ch;
+                        c.src[j] = reinterpret_cast<const float *>(wsb + L.s4act[o.src[j].tensor]);
+                        c.src_c4[j] = (c.src_ctotal[j] + 3) / 4;
+                        c.src_g0[j] = ch0 / 4;
+                        c.src_gn[j] = (ch0 + chn + 3) / 4 - ch0 / 4;
+                        c.src_ent0[j] = e;
+                        e += jb.pad ? (c.src_gn[j] + per - 1) / per * per : c.src_gn[j];
+                    }
+                    for (int j = c.n_src; j <= kConvMaxSrc; ++j) c.src_ent0[j] = e;
+                    c.src_fmt = 1;
+                    c.dst_fmt = 0;
+                    c.src_begin = 0;
+                    c.Win = Wp; c.Wout = Wp;
+                    c.acc_scale = 1.0f / kS4TrainWeightScale;
+                    c.wpk = s4w_arena + jb.out_off;
+                    c.nchunks = jb.rounds;
+                    c.chunk_begin = 0;
+                    c.chunk_end = jb.rounds;
+                    ConvChoice ch4;
+                    int nt4 = c.ntiles == 3 ? 3 : (c.ntiles < 2 ? 1 : 2), wide4 = 0;
+                    if (g_opt_use_tuned && choose_s4((int)o.k, c.Cin, c.Cout, c.Hout, c.Wout, B, &ch4) && ch4.kind == 5) { nt4 = ch4.p0; wide4 = ch4.p1; }
+                    if ((rc = launch_conv_s4(c, (int)o.k, nt4, wide4, B, s))) return rc;
+                    ++p->stats[7];
+                } else {
                 keep_padded = odd_f;
                 rc = run_conv(a, (int)o.k, (int)o.stride, theta + p->w_off[i], (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, 0, 0, 0, L.fwd_job[i]);
                 keep_padded = false;
                 if (rc) return rc;
+                }
                 float *aux = theta + p->aux_off[i];
                 float *stat = reinterpret_cast<float *>(wsb + L.stat[i]);
                 if ((rc = launch_bn_forward(y, B, (int)o.cout, out.h, out.w, bn_eps, bn_momentum, aux, aux + o.cout,
@@ -710,15 +808,19 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
                                             stat, stat + o.cout, bnpart, act(o.dst), (int)p->tensors[o.dst].channels, (int)o.dst_choff,
                                             (int)o.relu, odd_f ? (out.w + 3) / 4 * 4 : 0, s)))
                     return rc;
+                if ((rc = shadow(o.dst, (int)o.dst_choff, (int)o.dst_choff + (int)o.cout))) return rc;
             } else {
                 a.bias = theta + p->aux_off[i];
                 a.dst = act(o.dst); a.dst_ctotal = (int)p->tensors[o.dst].channels; a.dst_choff = (int)o.dst_choff; a.relu = (int)o.relu;
                 if ((rc = run_conv(a, (int)o.k, (int)o.stride, theta + p->w_off[i], (int)o.cin, (int)o.cout, src_ch, (int)o.n_src, 0, 0, 0, L.fwd_job[i]))) return rc;
+                if ((rc = shadow(o.dst, (int)o.dst_choff, (int)o.dst_choff + (int)o.cout))) return rc;
             }
         } else if (o.kind == OP_POOL) {
             if ((rc = launch_avgpool2(act(o.src[0].tensor), act(o.dst), B * (int)o.cin, in.h, in.w, nullptr, nullptr, s))) return rc;
+            if ((rc = shadow(o.dst, 0, (int)p->tensors[o.dst].channels))) return rc;
         } else if (o.kind == OP_UPSAMPLE) {
             if ((rc = launch_upsample(act(o.src[0].tensor), act(o.dst), B * (int)o.cin, in.h, in.w, out.h, out.w, nullptr, nullptr, s))) return rc;
+            if ((rc = shadow(o.dst, 0, (int)p->tensors[o.dst].channels))) return rc;
         } else if (o.kind == OP_HEAD) {
             if ((rc = launch_ce_fwd_bwd(act(o.src[0].tensor), B, (int)o.cin, in.h, in.w, labels, labels_i64, out_h, out_w, ignore_index, dfull,
                                         cepart, loss3, s)))

@@ -175,7 +175,7 @@ def test_timed_configuration_800x800_vs_oracle():
     finally:
         L.pf_set_option(b'train_table_batch', 0)
     print('training path at 800x800:', stats)
-    assert stats['table_shapes'] >= 60, stats                 # rows of csrc/train_tuned.inc (73 of the step's 126 geometries have one)
+    assert stats['table_shapes'] + stats['packed_pair_forward_convs'] >= 60, stats   # rows of csrc/train_tuned.inc (73 of the step's 126 geometries have one) or conv_s4 (forward)
     assert stats['padded_output_layers'] >= 20, stats         # conv + BatchNorm layers of the 50- / 25-pixel levels, forward
     assert stats['single_backward_data_convs'] >= 20, stats   # ... and their input gradients, one conv per layer
     assert stats['generic_kernel_launches'] == 0, stats
@@ -506,6 +506,48 @@ def test_mini_network_training_step_vs_autograd(size, taps):
         _mini_network_step(size)
     finally:
         pflib.load().pf_set_option(b'wgrad_taps', 1)
+
+
+@pytest.mark.parametrize('size', [(24, 40), (34, 70)])
+def test_mini_network_forward_on_packed_pairs_vs_autograd(size):
+    """Option train_forward_s4 (csrc/train_s4.hip, off by default): the forward conv + BatchNorm layers of a step on the inference
+    path's packed-pair kernels - weights packed on the device every step, activation slices shadowed as fp16 pairs (a slice that
+    starts at channel 10 of a tensor shares a 4-channel group with its neighbour), rows padded to 4 on the odd widths - against
+    float64 autograd at the bars of the fp32 step."""
+    from panoptic_forecasting_amd import lib as pflib
+    pflib.check(pflib.load().pf_set_option(b'train_forward_s4', 1), 'pf_set_option')
+    try:
+        _mini_network_step(size)
+    finally:
+        pflib.load().pf_set_option(b'train_forward_s4', 0)
+
+
+def test_forward_on_packed_pairs_is_the_same_step_to_rounding():
+    """The real network, fixture batch: with train_forward_s4 the 67 stride-1 conv + BatchNorm layers run on conv_s4 (path statistics),
+    the loss agrees to 1e-6, the gradients to the distance either step has from float64 (ReLU masks flip where a pre-activation
+    is closer to zero than the round-off: measured 0.9 % of the whole gradient's norm)."""
+    from panoptic_forecasting_amd import lib as pflib
+    from panoptic_forecasting_amd.bg_train import BGTrainer
+    z, batches = _fixture()
+    a_in, a_lab = (_cuda(d) for d in batches[0])
+    L = pflib.load()
+    got = {}
+    try:
+        for mode in (0, 1):
+            pflib.check(L.pf_set_option(b'train_forward_s4', mode), 'pf_set_option')
+            tr = BGTrainer(_params())
+            tr.load_state_dict(_sd())
+            r = tr.forward_backward(a_in, a_lab, update_running_stats=False)
+            got[mode] = (float(r['loss']), tr.grad.clone(), tr.path_stats())
+            if mode:
+                tr.forward_backward(a_in, a_lab, update_running_stats=False)
+                assert torch.equal(tr.grad, got[1][1])          # bit-reproducible
+    finally:
+        L.pf_set_option(b'train_forward_s4', 0)
+    assert got[0][2]['packed_pair_forward_convs'] == 0 and got[1][2]['packed_pair_forward_convs'] >= 60, (got[0][2], got[1][2])
+    assert got[1][2]['generic_kernel_launches'] == 0
+    assert abs(got[1][0] - got[0][0]) <= 1e-6 * abs(got[0][0])
+    assert _rel(got[1][1], got[0][1]) <= 3e-2
 
 
 def _mini_network_step(size):
