@@ -275,9 +275,10 @@ int pf_seg_loss(const float *logits, int B, int C, int Hin, int Win, const void 
  *   "train_forward_s4" (default 0; process-wide only, read by pf_train_create) 1 = the forward 3x3 stride-1 and 1x1 conv +
  *                   BatchNorm layers of a training step run on the packed-pair kernels of the inference path (csrc/train_s4.hip:
  *                   weights packed on the device every step with the fixed scale 2^12 - a weight of magnitude >= 16 becomes NaN,
- *                   loudly - activations shadowed as fp16 pairs slice by slice, fp32 outputs): the step 14.45 -> 13.97 ms at batch 8
- *                   of 800x800, the forward pass 1.0-1.2 x as far from float64 as torch-CPU fp32 instead of 0.9 x (one fp32 chain
- *                   per output instead of blocked sums) - which is why it is off; 0 = conv_dma on the fp32 matrix instruction;
+ *                   loudly - activation slices shadowed as fp16 pairs, fp32 outputs; the 3x3 layers on conv_s4_blocked_kernel, which
+ *                   sums every round of 8 input channels on its own like the fp32 step): the step 14.45 -> 14.24 ms at batch 8 of
+ *                   800x800, the forward pass 0.81-0.95 x as far from float64 as torch-CPU fp32 (fp32 step: 0.79-0.95 x; without
+ *                   the blocked sums 14.0 ms and 1.0-1.2 x); 0 = conv_dma on the fp32 matrix instruction;
  *   "wgrad_taps"    (default 1; process-wide only) weight gradients of 3x3 stride-1 layers with the taps folded into the matrix rows
  *                   (csrc/wgrad_taps.hip: rows = (cout, tap) pairs, 10 outputs fill 90 of 96 rows instead of 10 of 16): 1 = per layer
  *                   where it measured faster, 0 = never (wgrad_tiled_kernel), 2 = wherever the kernel exists; same fixed-order

@@ -106,392 +106,25 @@ struct S4Cfg {
     static_assert(KS == 1 || (size_t)MP * NT * NW * 64 * 16 <= STAGES_BYTES, "the K-split hand-over uses group 1's stage ring");
 };
 
-template <int NT, int TW_, int TH_, int KS_>
-__global__ __launch_bounds__(32 * TH_ * KS_, KS_ == 4 ? 1 : (TH_ == 16 || KS_ == 2) ? 2 : (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT == 3) ? 3 : 2) void conv_s4_kernel(ConvArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    using C = S4Cfg<NT, TW_, TH_, KS_>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    const int lane = threadIdx.x & 63;
-    const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int kgrp = C::KS > 1 ? wave_all / C::NW : 0;            // wave group of the K split (uniform)
-    const int wave = C::KS > 1 ? wave_all % C::NW : wave_all;      // wave inside its group
-    const int tid = C::KS > 1 ? (int)threadIdx.x & (C::NTHR - 1) : (int)threadIdx.x;   // thread inside its group
-    unsigned char *const smem_raw = smem_all + kgrp * C::STAGES_BYTES;   // this group's stage ring
-    int tid_lin, cgroup;   // XCD-aware order of tiles and cout groups (conv_mfma.h)
-    xcd_tile_order(a.tilesX * a.tilesY, tid_lin, cgroup);
-    const int tileY = tid_lin / a.tilesX, tileX = tid_lin - tileY * a.tilesX;
-    const int tile0 = cgroup * NT, b = blockIdx.z;
-    const int iy0 = tileY * C::TH - 1, ix0 = tileX * C::TW - 2;
-    const size_t plane_bytes = (size_t)a.Hin * a.Win * 8;
-    auto abuf = [&](int i) { return smem_raw + i * C::ABUF; };
-    auto wbuf = [&](int i) { return smem_raw + 2 * C::ABUF + i * C::WBUF; };
-
-    s4_f32x4 acc[C::MP][NT];
-#pragma unroll
-    for (int m = 0; m < C::MP; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = s4_f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // this lane's pieces of the plane its wave fetches: byte offset inside a group plane, or out of range
-    // this wave's plane of a stage and its first DMA instruction of that plane (4 waves: one plane each, all of it)
-    const int w4 = C::NW == 4 ? wave : (wave & 3), jb = C::NW == 4 ? 0 : (wave >> 2) * C::NDMA;
-    unsigned poff[C::NDMA];
-#pragma unroll
-    for (int j = 0; j < C::NDMA; ++j) {
-        const int p = (jb + j) * 64 + lane, row = p / C::ROWP, cp = p - row * C::ROWP;
-        const int gy = iy0 + row, gx = ix0 + 2 * cp;
-        poff[j] = (p < C::PIECES && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? (unsigned)(gy * a.Win + gx) * 8u : kS4Oob;
-    }
-    // weight pieces of a stage: piece p -> (cout tile n, block, [term][lane]); the same byte offset in LDS and, per tile, in
-    // the packed stream (blocks of a round are consecutive there)
-    const int nblocks = s4_blocks_total(a.nchunks);
-    unsigned woff[C::NITW];
-    bool wcol[C::NITW];                    // piece of the collected-tap block (BPT = 3 only): fetched in flush rounds only
-#pragma unroll
-    for (int it = 0; it < C::NITW; ++it) {
-        const int p = it * C::NTHR + tid, n = p / (C::BPT * 2 * 64), rem = p - n * (C::BPT * 2 * 64);
-        woff[it] = (p < C::WPIECES && tile0 + n < a.ntiles) ? ((unsigned)(tile0 + n) * (unsigned)nblocks * (2 * 64) + (unsigned)rem) * 16u : kS4Oob;
-        wcol[it] = rem >= 2 * 2 * 64;
-    }
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.wpk, 0, 0x7FFFFFFF, 0x00020000);
-
-    // A-fragment byte offsets inside a plane (M-tile part added as an immediate): the lane group picks the tap of instr 0 / 1;
-    // the collected tap (2,2) is the same for every lane
-    const int g = lane >> 4;
-    int aoff[2], aoff_col;
-    {
-        const int ky[2] = {g >> 1, g < 2 ? 2 : g - 2};
-        const int kx[2] = {g & 1, g < 2 ? g : 2};
-        // (M-tile = 16 consecutive pixels of a row.  Pairing even / odd pixels for 16-B epilogue stores was built and measured
-        //  +12 % on the fragment reads: profiles/r03_experiments.md)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) aoff[s] = ((wave * 2 + ky[s]) * C::IW + (lane & 15) + kx[s] + 1) * 8;
-        aoff_col = ((wave * 2 + 2) * C::IW + (lane & 15) + 2 + 1) * 8;
-    }
-
-    // operand roles are swapped with respect to conv_split.hip (weights = A, pixels = B): the D fragment of lane (g, i) is
-    // couts 4g .. 4g+3 of a pixel = one 8-B unit of the packed layout per term, no cross-lane traffic in the epilogue.
-    // The bias values of the workgroup's couts go to LDS by DMA now (4 B per lane, zero for couts past the layer) and are
-    // read back in the epilogue: kept in registers across the main loop they cost NT * 4 registers (spilled at NT = 2, 3),
-    // and either way the epilogue had to wait for them with vmcnt - which on gfx950 also waits for the epilogue's own stores
-    float *bias_lds = reinterpret_cast<float *>(smem_all + C::KS * C::STAGES_BYTES);
-    if (wave_all == 0 && lane < NT * 16) {
-        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)a.bias, 0, 0x7FFFFFFF, 0x00020000);
-        const int co = tile0 * 16 + lane;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (s4_lds_ptr_t)bias_lds, 4, co < a.ntiles * 16 ? (unsigned)co * 4u : kS4Oob, 0, 0, 0);
-    }
-
-    const int nrounds = a.nchunks;   // 3x3 launches always run the whole K range (the collected tap spans 4 rounds)
-    // K split: group k runs rounds [k * chunk, (k + 1) * chunk); chunk is a multiple of 4, so every group but the last ends on a
-    // flush round and all see whole groups of four collected-tap rounds.  All groups execute the same number of barriers
-    const int chunk = C::KS > 1 ? (((nrounds + C::KS - 1) / C::KS + 3) / 4) * 4 : nrounds;
-    const int r_begin = min(nrounds, kgrp * chunk), r_end = min(nrounds, r_begin + chunk);
-    const int n_iter = chunk;
-    // The DMA instructions of the next stage go out between the matrix groups of the current one (a part = one activation
-    // piece + its share of the weight pieces): issued in one block they cost the wave ~1000 clocks per round in which it
-    // feeds no MFMA (tools/probe_s4.py).
-    constexpr int HALVES = C::MP / 4;
-    __amdgpu_buffer_rsrc_t ars;
-    unsigned asoff = 0;
-    bool areal = true;
-    auto prepare_round = [&](int r) {
-        // activations: wave w fetches plane (term = w >> 1, entry = 2 r + (w & 1))
-        const char *base;
-        unsigned goff, tstride;
-        areal = s4_entry(a, 2 * r + (w4 & 1), b, plane_bytes, base, goff, tstride);
-        ars = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7FFFFFFF, 0x00020000);
-        asoff = goff + (unsigned)(w4 >> 1) * tstride;
-    };
-    auto is_flush = [&](int r) { return (r & 3) == 3 || r == nrounds - 1; };
-    auto issue_part = [&](int r, int stage, int j) {
-        if ((jb + j) * 64 + lane < C::PIECES)   // the plane holds exactly its pieces: lanes past the last one write nothing
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (s4_lds_ptr_t)(abuf(stage) + w4 * C::PLANE + (jb + j) * 1024), 16,
-                                                     areal ? poff[j] : kS4Oob, asoff, 0, S4_ACT_AUX);
-        unsigned char *wdst = wbuf(stage);
-        const bool flush = is_flush(r);
-#pragma unroll
-        for (int it = j; it < C::NITW; it += C::NDMA)
-            if (it * C::NTHR + tid < C::WPIECES && (flush || !wcol[it]))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (s4_lds_ptr_t)(wdst + (it * C::NTHR + wave * 64) * 16), 16, woff[it],
-                                                         (unsigned)s4_blocks_before(r) * C::WBLK, 0, 0);
-    };
-    // part j of the next stage goes out after MFMA group kS4IssueFirst + j * kS4IssueStep of the round (6 HALVES groups)
-    auto issue_slot = [&](int round, bool more, int slot) {
-        if (!more) return;
-#pragma unroll
-        for (int j = 0; j < C::NDMA; ++j)
-            if (slot == kS4IssueFirst + j * kS4IssueStep) issue_part(round + 1, (round + 1) & 1, j);
-    };
-    static_assert(kS4IssueFirst + (C::NDMA - 1) * kS4IssueStep < 6 * HALVES, "every DMA part needs a slot inside the two full instructions");   // (batches of 2 M-tiles: 12 slots)
-
-    // collected tap: K-slice g of these fragments = entries of round 4q + g
-    s4_h8 col_h[C::MP], col_m[C::MP];
-    const s4_h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int m = 0; m < C::MP; ++m) col_h[m] = col_m[m] = zero8;
-
-    if (r_begin < r_end) {
-        prepare_round(r_begin);
-#pragma unroll
-        for (int j = 0; j < C::NDMA; ++j) issue_part(r_begin, r_begin & 1, j);
-    }
-    for (int it_ = 0; it_ < n_iter; ++it_) {
-        const int round = r_begin + it_;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
-        S4_PROBE(round * 4 + 0);
-        __syncthreads();                                    // everyone's have, and everyone is done reading the other stage
-        S4_PROBE(round * 4 + 1);
-        if (C::KS > 1 && round >= r_end) continue;          // a shorter part of a K split idles through the others' last rounds
-        const bool more = round + 1 < r_end;
-        if (more) prepare_round(round + 1);
-        S4_PROBE(round * 4 + 2);
-        const unsigned char *ab = abuf(round & 1), *wb = wbuf(round & 1);
-#if S4_SETPRIO
-        __builtin_amdgcn_s_setprio(S4_SETPRIO);
-#endif
-        auto frag = [&](const unsigned char *p, s4_h8 &h, s4_h8 &md) {
-            if constexpr (S4_FRAG_B64 == 1 || (S4_FRAG_B64 == 2 && NT != 2)) {
-                // four plain ds_read_b64, each straight into its half of an operand tuple (see S4_FRAG_B64 above)
-                typedef const volatile __attribute__((address_space(3))) s4_h4 *lds_h4;
-                const lds_h4 q = (lds_h4)(const __attribute__((address_space(3))) unsigned char *)p;
-                constexpr int PL = C::PLANE / 8;
-                h = s4_join(q[0], q[PL]);
-                md = s4_join(q[2 * PL], q[3 * PL]);
-            } else {
-                h = s4_join(*reinterpret_cast<const s4_h4 *>(p), *reinterpret_cast<const s4_h4 *>(p + C::PLANE));
-                md = s4_join(*reinterpret_cast<const s4_h4 *>(p + 2 * C::PLANE), *reinterpret_cast<const s4_h4 *>(p + 3 * C::PLANE));
-            }
-        };
-        auto mtile_off = [&](int mm) {
-            return ((mm / C::MTR) * C::IW + (mm % C::MTR) * 16) * 8;
-        };
-        // the three products of one block of weights with FT M-tiles; `slot0` numbers the MFMA groups for the DMA parts.
-        // FT = 4 M-tiles per batch of fragment reads, or 2 for <2, 32> with the plain 8-B reads: its 126 registers have no
-        // room for 32 fragment registers that are all live at once (the reads are volatile: none may be sunk below a matrix
-        // instruction) - two tiles at a time need 16
-        constexpr bool kB64 = S4_FRAG_B64 == 1 || (S4_FRAG_B64 == 2 && NT != 2);
-        constexpr int FT = (kB64 && NT == 2 && C::MP == 4) ? 2 : 4;
-        auto mfmas = [&](const s4_h8 (&wh)[NT], const s4_h8 (&wm)[NT], int m0, const auto &fh, const auto &fm, int slot0, bool dma) {
-            constexpr int FTn = (int)(sizeof(fh) / sizeof(fh[0]));
-#pragma unroll
-            for (int m = 0; m < FTn; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = PF_MFMA_SPLIT(wh[n], fm[m], acc[m0 + m][n]);
-            if (dma) issue_slot(round, more, slot0 + 0);
-#pragma unroll
-            for (int m = 0; m < FTn; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = PF_MFMA_SPLIT(wm[n], fh[m], acc[m0 + m][n]);
-            if (dma) issue_slot(round, more, slot0 + 1);
-#pragma unroll
-            for (int m = 0; m < FTn; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m0 + m][n] = PF_MFMA_SPLIT(wh[n], fh[m], acc[m0 + m][n]);
-            if (dma) issue_slot(round, more, slot0 + 2);
-        };
-        constexpr int NB = C::MP / FT;      // fragment batches per instruction of a round
-        // S4_COL_EARLY (<2, 32>): the collected-tap weights of a flush round are requested BEFORE the round's DMA parts: loads return in
-        // order, so waiting for them at the flush then does not wait for the next stage's DMA as well (16 registers across the round:
-        // <3, 32> has no room for its 24)
-        constexpr bool kColEarly = S4_COL_EARLY && C::COLREG && NT == 2;
-        s4_h8 cwh[NT], cwm[NT];
-        if (kColEarly && is_flush(round)) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const bool real = tile0 + n < a.ntiles;   // uniform
-                const char *wp = reinterpret_cast<const char *>(a.wpk) +
-                                 ((size_t)(real ? tile0 + n : 0) * nblocks + s4_blocks_before(round) + 2) * C::WBLK + lane * 16;
-                cwh[n] = real ? *reinterpret_cast<const s4_h8 *>(wp) : zero8;
-                cwm[n] = real ? *reinterpret_cast<const s4_h8 *>(wp + 64 * 16) : zero8;
-            }
-        }
-        // S4_PREFETCH (experiment, off): the fragments of batch k + 1 are read while the matrix instructions of batch k run
-        constexpr bool kPrefetch = S4_PREFETCH && kB64 && NT <= 2 && KS_ == 1 && TH_ == 8 && TW_ == 32;
-        if constexpr (kPrefetch) {
-            s4_h8 fh[2][FT], fm[2][FT];
-            auto read_batch = [&](int k, s4_h8 (&h)[FT], s4_h8 (&md)[FT]) {
-#pragma unroll
-                for (int m = 0; m < FT; ++m) frag(ab + aoff[k / NB] + mtile_off((k % NB) * FT + m), h[m], md[m]);
-            };
-            read_batch(0, fh[0], fm[0]);
-            s4_h8 wh[NT], wm[NT];
-#pragma unroll
-            for (int k = 0; k < 2 * NB; ++k) {
-                const int sI = k / NB;
-                if (k % NB == 0) {
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        wh[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * C::BPT + sI) * 2 + 0) * 64 + lane) * 16);
-                        wm[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * C::BPT + sI) * 2 + 1) * 64 + lane) * 16);
-                    }
-                }
-                if (k + 1 < 2 * NB) read_batch(k + 1, fh[(k + 1) & 1], fm[(k + 1) & 1]);
-                mfmas(wh, wm, (k % NB) * FT, fh[k & 1], fm[k & 1], 3 * k, true);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            s4_h8 wh[NT], wm[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                wh[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * C::BPT + s) * 2 + 0) * 64 + lane) * 16);
-                wm[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * C::BPT + s) * 2 + 1) * 64 + lane) * 16);
-            }
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) {
-                s4_h8 fh[FT], fm[FT];
-#pragma unroll
-                for (int m = 0; m < FT; ++m) frag(ab + aoff[s] + mtile_off(bt * FT + m), fh[m], fm[m]);
-                mfmas(wh, wm, bt * FT, fh, fm, 3 * (s * NB + bt), true);
-                __builtin_amdgcn_sched_barrier(0);   // keep the next unit's fragment reads behind these MFMAs (registers)
-            }
-        }
-        }
-        // the ninth tap of this round's entries: K-slice (round & 3)
-        if (g == (round & 3)) {
-#pragma unroll
-            for (int m = 0; m < C::MP; ++m) frag(ab + aoff_col + mtile_off(m), col_h[m], col_m[m]);
-        }
-        if (is_flush(round)) {
-            // the collected-tap block of this flush round (third block of the round in the packed stream).  COLREG: global ->
-            // registers (L2-resident; the fragment registers of the two full instructions are dead here); else from LDS
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                if (kColEarly) continue;
-                if (C::COLREG) {
-                    const bool real = tile0 + n < a.ntiles;   // uniform
-                    const char *wp = reinterpret_cast<const char *>(a.wpk) +
-                                     ((size_t)(real ? tile0 + n : 0) * nblocks + s4_blocks_before(round) + 2) * C::WBLK + lane * 16;
-                    cwh[n] = real ? *reinterpret_cast<const s4_h8 *>(wp) : zero8;
-                    cwm[n] = real ? *reinterpret_cast<const s4_h8 *>(wp + 64 * 16) : zero8;
-                } else {
-                    cwh[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * 3 + 2) * 2 + 0) * 64 + lane) * 16);
-                    cwm[n] = *reinterpret_cast<const s4_h8 *>(wb + (((n * 3 + 2) * 2 + 1) * 64 + lane) * 16);
-                }
-            }
-#pragma unroll
-            for (int hf = 0; hf < HALVES; ++hf) {
-                s4_h8 fh[4], fm[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    fh[m] = col_h[hf * 4 + m];
-                    fm[m] = col_m[hf * 4 + m];
-                }
-                mfmas(cwh, cwm, hf * 4, fh, fm, 0, false);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int m = 0; m < C::MP; ++m) col_h[m] = col_m[m] = zero8;
-        }
-#if S4_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        S4_PROBE(round * 4 + 3);
-    }
-    S4_PROBE(58);
-    if (C::KS > 1) {
-        // hand-over of the K split: groups 1.. park their sums in their own stage rings (conflict-free 16-B units), group 0 adds them
-        __syncthreads();                                    // every wave is done reading its ring
-        if (kgrp > 0) {
-            s4_f32x4 *red = reinterpret_cast<s4_f32x4 *>(smem_raw);
-#pragma unroll
-            for (int m = 0; m < C::MP; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) red[((m * NT + n) * C::NW + wave) * 64 + lane] = acc[m][n];
-        }
-        __syncthreads();
-        if (kgrp > 0) return;
-#pragma unroll
-        for (int k = 1; k < C::KS; ++k) {
-            const s4_f32x4 *red = reinterpret_cast<const s4_f32x4 *>(smem_all + k * C::STAGES_BYTES);
-#pragma unroll
-            for (int m = 0; m < C::MP; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] += red[((m * NT + n) * C::NW + wave) * 64 + lane];
-        }
-    }
-
-    // ---- epilogue: bias + ReLU; lane (g, i) holds couts 4g..4g+3 of the pixel pair (2i, 2i+1) of every M-tile pair: one
-    //      16-B unit [2 px][4 ch] per term, or fp32 NCHW pairs
-    {
-        // Nothing in flight may be left for the compiler's wait-count pass to protect inside the store loop below: the main
-        // loop's waits are inline asm (invisible to the pass), so a register it believes pending - a scratch reload, a value
-        // loaded before the loop - got an s_waitcnt vmcnt(0) in EVERY iteration of that loop, and on gfx950 stores count in
-        // vmcnt: each unit then sat through the store round trips of the unit before it (tools/asm_store_waits.py lists the
-        // kernels that wait for their own stores).  One wait the pass can see, here:
-        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt / lgkmcnt untouched
-        const int g = lane >> 4, px = lane & 15;
-        const size_t hw = (size_t)a.Hout * a.Wout;
-        const size_t term = (size_t)a.dst_c4 * hw * 8;
-        const bool mis = (a.dst_choff & 2) != 0;   // the range starts in the middle of a group (uniform)
-        const float relu_lo = a.relu ? 0.f : -__builtin_inff();
-        float vmax = 0.f;                          // range guard of the operand split (conv_mfma.h)
-        typedef split_x2 h2;
-        // one pixel's 4 channels (group tails, ranges that start in the middle of a group)
-        auto store_px = [&](int co, size_t pix, s4_f32x4 v) {
-            s4_h4 hi, mid;
-            split_terms4(v, hi, mid);
-            const int chb = a.dst_choff + co;
-            const bool ok0 = chb < a.dst_limit, ok1 = chb + 2 < a.dst_limit;
-            char *p = reinterpret_cast<char *>(a.dst) + (size_t)b * 2 * term + pix * 8 + (size_t)(chb >> 2) * hw * 8;
-            if (!mis) {
-                if (ok1) {
-#if S4_STORE_NT
-                    __builtin_nontemporal_store(hi, reinterpret_cast<s4_h4 *>(p));
-                    __builtin_nontemporal_store(mid, reinterpret_cast<s4_h4 *>(p + term));
-#else
-                    *reinterpret_cast<s4_h4 *>(p) = hi;
-                    *reinterpret_cast<s4_h4 *>(p + term) = mid;
-#endif
-                } else if (ok0) {
-                    *reinterpret_cast<h2 *>(p) = h2{hi[0], hi[1]};
-                    *reinterpret_cast<h2 *>(p + term) = h2{mid[0], mid[1]};
-                }
-            } else {   // upper half of one group, lower half of the next
-                if (ok0) {
-                    *reinterpret_cast<h2 *>(p + 4) = h2{hi[0], hi[1]};
-                    *reinterpret_cast<h2 *>(p + 4 + term) = h2{mid[0], mid[1]};
-                }
-                if (ok1) {
-                    *reinterpret_cast<h2 *>(p + hw * 8) = h2{hi[2], hi[3]};
-                    *reinterpret_cast<h2 *>(p + hw * 8 + term) = h2{mid[2], mid[3]};
-                }
-            }
-        };
-#pragma unroll
-        for (int m = 0; m < C::MP; ++m) {
-            const int mt = wave * C::MP + m;
-            const int oy = tileY * C::TH + mt / C::MTR;
-            const int ox = tileX * C::TW + (mt % C::MTR) * 16 + px;
-            if (oy >= a.Hout || ox >= a.Wout) continue;
-            const size_t pix = (size_t)oy * a.Wout + ox;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int co = (tile0 + n) * 16 + 4 * g;
-                if (co >= a.Cout + 2) continue;
-                s4_f32x4 v = acc[m][n];
-                const s4_f32x4 b4 = *reinterpret_cast<const s4_f32x4 *>(bias_lds + n * 16 + 4 * g);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r] * a.acc_scale + b4[r], relu_lo);   // relu_lo = 0 or -inf: one max, no select
-                vmax = range_acc(vmax, v[0], v[1], v[2], v[3]);
-                if (a.dst_fmt) {
-                    store_px(co, pix, v);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (co + r < a.Cout) a.dst[((size_t)b * a.dst_ctotal + a.dst_choff + co + r) * hw + pix] = v[r];
-                }
-            }
-        }
-        range_commit(a.status, a.range_slot, vmax);
-    }
-    S4_PROBE(59);
-#endif
-}
+// KACC (training, train_s4.hip): every round's products (72 terms per output: 8 channels x 9 taps) are summed on their own and added
+// to a second accumulator set - blocked summation, like the fp32 step's conv_dma (KACC there) and like ATen - instead of one fp32
+// chain over all 9 Cin terms: the forward pass of a training step is then as close to float64 as the fp32 step's
+#define S4_KERNEL_NAME conv_s4_kernel
+#define S4_KERNEL_KACC 0
+#define S4_KERNEL_WAVES (KS_ == 4 ? 1 : (TH_ == 16 || KS_ == 2) ? 2 : (TW_ == 32 && NT <= 2) ? 4 : (TW_ == 32 && NT == 3) ? 3 : 2)
+#include "conv_s4_kernel.inc"
+#undef S4_KERNEL_NAME
+#undef S4_KERNEL_KACC
+#undef S4_KERNEL_WAVES
+// the blocked-sum form (instantiated for 8 x 32 tiles without a K split): one workgroup per CU fewer than the plain form where the
+// second accumulator set needs the registers
+#define S4_KERNEL_NAME conv_s4_blocked_kernel
+#define S4_KERNEL_KACC 1
+#define S4_KERNEL_WAVES (NT == 1 ? 4 : (NT == 2 ? 3 : 2))
+#include "conv_s4_kernel.inc"
+#undef S4_KERNEL_NAME
+#undef S4_KERNEL_KACC
+#undef S4_KERNEL_WAVES
 
 template <int NT, int TW_, int TH_ = 8, int KS_ = 1>
 static int launch_s4_cfg(const ConvArgs &a0, int B, hipStream_t s) {
@@ -512,6 +145,26 @@ static int launch_s4_cfg(const ConvArgs &a0, int B, hipStream_t s) {
                  4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * 9));
     hipLaunchKernelGGL((conv_s4_kernel<NT, TW_, TH_, KS_>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(C::NTHR * C::KS), C::LDS_BYTES, s, a);
     PF_LAUNCH_CHECK("conv_s4_kernel");
+    return PF_OK;
+}
+
+template <int NT>
+static int launch_s4_blocked_cfg(const ConvArgs &a0, int B, hipStream_t s) {
+    using C = S4Cfg<NT, 32, 8, 1>;
+    ConvArgs a = a0;
+    a.tilesX = (a.Wout + C::TW - 1) / C::TW;
+    a.tilesY = (a.Hout + C::TH - 1) / C::TH;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s4_blocked_kernel<NT, 32, 8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_set = true;
+    }
+    char label[96];
+    snprintf(label, sizeof(label), "void pf::conv_s4_blocked_kernel<%d, 32, 8, 1>(pf::ConvArgs)", NT);
+    const double px = (double)B * a.Hout * a.Wout;
+    ProfScope ps(s, label, 2.0 * px * a.Cout * a.Cin * 9, 4.0 * ((double)B * a.Cin * a.Hin * a.Win + px * a.Cout + (double)a.Cout * a.Cin * 9));
+    hipLaunchKernelGGL((conv_s4_blocked_kernel<NT, 32, 8, 1>), dim3(a.tilesX * a.tilesY, (a.ntiles + NT - 1) / NT, B), dim3(C::NTHR), C::LDS_BYTES, s, a);
+    PF_LAUNCH_CHECK("conv_s4_blocked_kernel");
     return PF_OK;
 }
 
@@ -878,6 +531,11 @@ int launch_conv_s4(const ConvArgs &a, int ks, int nt, int wide, int B, hipStream
     if (ks == 3) {
         if (a.pool || a.res || a.no_bias) return fail(PF_EUNSUPPORTED, "conv_s4 3x3: no fused epilogue stages");
         if (a.chunk_begin != 0 || a.chunk_end != a.nchunks) return fail(PF_EUNSUPPORTED, "conv_s4 3x3: whole K range only");
+        if (a.kacc) {      // blocked summation (training): 8 x 32 tiles, 1 - 3 cout tiles
+            if (nt == 1) return launch_s4_blocked_cfg<1>(a, B, s);
+            if (nt == 2) return launch_s4_blocked_cfg<2>(a, B, s);
+            return launch_s4_blocked_cfg<3>(a, B, s);
+        }
         if (wide == 2) {   // 16x32-pixel tiles, 8 waves
             if (nt == 1) return launch_s4_cfg<1, 32, 16>(a, B, s);
             return launch_s4_cfg<2, 32, 16>(a, B, s);

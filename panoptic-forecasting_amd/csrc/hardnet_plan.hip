@@ -87,7 +87,7 @@ int g_opt_up_two_pass = 1;  // upsample_bwd_two_pass: the bilinear transposes of
 int g_opt_train_table_batch = 0;   // train_table_batch: batch size the rows of train_tuned.inc are looked up with (0 = the call's own)
 int g_opt_train_kacc = 1;   // train_blocked_sum: per-round partial sums in the 3x3 convolutions of a training step (conv_dma.hip: KACC)
 extern int g_opt_wgrad_taps;   // wgrad_taps (train_kernels.hip)
-int g_opt_train_s4 = 0;         // train_forward_s4: the forward convolutions of a training step on conv_s4 (train_s4.hip); off: 1.2x instead of 0.9x ATen's distance to float64
+int g_opt_train_s4 = 0;         // train_forward_s4: the forward convolutions of a training step on conv_s4 with blocked sums (train_s4.hip); opt-in
 int g_opt_train_side = 1;   // train_side_stream: weight gradients on the training plan's own stream (train_plan.hip)
 }
 

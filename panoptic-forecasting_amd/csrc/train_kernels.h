@@ -47,6 +47,8 @@ int launch_wgrad(const ConvArgs &a, int ks, int stride, const float *dy, int B, 
 // train_s4.hip: the forward convolutions of a step on the packed-pair kernels (conv_s4.hip)
 constexpr int kS4WBatch = 16;
 constexpr float kS4TrainWeightScale = 4096.f;     // 2^12: |w| < 16 fits fp16 (a larger weight is stored as NaN: the step's loss is NaN)
+constexpr float kS4TrainActScale = 1.f;           // activations are shadowed as they are (post-BatchNorm values are O(1); |z| < 2^-2 keeps 2^-25 absolute:
+                                                  // conv_mfma.h.  A 2^6 pre-scale was measured: same forward distance, profiles/r06_experiments.md)
 struct S4WJob {            // one conv's device-side weight packing (pack_conv_weights_s4's layout)
     long long w_off;       // OIHW weights: floats into theta
     unsigned out_off;      // floats into the packed arena
@@ -61,9 +63,11 @@ struct S4WBatch {
 static_assert(sizeof(S4WBatch) <= 3584, "S4WBatch travels as kernel arguments");
 size_t s4_wjob_init(S4WJob &jb, size_t w_off, int cin, int cout, int ks, const S4Range *r, int n_src, int pad_sources);
 int launch_s4_pack_weights_dev(const float *theta, float *arena, const S4WJob *jobs, int n, float scale, hipStream_t s);
-// channels [c0, c1) of the fp32 tensor src [B][ctotal][H][W] -> its packed-pair shadow with rows of Wp >= W pixels (zeros in the pad columns)
-// fill_lo / fill_up: also zero the half group in front of / behind a slice that starts / ends in the middle of a 4-channel group
-int launch_s4_pack_act(const float *src, int B, int ctotal, int c0, int c1, int fill_lo, int fill_up, int H, int W, int Wp, void *dst, hipStream_t s);
+// channels [c0, c1) of the fp32 tensor src [B][ctotal][H][W], times `scale` (a power of two) -> its packed-pair shadow with rows of
+// Wp >= W pixels (zeros in the pad columns).  fill_lo / fill_up: also zero the half group in front of / behind a slice that starts /
+// ends in the middle of a 4-channel group
+int launch_s4_pack_act(const float *src, int B, int ctotal, int c0, int c1, int fill_lo, int fill_up, int H, int W, int Wp, void *dst, float scale,
+                       hipStream_t s);
 // wgrad_taps.hip: 3x3 stride-1 layers, the taps folded into the matrix rows; partial[slab][co_pad][ci_pad][9], *slabs_used <= max_slabs
 bool wgrad_taps_ok(int ks, int stride, int Hin, int Win, int Hout, int Wout);
 // mode = option wgrad_taps: 0 never, 2 wherever the kernel exists, 1 where it measured faster than wgrad_tiled_kernel

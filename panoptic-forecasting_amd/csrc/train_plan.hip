@@ -659,7 +659,7 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
         if (wr.empty()) wr.assign((size_t)ct + 4, 0);
         const int fill_lo = (c0 & 2) && !wr[c0 - 2], fill_up = (c1 & 3) == 2 && c1 < ct && !wr[c1];
         for (int c = c0; c < c1; ++c) wr[c] = 1;
-        return launch_s4_pack_act(act(t), B, ct, c0, c1, fill_lo, fill_up, d[t].h, d[t].w, (d[t].w + 3) / 4 * 4, wsb + L.s4act[t], s);
+        return launch_s4_pack_act(act(t), B, ct, c0, c1, fill_lo, fill_up, d[t].h, d[t].w, (d[t].w + 3) / 4 * 4, wsb + L.s4act[t], kS4TrainActScale, s);
     };
     const GradFirst gfirst = grad_first_writers(p, d);      // (no cleared gradient arena: first writers store)
     for (const auto &c : gfirst.clear)
@@ -785,11 +785,12 @@ static int train_pass(const pf_train *p, float *theta, float *grad, int accumula
                     c.dst_fmt = 0;
                     c.src_begin = 0;
                     c.Win = Wp; c.Wout = Wp;
-                    c.acc_scale = 1.0f / kS4TrainWeightScale;
+                    c.acc_scale = 1.0f / (kS4TrainWeightScale * kS4TrainActScale);
                     c.wpk = s4w_arena + jb.out_off;
                     c.nchunks = jb.rounds;
                     c.chunk_begin = 0;
                     c.chunk_end = jb.rounds;
+                    c.kacc = (g_opt_train_kacc && o.k == 3) ? 1 : 0;      // blocked summation, as in the fp32 step (conv_s4_kernel.inc: KACC)
                     ConvChoice ch4;
                     int nt4 = c.ntiles == 3 ? 3 : (c.ntiles < 2 ? 1 : 2), wide4 = 0;
                     if (g_opt_use_tuned && choose_s4((int)o.k, c.Cin, c.Cout, c.Hout, c.Wout, B, &ch4) && ch4.kind == 5) { nt4 = ch4.p0; wide4 = ch4.p1; }

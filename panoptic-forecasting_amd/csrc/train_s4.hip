@@ -138,7 +138,7 @@ size_t s4_wjob_init(S4WJob &jb, size_t w_off, int cin, int cout, int ks, const S
 // zeros in the pad columns.  A thread = two neighbouring pixels of one channel group: 16 B per term where the slice owns the whole
 // group (a slice that ends at the tensor's last channel owns the group's missing channels too: zeros), else the 4-B half it owns.
 __global__ __launch_bounds__(256) void s4_pack_act_kernel(const float *src, int ctotal, int c0, int c1, int fill_lo, int fill_up, int H, int W, int Wp,
-                                                          unsigned short *dst) {
+                                                          unsigned short *dst, float scale) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int pairs = H * (Wp / 2), pp = blockIdx.x * 256 + threadIdx.x;
     if (pp >= pairs) return;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void s4_pack_act_kernel(const float *src, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = 4 * g + r;
-            v[k][r] = (c >= c0 && c < c1 && x + k < W) ? src[((size_t)b * ctotal + c) * hw + (size_t)y * W + x + k] : 0.f;
+            v[k][r] = (c >= c0 && c < c1 && x + k < W) ? src[((size_t)b * ctotal + c) * hw + (size_t)y * W + x + k] * scale : 0.f;
         }
     s4_h4 hi[2], mid[2];
     split_terms4(v[0], hi[0], mid[0]);
@@ -181,11 +181,12 @@ __global__ __launch_bounds__(256) void s4_pack_act_kernel(const float *src, int 
 #endif
 }
 
-int launch_s4_pack_act(const float *src, int B, int ctotal, int c0, int c1, int fill_lo, int fill_up, int H, int W, int Wp, void *dst, hipStream_t s) {
+int launch_s4_pack_act(const float *src, int B, int ctotal, int c0, int c1, int fill_lo, int fill_up, int H, int W, int Wp, void *dst, float scale,
+                       hipStream_t s) {
     if ((c0 & 1) || (Wp & 3) || Wp < W || c1 <= c0) return fail(PF_EINVAL, "s4_pack_act: slice [%d, %d) of %d channels, width %d pitch %d", c0, c1, ctotal, W, Wp);
     const int groups = (c1 + 3) / 4 - c0 / 4, pairs = H * (Wp / 2);
     hipLaunchKernelGGL(s4_pack_act_kernel, dim3((unsigned)((pairs + 255) / 256), groups, B), dim3(256), 0, s, src, ctotal, c0, c1, fill_lo, fill_up, H, W,
-                       Wp, reinterpret_cast<unsigned short *>(dst));
+                       Wp, reinterpret_cast<unsigned short *>(dst), scale);
     PF_LAUNCH_CHECK("s4_pack_act_kernel");
     return PF_OK;
 }

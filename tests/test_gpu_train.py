@@ -511,7 +511,7 @@ def test_mini_network_training_step_vs_autograd(size, taps):
 @pytest.mark.parametrize('size', [(24, 40), (34, 70)])
 def test_mini_network_forward_on_packed_pairs_vs_autograd(size):
     """Option train_forward_s4 (csrc/train_s4.hip, off by default): the forward conv + BatchNorm layers of a step on the inference
-    path's packed-pair kernels - weights packed on the device every step, activation slices shadowed as fp16 pairs (a slice that
+    path's packed-pair kernels with blocked sums (conv_s4_blocked_kernel) - weights packed on the device every step, activation slices shadowed as fp16 pairs (a slice that
     starts at channel 10 of a tensor shares a 4-channel group with its neighbour), rows padded to 4 on the odd widths - against
     float64 autograd at the bars of the fp32 step."""
     from panoptic_forecasting_amd import lib as pflib
@@ -524,7 +524,7 @@ def test_mini_network_forward_on_packed_pairs_vs_autograd(size):
 
 def test_forward_on_packed_pairs_is_the_same_step_to_rounding():
     """The real network, fixture batch: with train_forward_s4 the 67 stride-1 conv + BatchNorm layers run on conv_s4 (path statistics),
-    the loss agrees to 1e-6, the gradients to the distance either step has from float64 (ReLU masks flip where a pre-activation
+    the loss agrees to 1e-5, the gradients to the distance either step has from float64 (ReLU masks flip where a pre-activation
     is closer to zero than the round-off: measured 0.9 % of the whole gradient's norm)."""
     from panoptic_forecasting_amd import lib as pflib
     from panoptic_forecasting_amd.bg_train import BGTrainer
@@ -546,7 +546,7 @@ def test_forward_on_packed_pairs_is_the_same_step_to_rounding():
         L.pf_set_option(b'train_forward_s4', 0)
     assert got[0][2]['packed_pair_forward_convs'] == 0 and got[1][2]['packed_pair_forward_convs'] >= 60, (got[0][2], got[1][2])
     assert got[1][2]['generic_kernel_launches'] == 0
-    assert abs(got[1][0] - got[0][0]) <= 1e-6 * abs(got[0][0])
+    assert abs(got[1][0] - got[0][0]) <= 1e-5 * abs(got[0][0])
     assert _rel(got[1][1], got[0][1]) <= 3e-2
 
 

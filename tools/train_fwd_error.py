@@ -28,6 +28,9 @@ ap.add_argument('--table-batch', type=int, default=8)
 ap.add_argument('--use-table', type=int, default=1)
 ap.add_argument('--blocked', type=int, default=1, help='option train_blocked_sum: per-round partial sums in the 3x3 convolutions (round 6)')
 a = ap.parse_args()
+for kv in filter(None, os.environ.get('PF_OPTS', '').split(',')):    # e.g. PF_OPTS=train_forward_s4=1
+    k, v = kv.split('=')
+    pflib.check(pflib.load().pf_set_option(k.encode(), int(v)), 'pf_set_option')
 h, w, b = a.size, a.width or a.size, a.batch
 with open(os.path.join(ROOT, 'tests', 'golden', 'calib_seed1234.json')) as f:
     sd = synth.make_state_dict(seed=1234, calib=json.load(f))
