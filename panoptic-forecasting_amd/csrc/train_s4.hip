@@ -1,18 +1,20 @@
-// Training step, forward pass on the packed-pair kernels (round 6).
+// Training step, forward pass on the packed-pair kernels (round 6; opt-in: option "train_forward_s4", training.forward_packed_pairs).
 //
 // The forward 3x3 stride-1 and 1x1 convolutions of a training step (models/bg/hardnet.py:16-25 under bg_model.py:73-89) are the
 // same functions the inference path runs on conv_s4 (every fp32 operand as two round-to-nearest fp16 terms, three products on
-// v_mfma_f32_16x16x32_f16, fp32 accumulation: conv_mfma.h - as far from float64 as the fp32 matrix instruction, ~5x its rate).
-// What training adds:
-//   * weights change every step: s4_pack_weights_dev_kernel packs them ON THE DEVICE from the fp32 arena (theta) into the layout
-//     pack_conv_weights_s4 (conv_s4.hip) produces on the host - same blocks, same rounding (tests/test_gpu_train.py pins one against
-//     the other through a whole step) - with ONE fixed scale 2^12 instead of a per-conv 2^k from max|w| (the kernel's 2^-k is a
-//     launch argument: a data-dependent scale would need the host to wait for the device).  |w| >= 16 does not fit fp16 then: the
-//     kernel stores NaN for such a weight, the loss of the step is NaN - loud, never a silently clipped weight;
+// v_mfma_f32_16x16x32_f16, fp32 accumulation: conv_mfma.h).  What training adds:
+//   * weights change every step: s4_pack_weights_dev_kernel packs them ON THE DEVICE from the fp32 arena (theta) into the block layout
+//     pack_conv_weights_s4 (conv_s4.hip) produces on the host (checked end to end against float64 autograd:
+//     tests/test_gpu_train.py::test_mini_network_forward_on_packed_pairs_vs_autograd) - with ONE fixed scale 2^12 instead of a per-conv 2^k
+//     from max|w| (the kernel's 2^-k is a launch argument: a data-dependent scale would need the host to wait for the device).
+//     |w| >= 16 does not fit fp16 then: the kernel stores NaN for such a weight, the loss of the step is NaN - loud, never a silently
+//     clipped weight;
 //   * activations are fp32 NCHW (BatchNorm, pooling, the weight gradients read them): s4_pack_act_kernel writes the packed-pair
 //     SHADOW of every slice a producer finishes, for the tensors a packed-pair convolution reads; odd-width levels (50, 25 pixels at
 //     800 x 800) get rows padded to a multiple of 4 with zero pad columns = the convolution's own zero padding (train_kernels.hip);
-//   * outputs stay fp32 (pre-BatchNorm y): conv_s4's fp32 epilogue.
+//   * outputs stay fp32 (pre-BatchNorm y): conv_s4's fp32 epilogue; the 3x3 layers run conv_s4_blocked_kernel (conv_s4_kernel.inc with
+//     KACC: per-round partial sums, like the fp32 step) - the forward pass is then 0.81-0.95 x as far from float64 as torch-CPU fp32.
+// Measured: profiles/r06_experiments.md (section 11).
 #include "conv_mfma.h"
 #include "conv_s4.h"
 #include "train_kernels.h"
