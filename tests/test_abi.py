@@ -47,3 +47,18 @@ def test_version_and_argument_errors_without_a_gpu():
     plan = ctypes.c_void_p()
     junk = ctypes.create_string_buffer(b'x' * 128, 128)
     assert L.pf_hardnet_plan_create(junk, 128, 36, 11, ctypes.byref(plan)) == -3          # PF_EBLOB
+
+
+def test_every_documented_option_name_is_accepted():
+    """include/pfhip.h documents the names pf_set_option takes: each is accepted (set to its documented default, so the process
+    keeps the library's behaviour), an unknown name is refused - the comment block and hardnet_plan.hip's table cannot drift apart."""
+    import re
+    text = open(os.path.join(ROOT, 'include', 'pfhip.h')).read()
+    block = text[:text.index('int pf_set_option(const char *name, int value);')]
+    block = block[block.rindex('/*'):]
+    opts = re.findall(r'^ \*   "([a-z0-9_]+)"\s*\(default (\d+)', block, re.M)
+    assert len(opts) >= 16 and ('train_forward_s4', '0') in opts and ('wgrad_taps', '1') in opts and ('fuse_pairs', '1') in opts
+    L = pflib.load()
+    for name, default in opts:
+        assert L.pf_set_option(name.encode(), int(default)) == 0, name
+    assert L.pf_set_option(b'no_such_option', 1) != 0
