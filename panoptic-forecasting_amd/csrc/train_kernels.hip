@@ -787,7 +787,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
         const int t = (int)(o % ks2);
         const int ci = (int)((o / ks2) % Cin), co = (int)(o / ((long long)ks2 * Cin));
         const long long at = ((long long)co * ci_pad + ci) * ks2 + t, stride = (long long)co_pad * ci_pad * ks2;
-        for (int k = j; k < slabs; k += 4) s += partial[k * stride + at];
+        // four independent chains per lane (slabs k, k + 4, k + 8, k + 12 of its residue class): the loads of a chain are dependent
+        // round trips to the L2, and a 91 -> 28 layer has 170 slabs; fixed order, so still bit-reproducible
+        const float *p = partial + at;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = j;
+        for (; k + 12 < slabs; k += 16) {
+            s += p[k * stride];
+            s1 += p[(k + 4) * stride];
+            s2 += p[(k + 8) * stride];
+            s3 += p[(k + 12) * stride];
+        }
+        for (; k < slabs; k += 4) s += p[k * stride];
+        s = (s + s1) + (s2 + s3);
     }
     sm[j][l] = s;
     __syncthreads();
